@@ -1,0 +1,38 @@
+# Build the gfx950 kernel library (product) and, for CPU-side kernel debugging only, the wave-simulator build.
+HIPCC      ?= /opt/rocm/bin/hipcc
+HOSTCXX    ?= /opt/rocm/lib/llvm/bin/clang++
+CSRC       := clip-lite_amd/csrc
+LIBDIR     := clip-lite_amd/lib
+SRCS       := $(wildcard $(CSRC)/*.hip)
+HDRS       := $(wildcard $(CSRC)/*.h) include/clite.h
+OBJS       := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))
+SIMOBJS    := $(patsubst $(CSRC)/%.hip,build/sim/%.o,$(SRCS)) build/sim/wavesim.o
+HIPFLAGS   := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wno-unused-value
+SIMFLAGS   := -x c++ -std=c++20 -O1 -g -fPIC -pthread -Itests/wavesim -Iinclude -I$(CSRC) -include tests/wavesim/wavesim.h -Wno-unknown-attributes -Wno-unused-value -Wno-psabi $(SIM_EXTRA)
+
+.PHONY: hip sim clean
+hip: $(LIBDIR)/libclite_hip.so
+sim: tests/wavesim/_build/libclite_sim.so
+
+$(LIBDIR)/libclite_hip.so: $(OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
+
+build/hip/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/hip
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+tests/wavesim/_build/libclite_sim.so: $(SIMOBJS)
+	@mkdir -p tests/wavesim/_build
+	$(HOSTCXX) -shared -fPIC -pthread -o $@ $(SIMOBJS) $(SIM_EXTRA)
+
+build/sim/%.o: $(CSRC)/%.hip $(HDRS) tests/wavesim/wavesim.h
+	@mkdir -p build/sim
+	$(HOSTCXX) $(SIMFLAGS) -c $< -o $@
+
+build/sim/wavesim.o: tests/wavesim/wavesim.cpp tests/wavesim/wavesim.h
+	@mkdir -p build/sim
+	$(HOSTCXX) -std=c++20 -O1 -g -fPIC -pthread -c $< -o $@
+
+clean:
+	rm -rf build $(LIBDIR)/*.so tests/wavesim/_build

@@ -1,0 +1,473 @@
+// Implicit-GEMM tile engine for gfx950: C[M,N] (+)= Aop[M,K] * Bop[N,K]^T, bf16 in, fp32 accumulate
+// on v_mfma_f32_32x32x16_bf16.
+//
+// One engine serves every dense contraction of the CLIP-Lite train step:
+//   * conv forward  (reference: torchvision ResNet convs behind encoder.py:36-65): A = NHWC activations
+//     gathered im2col-style, B = weights [Cout][R*S*Cin]
+//   * conv dgrad: A = dY gathered with transposed-conv geometry, B = weights read k-strided ("XC" image)
+//   * conv/linear wgrad: both operands are contracted over their slow (pixel / token) dimension, so both
+//     LDS images are [k][x] and the MFMA fragments come from ds_read_b64_tr_b16 transposed reads
+//   * every nn.Linear of BERT (encoder.py:165-196) and of the MI heads / priors (loss.py:12-53).
+//
+// Operand images in LDS:
+//   KC (k-contiguous in memory): [ROWS][BK] bf16, row pitch BK*2+16 B  -> conflict-free ds_read_b128 fragments
+//   XC (x-contiguous in memory, contraction index is the slow one): [BK][ROWS] bf16, pitch ROWS*2+64 B
+//       -> conflict-free ds_read_b64_tr_b16 (a 32-lane half covers 4 k-rows x 64 B on disjoint banks)
+// Staging is global -> VGPR (buffer loads: out-of-range = 0, which implements im2col padding, ragged
+// tile edges and K tails without branches) -> ds_write_b128, double-buffered, one barrier per K tile;
+// the loads of tile t+1 are issued before the MFMAs of tile t and written after them.
+#ifndef CLITE_IGEMM_H
+#define CLITE_IGEMM_H
+#include "intrin.h"
+#include "rng.h"
+#include "clite.h"
+
+namespace clite {
+
+struct FastDiv {  // q = n / d for n < 2^31, d >= 1 (host fills; see fastdiv_make)
+  uint32_t mul, shift, d;
+};
+DEV uint32_t fd_div(uint32_t n, FastDiv f) { return (umulhi32(n, f.mul) + n) >> f.shift; }
+
+// Geometry of a gathered NHWC tensor seen through a conv window. Element strides are explicit so the
+// 7x7 stem can be expressed on a pre-padded [N][Hp][Wp][4] image as a 7x1 window over 32 "virtual"
+// channels (8 adjacent pixels x 4 channels are contiguous in memory).
+struct ConvGeom {
+  int H, W, C;        // spatial extent and channel count (k-inner) of the gathered tensor
+  int sN, sH, sW;     // element strides of the gathered tensor
+  int RH, RW;         // spatial extent of the row space (output pixels for fwd/wgrad, input pixels for dgrad)
+  int R, S;           // window
+  int stride, pad;
+  int rows;           // N * RH * RW
+  FastDiv div_hw, div_w;  // by RH*RW and by RW
+};
+
+// ------------------------------------------------------------------------------------------------
+// KC gather loader: rows = pixels of the row space, k = (r, s, c) with c contiguous.
+// DGRAD=false: hi = rh*stride - pad + r.   DGRAD=true: hi = (rh + pad - r) / stride when divisible.
+template <int ROWS, int BK, bool DGRAD>
+struct GatherKC {
+  static constexpr int CPR = BK / 8;                 // 16-B chunks per row
+  static constexpr int NCH = ROWS * CPR / 256;       // chunks per thread
+  static constexpr int PITCH = BK * 2 + 16;
+  static constexpr int BYTES = ROWS * PITCH;
+  static constexpr bool XC = false;
+  const void* ptr;
+  uint32_t bytes;
+  ConvGeom g;
+
+  struct State {
+    rsrc_t rs;
+    int base[NCH], h0[NCH], w0[NCH];  // base = n*sN, or -1 when the row is out of range
+    int kc8;                          // element offset of this thread's chunk inside the K tile
+    int r, s, c0;
+  };
+  DEV void init(State& st, int row0, int tid, int t_begin) const {
+    st.rs = make_rsrc(ptr, bytes);
+    st.kc8 = (tid % CPR) * 8;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int row = row0 + (tid + 256 * i) / CPR;
+      if (row < g.rows) {
+        uint32_t n = fd_div(row, g.div_hw);
+        uint32_t rem = row - n * g.div_hw.d;
+        uint32_t rh = fd_div(rem, g.div_w);
+        uint32_t rw = rem - rh * g.div_w.d;
+        st.base[i] = n * g.sN;
+        if (DGRAD) { st.h0[i] = rh + g.pad; st.w0[i] = rw + g.pad; }
+        else { st.h0[i] = rh * g.stride - g.pad; st.w0[i] = rw * g.stride - g.pad; }
+      } else {
+        st.base[i] = -1; st.h0[i] = 0; st.w0[i] = 0;
+      }
+    }
+    int k0 = t_begin * BK;
+    int rs = k0 / g.C;
+    st.c0 = k0 - rs * g.C;
+    st.r = rs / g.S;
+    st.s = rs - st.r * g.S;
+  }
+  DEV void load(State& st, u32x4 (&regs)[NCH]) const {
+    int c = st.c0 + st.kc8;
+    bool kvalid = c < g.C && st.r < g.R;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int hi, wi;
+      bool v = kvalid && st.base[i] >= 0;
+      if (DGRAD) {
+        int hh = st.h0[i] - st.r, ww = st.w0[i] - st.s;
+        if (g.stride == 1) { hi = hh; wi = ww; }
+        else if (g.stride == 2) { v = v && ((hh | ww) & 1) == 0; hi = hh >> 1; wi = ww >> 1; }
+        else { v = v && hh % g.stride == 0 && ww % g.stride == 0; hi = hh / g.stride; wi = ww / g.stride; }
+        v = v && hh >= 0 && ww >= 0;
+      } else {
+        hi = st.h0[i] + st.r; wi = st.w0[i] + st.s;
+      }
+      v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+      uint32_t off = v ? (uint32_t)(st.base[i] + hi * g.sH + wi * g.sW + c) * 2u : OOB_OFF;
+      regs[i] = buf_load16(st.rs, off);
+    }
+    st.c0 += BK;
+    if (st.c0 >= g.C) { st.c0 = 0; if (++st.s == g.S) { st.s = 0; ++st.r; } }
+  }
+  DEV static void store(char* lds, int tid, const u32x4 (&regs)[NCH]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int c = tid + 256 * i;
+      *(u32x4*)(lds + (c / CPR) * PITCH + (c % CPR) * 16) = regs[i];
+    }
+  }
+  // MFMA 32x32x16 fragment for the 32-row block starting at x0, k-step ks (16 deep)
+  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
+    Chunk16 ch;
+    ch.u = *(const u32x4*)(lds + (x0 + (lane & 31)) * PITCH + (ks * 16 + 8 * (lane >> 5)) * 2);
+    return ch.h;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// XC strided loader: element (k, x) at ptr[(k0+krow)*ld + rs*Cx + x]; k = (rs, kk) with kk < Ck.
+// Serves: weights for dgrad (W[co][r][s][ci]: ld = R*S*Cin, Cx = Cin, Ck = Cout, RS = R*S),
+//         linear dgrad (W[n][k]: ld = K, Cx = K, Ck = N, RS = 1), wgrad's dY ([P][Cout]: ld = Cx = Cout, Ck = P).
+template <int COLS, int BK>
+struct StridedXC {
+  static constexpr int CPR = COLS / 8;
+  static constexpr int NCH = BK * CPR / 256;
+  static constexpr int RPS = 256 / CPR;              // k-rows per sweep of the block
+  static constexpr int PITCH = COLS * 2 + 64;
+  static constexpr int BYTES = BK * PITCH;
+  static constexpr bool XC = true;
+  const void* ptr;
+  uint32_t bytes;
+  int ld, Cx, Ck, RS;
+
+  struct State {
+    rsrc_t rs_;
+    int x, krow0;
+    bool xvalid;
+    int rs, k0;
+  };
+  DEV void init(State& st, int x0, int tid, int t_begin) const {
+    st.rs_ = make_rsrc(ptr, bytes);
+    st.x = x0 + (tid % CPR) * 8;
+    st.xvalid = st.x < Cx;
+    st.krow0 = tid / CPR;
+    int kk = t_begin * BK;
+    st.rs = (RS == 1) ? 0 : kk / Ck;
+    st.k0 = kk - st.rs * Ck;
+  }
+  DEV void load(State& st, u32x4 (&regs)[NCH]) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int k = st.k0 + st.krow0 + i * RPS;
+      bool v = st.xvalid && k < Ck && st.rs < RS;
+      uint32_t off = v ? (uint32_t)(k * ld + st.rs * Cx + st.x) * 2u : OOB_OFF;
+      regs[i] = buf_load16(st.rs_, off);
+    }
+    st.k0 += BK;
+    if (st.k0 >= Ck && RS > 1) { st.k0 = 0; ++st.rs; }
+  }
+  DEV static void store(char* lds, int tid, const u32x4 (&regs)[NCH]) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+      *(u32x4*)(lds + (tid / CPR + i * RPS) * PITCH + (tid % CPR) * 16) = regs[i];
+  }
+  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
+    // lane 4q+p of each 16-lane group addresses k-row q, columns 4p..4p+3 of a [4 k][16 x] block
+    int x = x0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    int k = ks * 16 + 8 * (lane >> 5) + ((lane >> 2) & 3);
+    const char* p = lds + k * PITCH + x * 2;
+    s16x4 lo = lds_read_tr16(p);
+    s16x4 hi = lds_read_tr16(p + 4 * PITCH);
+    union { s16x4 v[2]; bf16x8 h; } u;
+    u.v[0] = lo; u.v[1] = hi;
+    return u.h;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// XC gather loader (wgrad's activation operand): k = output pixel p -> (n, ho, wo); x = (r, s, ci).
+template <int COLS, int BK>
+struct GatherXC {
+  static constexpr int CPR = COLS / 8;
+  static constexpr int NCH = BK * CPR / 256;
+  static constexpr int RPS = 256 / CPR;
+  static constexpr int PITCH = COLS * 2 + 64;
+  static constexpr int BYTES = BK * PITCH;
+  static constexpr bool XC = true;
+  const void* ptr;
+  uint32_t bytes;
+  ConvGeom g;   // rows = N*Ho*Wo pixels (the contraction index); RH,RW = Ho,Wo
+
+  struct State {
+    rsrc_t rs_;
+    int xoff;      // r*sH + s*sW + ci, or -1 if this column is out of range
+    int r, s;
+    int krow0, p0;
+  };
+  DEV void init(State& st, int x0, int tid, int t_begin) const {
+    st.rs_ = make_rsrc(ptr, bytes);
+    int x = x0 + (tid % CPR) * 8;
+    int rs = x / g.C;
+    int ci = x - rs * g.C;
+    st.r = rs / g.S;
+    st.s = rs - st.r * g.S;
+    st.xoff = (x < g.R * g.S * g.C) ? ci : -1;
+    st.krow0 = tid / CPR;
+    st.p0 = t_begin * BK;
+  }
+  DEV void load(State& st, u32x4 (&regs)[NCH]) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      int p = st.p0 + st.krow0 + i * RPS;
+      bool v = st.xoff >= 0 && p < g.rows;
+      uint32_t n = fd_div(p, g.div_hw);
+      uint32_t rem = p - n * g.div_hw.d;
+      uint32_t ho = fd_div(rem, g.div_w);
+      uint32_t wo = rem - ho * g.div_w.d;
+      int hi = (int)ho * g.stride - g.pad + st.r;
+      int wi = (int)wo * g.stride - g.pad + st.s;
+      v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+      uint32_t off = v ? (uint32_t)((int)n * g.sN + hi * g.sH + wi * g.sW + st.xoff) * 2u : OOB_OFF;
+      regs[i] = buf_load16(st.rs_, off);
+    }
+    st.p0 += BK;
+  }
+  DEV static void store(char* lds, int tid, const u32x4 (&regs)[NCH]) {
+    StridedXC<COLS, BK>::store(lds, tid, regs);
+  }
+  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
+    return StridedXC<COLS, BK>::frag(lds, x0, ks, lane);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue description (runtime flags; all branches are block-uniform).
+enum { ACT_NONE = CLITE_ACT_NONE, ACT_RELU = CLITE_ACT_RELU, ACT_GELU = CLITE_ACT_GELU, ACT_TANH = CLITE_ACT_TANH };
+typedef clite_epilogue Epilogue;   // layout and semantics: include/clite.h
+
+DEV float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+DEV float gelu_grad_f(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+template <int BM_, int BN_, int BK_, int WM_, int WN_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+  static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
+  static constexpr int RM = WM / 32, RN = WN / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroups");
+  static constexpr int EPI_PITCH = BN * 4 + 16;
+  static constexpr int EPI_BYTES = WM * EPI_PITCH;
+};
+
+template <class CFG, class LA, class LB>
+__global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, int M, int N, int ktiles, int ktiles_per_split) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int SMEM = (2 * STAGE > CFG::EPI_BYTES) ? 2 * STAGE : CFG::EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+
+  // XCD-aware tile order: workgroups b and b+8 share an XCD (and its 4 MiB L2) under round-robin dispatch, so give
+  // each XCD a contiguous run of logical tiles (bijective for any grid size); placement affects speed only.
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tm = wg / tiles_n;
+  const int tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t_begin = blockIdx.z * ktiles_per_split;
+  int t_end = t_begin + ktiles_per_split;
+  if (t_end > ktiles) t_end = ktiles;
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, tid, t_begin);
+  lb.init(sb, n0, tid, t_begin);
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[LA::NCH], rb[LB::NCH];
+  if (t_begin < t_end) {
+    la.load(sa, ra);
+    lb.load(sb, rb);
+    LA::store(smem, tid, ra);
+    LB::store(smem + LA::BYTES, tid, rb);
+  }
+  __syncthreads();
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    const bool more = t + 1 < t_end;
+    if (more) {
+      la.load(sa, ra);
+      lb.load(sb, rb);
+    }
+    const char* abuf = smem + cur * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[RM], bfr[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) af[i] = LA::frag(abuf, wm0 + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) bfr[j] = LB::frag(bbuf, wn0 + j * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+    }
+    if (more) {
+      char* nbuf = smem + (cur ^ 1) * STAGE;
+      LA::store(nbuf, tid, ra);
+      LB::store(nbuf + LA::BYTES, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  if (ep.atomic) {
+    float* out = (float*)ep.out;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j) {
+        int col = n0 + wn0 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (row < M && col < N) atomic_add_f32(out + (size_t)row * ep.ldc + col, ep.alpha * acc[i][j][r]);
+        }
+      }
+    return;
+  }
+
+  constexpr int CPRE = BN / 8;          // 8-column chunks per tile row
+  constexpr int RPSE = 256 / CPRE;      // rows per sweep
+  const int ecol = (tid % CPRE) * 8;
+  const int erow0 = tid / CPRE;
+  const float keep_scale = ep.drop_p > 0.f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+  float csum[8], csq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; }
+
+  for (int pass = 0; pass < CFG::WAVES_M; ++pass) {
+    if (wave / CFG::WAVES_N == pass) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            int col = wn0 + j * 32 + (lane & 31);
+            *(float*)(smem + row * CFG::EPI_PITCH + col * 4) = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    const int gcol = n0 + ecol;
+    if (gcol < N) {
+      float bias[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias[e] = ep.bias ? ep.bias[gcol + e] : 0.f;
+      for (int rr = erow0; rr < CFG::WM; rr += RPSE) {
+        int grow = m0 + pass * CFG::WM + rr;
+        if (grow >= M) break;
+        const float* src = (const float*)(smem + rr * CFG::EPI_PITCH + ecol * 4);
+        f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        size_t gidx = (size_t)grow * ep.ldc + gcol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
+        if (ep.preact) {
+          Chunk16 pc;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pc.e[e] = f2bf(v[e]);
+          *(u32x4*)((bf16*)ep.preact + gidx) = pc.u;
+        }
+        if (ep.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (ep.act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (ep.act == ACT_TANH) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+        }
+        if (ep.dact_aux) {
+          Chunk16 ac;
+          ac.u = *(const u32x4*)((const bf16*)ep.dact_aux + gidx);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float a = bf2f(ac.e[e]);
+            float d = ep.dact == 1 ? (a > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_f(a) : (1.f - a * a);
+            v[e] *= d;
+          }
+        }
+        if (ep.drop_p > 0.f) {
+          float u[8];
+          dropout_uniform8(ep.drop_seed, ep.drop_site, gidx, u);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = u[e] >= ep.drop_p ? v[e] * keep_scale : 0.f;
+        }
+        if (ep.residual) {
+          Chunk16 rc;
+          rc.u = *(const u32x4*)((const bf16*)ep.residual + gidx);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf2f(rc.e[e]);
+        }
+        if (ep.out_f32) {
+          float* o = (float*)ep.out + gidx;
+          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+          *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+          Chunk16 oc;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) oc.e[e] = f2bf(v[e]);
+          *(u32x4*)((bf16*)ep.out + gidx) = oc.u;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = bf2f(oc.e[e]);   // statistics of what was stored
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (ep.colsum) {
+    // threads sharing a column chunk are tid, tid+CPRE, ...: fold them through LDS, one atomic per column
+    float* red = (float*)smem;                      // [RPSE][CPRE*16]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + e] = csum[e];
+      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + 8 + e] = csq[e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < CPRE * 16; idx += 256) {
+      float s = 0.f;
+      for (int r = 0; r < RPSE; ++r) s += red[r * (CPRE * 16) + idx];
+      int chunk = idx / 16, e = idx % 16;
+      int col = n0 + chunk * 8 + (e & 7);
+      if (col < N) atomic_add_f32(ep.colsum + (e >= 8 ? N : 0) + col, s);
+    }
+  }
+}
+
+}  // namespace clite
+#endif  // CLITE_IGEMM_H

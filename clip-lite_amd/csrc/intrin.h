@@ -1,0 +1,91 @@
+// gfx950 (CDNA4) intrinsic wrappers used by every kernel in csrc/.
+//
+// Kernels never spell __builtin_amdgcn_* directly; they go through these thin
+// inline wrappers so that the wavefront simulator used by the CPU-side kernel
+// tests (tests/wavesim/, test infrastructure only) can supply lane-accurate
+// emulations of the same names. This header is the ONLY definition the shipped
+// library is built with.
+#ifndef CLITE_INTRIN_H
+#define CLITE_INTRIN_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DEV __device__ __forceinline__
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define WAVE 64
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+// Buffer resource over [ptr, ptr+bytes): loads past the end return 0, stores
+// past the end are dropped by hardware (raw buffer, stride 0).
+DEV rsrc_t make_rsrc(const void* ptr, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, (int)bytes, 0x00020000);
+}
+// Byte offset that is out of range for every buffer (<4 GiB): reads as zero.
+#define OOB_OFF 0xFFFFFFF0u
+
+DEV u32x4 buf_load16(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
+DEV u32x2 buf_load8(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
+DEV uint32_t buf_load4(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+DEV void buf_store16(rsrc_t r, uint32_t off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0); }
+DEV void buf_store8(rsrc_t r, uint32_t off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0); }
+DEV void buf_store4(rsrc_t r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 0); }
+
+// v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k 8*(l>>5)+j], B[k 8*(l>>5)+j][col l&31];
+// D reg i of lane l = D[row (i&3)+8*(i>>2)+4*(l>>5)][col l&31].
+DEV f32x16 mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_32x32x2_f32 (exact f32): lane l holds A[row l&31][k l>>5], B[k l>>5][col l&31].
+DEV f32x16 mfma32_f32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q,
+// columns 4p..4p+3 of a 4x16 block of 16-bit elements; lane i receives column i
+// (rows 0..3 in elements 0..3). Address must be 8-byte aligned, EXEC all ones.
+DEV s16x4 lds_read_tr16(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+
+DEV float bf2f(bf16 x) { return (float)x; }
+DEV bf16 f2bf(float x) { return (bf16)x; }   // round-to-nearest-even (v_cvt_pk_bf16_f32)
+
+DEV float wave_shfl_xor(float v, int m) { return __shfl_xor(v, m, WAVE); }
+DEV int wave_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, WAVE); }
+DEV float wave_shfl(float v, int src) { return __shfl(v, src, WAVE); }
+
+DEV float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += wave_shfl_xor(v, m);
+  return v;
+}
+DEV float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, wave_shfl_xor(v, m));
+  return v;
+}
+
+DEV void atomic_add_f32(float* p, float v) { atomicAdd(p, v); }
+
+DEV uint32_t umulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+// pack / unpack helpers on 16-byte chunks of 8 bf16
+union Chunk16 {
+  u32x4 u;
+  bf16x8 h;
+  bf16 e[8];
+};
+
+#endif  // CLITE_INTRIN_H

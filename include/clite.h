@@ -1,0 +1,78 @@
+/* clite.h — C ABI of libclite_hip.so, the MI355X (gfx950) kernel library behind the CLIP-Lite
+ * pretraining step.
+ *
+ * The reference (4m4n5/CLIP-Lite) has no native layer: its hot path is Python calling ATen/cuDNN/cuBLAS.
+ * Every entry point below therefore cites the reference *call site* whose device math it replaces
+ * (file:line relative to the reference repository). The host side that mirrors the reference's Python
+ * classes lives in clip-lite_amd/ and reaches these functions through ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are device pointers owned by the caller
+ *   - bf16 tensors are passed as void*; "f32" means IEEE binary32
+ *   - activations are NHWC / row-major [rows][features]; weights are [out][...in], inner dim contiguous
+ *   - `stream` is a hipStream_t; kernels are only enqueued, nothing synchronises, nothing allocates
+ *   - return value: 0 on success, a hipError_t value or -1 (bad argument) otherwise; nothing throws
+ *   - entry points are re-entrant and hold no global mutable state (forward runs on the Python main
+ *     thread, backward on the autograd engine thread)
+ */
+#ifndef CLITE_H
+#define CLITE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLITE_ABI_VERSION 1
+int clite_abi_version(void);
+
+enum { CLITE_ACT_NONE = 0, CLITE_ACT_RELU = 1, CLITE_ACT_GELU = 2, CLITE_ACT_TANH = 3 };
+
+/* Fused GEMM epilogue. v = alpha*acc + bias; preact <- v; v = act(v); v *= act'(dact_aux);
+ * v = dropout(v); v += residual; out <- v; colsum += (sum, sum of squares) of the stored values. */
+typedef struct clite_epilogue {
+  void* out;            /* [M][ldc] bf16 (out_f32 = 0) or f32 (out_f32 = 1) */
+  int32_t ldc;
+  int32_t out_f32;
+  int32_t atomic;       /* 1: out (f32) += alpha*acc with float atomics (split-K / gradient accumulation) */
+  float alpha;
+  const float* bias;    /* [N] f32 or NULL */
+  int32_t act;          /* CLITE_ACT_* */
+  void* preact;         /* bf16 [M][ldc] or NULL */
+  const void* dact_aux; /* bf16 [M][ldc] or NULL */
+  int32_t dact;         /* 1 relu' (aux = forward output), 2 gelu' (aux = pre-activation), 3 tanh' (aux = output) */
+  float drop_p;
+  uint64_t drop_seed;
+  uint32_t drop_site;
+  const void* residual; /* bf16 [M][ldc] or NULL */
+  float* colsum;        /* f32 [2][N] or NULL */
+} clite_epilogue;
+
+/* NHWC convolution problem. x: [N][H][W][C] bf16, w: [K][R][S][C] bf16, y: [N][Ho][Wo][K] bf16. */
+typedef struct clite_conv {
+  int32_t N, H, W, C;
+  int32_t K, R, S;
+  int32_t stride, pad;
+  int32_t Ho, Wo;
+} clite_conv;
+
+/* C[M,N] = A[M,K] * B[N,K]^T  — nn.Linear forward (reference loss.py:16-22,46-48; HF BertModel linears
+ * behind encoder.py:193). K % 8 == 0, N % 8 == 0. */
+int clite_gemm_nt(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream);
+/* C[M,N] = A[M,K] * B[K,N]       — nn.Linear input gradient (autograd of the same call sites). */
+int clite_gemm_nn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream);
+/* C[M,N] (+)= A[K,M]^T * B[K,N]  — nn.Linear weight gradient; ep->atomic selects f32 accumulation. */
+int clite_gemm_tn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream);
+
+/* y = conv(x, w): torchvision ResNet nn.Conv2d forward (reference encoder.py:36-38,63; block arithmetic as
+ * restated in model_zoo/resnet.py:60-100). Epilogue applies to y viewed as [N*Ho*Wo][K]. */
+int clite_conv_fwd(const void* x, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream);
+/* dx = conv_transpose(dy, w): autograd of the same call. Epilogue applies to dx viewed as [N*H*W][C]. */
+int clite_conv_dgrad(const void* dy, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream);
+/* dw[K][R][S][C] (f32) += dy^T * im2col(x): autograd of the same call; float-atomic split-K. */
+int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLITE_H */

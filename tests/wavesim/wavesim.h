@@ -1,0 +1,293 @@
+// wavesim — TEST INFRASTRUCTURE ONLY. Never linked into the shipped library.
+//
+// A lane-accurate host emulation of the small HIP/gfx950 subset that the kernels in
+// clip-lite_amd/csrc use, so kernel index math (LDS images, MFMA operand maps,
+// transposed LDS reads, buffer bounds) can be debugged on the CPU build box, which
+// has no GPU, and run under host AddressSanitizer. One OS thread per GPU thread,
+// workgroups run one after another; wave-collective operations (MFMA, ds_read_tr,
+// shuffles) rendezvous on a per-wave barrier.
+//
+// Built by tests/wavesim/Makefile with `clang++ -x c++ -include wavesim.h`; this
+// header pre-defines CLITE_INTRIN_H so csrc/intrin.h's device definitions are
+// skipped and the emulations below are used instead.
+#ifndef CLITE_WAVESIM_H
+#define CLITE_WAVESIM_H
+#define CLITE_INTRIN_H  // shadow csrc/intrin.h
+
+#include <atomic>
+#include <barrier>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+#define DEV inline __attribute__((always_inline))
+#define WAVE 64
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
+  memset(p, v, n);
+  return hipSuccess;
+}
+
+namespace wavesim {
+struct WaveCtx {
+  std::unique_ptr<std::barrier<>> bar;
+  uint64_t slot[64][8];  // per-lane exchange area (up to 64 B per lane)
+};
+struct BlockCtx {
+  std::unique_ptr<std::barrier<>> bar;
+  std::vector<WaveCtx> waves;
+};
+extern thread_local BlockCtx* g_block;
+extern thread_local int g_lane;
+extern thread_local int g_wave;
+}  // namespace wavesim
+
+extern thread_local dim3 threadIdx;
+extern thread_local dim3 blockIdx;
+extern thread_local dim3 blockDim;
+extern thread_local dim3 gridDim;
+
+inline void __syncthreads() { wavesim::g_block->bar->arrive_and_wait(); }
+inline void wave_barrier_() { wavesim::g_block->waves[wavesim::g_wave].bar->arrive_and_wait(); }
+
+template <class K, class... Args>
+void wavesim_launch(K kernel, dim3 grid, dim3 block, Args... args) {
+  unsigned nthreads = block.x * block.y * block.z;
+  assert(block.y == 1 && block.z == 1 && "wavesim: 1-D blocks only");
+  assert(nthreads % 64 == 0 && "wavesim: block size must be a multiple of 64");
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        wavesim::BlockCtx ctx;
+        ctx.bar = std::make_unique<std::barrier<>>(nthreads);
+        ctx.waves.resize(nthreads / 64);
+        for (auto& w : ctx.waves) w.bar = std::make_unique<std::barrier<>>(64);
+        std::vector<std::thread> ts;
+        ts.reserve(nthreads);
+        for (unsigned t = 0; t < nthreads; ++t) {
+          ts.emplace_back([&, t]() {
+            threadIdx = dim3(t, 0, 0);
+            blockIdx = dim3(bx, by, bz);
+            blockDim = block;
+            gridDim = grid;
+            wavesim::g_block = &ctx;
+            wavesim::g_lane = t & 63;
+            wavesim::g_wave = t >> 6;
+            kernel(args...);
+          });
+        }
+        for (auto& th : ts) th.join();
+      }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  wavesim_launch(kernel, dim3(grid), dim3(block), ##__VA_ARGS__)
+
+// ---------------------------------------------------------------- types
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+union Chunk16 {
+  u32x4 u;
+  bf16x8 h;
+  bf16 e[8];
+};
+
+// ---------------------------------------------------------------- buffer resources
+struct rsrc_t {
+  char* base;
+  uint32_t bytes;
+};
+#define OOB_OFF 0xFFFFFFF0u
+inline rsrc_t make_rsrc(const void* p, uint32_t bytes) { return rsrc_t{(char*)p, bytes}; }
+inline bool wavesim_in_range(rsrc_t r, uint32_t off, uint32_t n, const char* what) {
+  if ((uint64_t)off + n <= r.bytes) return true;
+  // Kernels mark intentional zero-fill with OOB_OFF-based offsets (>= 0x80000000).
+  // Any other out-of-range access is an indexing bug: fail loudly in the simulator.
+  if (off < 0x80000000u) {
+    fprintf(stderr, "wavesim: unintended out-of-range buffer %s: off=%u n=%u size=%u (block %u thread %u)\n",
+            what, off, n, r.bytes, blockIdx.x, threadIdx.x);
+    abort();
+  }
+  return false;
+}
+template <class T>
+inline T wavesim_buf_load(rsrc_t r, uint32_t off) {
+  T v;
+  memset(&v, 0, sizeof(T));
+  if (wavesim_in_range(r, off, sizeof(T), "load")) memcpy(&v, r.base + off, sizeof(T));
+  return v;
+}
+template <class T>
+inline void wavesim_buf_store(rsrc_t r, uint32_t off, T v) {
+  if (wavesim_in_range(r, off, sizeof(T), "store")) memcpy(r.base + off, &v, sizeof(T));
+}
+inline u32x4 buf_load16(rsrc_t r, uint32_t off) { assert(off % 4 == 0); return wavesim_buf_load<u32x4>(r, off); }
+inline u32x2 buf_load8(rsrc_t r, uint32_t off) { assert(off % 4 == 0); return wavesim_buf_load<u32x2>(r, off); }
+inline uint32_t buf_load4(rsrc_t r, uint32_t off) { assert(off % 4 == 0); return wavesim_buf_load<uint32_t>(r, off); }
+inline void buf_store16(rsrc_t r, uint32_t off, u32x4 v) { assert(off % 4 == 0); wavesim_buf_store(r, off, v); }
+inline void buf_store8(rsrc_t r, uint32_t off, u32x2 v) { assert(off % 4 == 0); wavesim_buf_store(r, off, v); }
+inline void buf_store4(rsrc_t r, uint32_t off, uint32_t v) { assert(off % 4 == 0); wavesim_buf_store(r, off, v); }
+
+// ---------------------------------------------------------------- conversions
+inline float bf2f(bf16 x) {
+  uint16_t b;
+  memcpy(&b, &x, 2);
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline bf16 f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  uint16_t b;
+  if ((u & 0x7fffffffu) > 0x7f800000u) b = (uint16_t)((u >> 16) | 0x40);
+  else b = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  bf16 r;
+  memcpy(&r, &b, 2);
+  return r;
+}
+
+// ---------------------------------------------------------------- wave collectives
+inline float wave_shfl(float v, int src) {
+  auto& w = wavesim::g_block->waves[wavesim::g_wave];
+  memcpy(&w.slot[wavesim::g_lane][0], &v, 4);
+  wave_barrier_();
+  float r;
+  memcpy(&r, &w.slot[src & 63][0], 4);
+  wave_barrier_();
+  return r;
+}
+inline float wave_shfl_xor(float v, int m) { return wave_shfl(v, wavesim::g_lane ^ m); }
+inline int wave_shfl_xor_i(int v, int m) {
+  float f;
+  memcpy(&f, &v, 4);
+  f = wave_shfl_xor(f, m);
+  int r;
+  memcpy(&r, &f, 4);
+  return r;
+}
+inline float wave_sum(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v += wave_shfl_xor(v, m);
+  return v;
+}
+inline float wave_max(float v) {
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, wave_shfl_xor(v, m));
+  return v;
+}
+
+// v_mfma_f32_32x32x16_bf16, operand maps per cdna_hip_programming.md §3.
+inline f32x16 mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  auto& w = wavesim::g_block->waves[wavesim::g_wave];
+  int l = wavesim::g_lane;
+  memcpy(&w.slot[l][0], &a, 16);
+  memcpy(&w.slot[l][2], &b, 16);
+  wave_barrier_();
+  int col = l & 31;
+  for (int i = 0; i < 16; ++i) {
+    int row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+    float acc = c[i];
+    for (int k = 0; k < 16; ++k) {
+      bf16x8 av, bv;
+      memcpy(&av, &w.slot[row + 32 * (k >> 3)][0], 16);  // A[row][k] lives in lane row+32*(k/8), elem k%8
+      memcpy(&bv, &w.slot[col + 32 * (k >> 3)][2], 16);  // B[k][col] lives in lane col+32*(k/8), elem k%8
+      acc = fmaf(bf2f(av[k & 7]), bf2f(bv[k & 7]), acc);
+    }
+    c[i] = acc;
+  }
+  wave_barrier_();
+  return c;
+}
+// v_mfma_f32_32x32x2_f32
+inline f32x16 mfma32_f32(float a, float b, f32x16 c) {
+  auto& w = wavesim::g_block->waves[wavesim::g_wave];
+  int l = wavesim::g_lane;
+  memcpy(&w.slot[l][0], &a, 4);
+  memcpy(&w.slot[l][1], &b, 4);
+  wave_barrier_();
+  int col = l & 31;
+  for (int i = 0; i < 16; ++i) {
+    int row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+    float acc = c[i];
+    for (int k = 0; k < 2; ++k) {
+      float av, bv;
+      memcpy(&av, &w.slot[row + 32 * k][0], 4);
+      memcpy(&bv, &w.slot[col + 32 * k][1], 4);
+      acc = fmaf(av, bv, acc);
+    }
+    c[i] = acc;
+  }
+  wave_barrier_();
+  return c;
+}
+
+// ds_read_b64_tr_b16 per cdna_hip_programming.md §5.5 T10: inside each group of 16
+// consecutive lanes, lane 4q+p supplies the address of row q, columns 4p..4p+3 of a
+// 4x16 block of 16-bit elements; lane i receives column i, row q in element q.
+inline s16x4 lds_read_tr16(const void* p) {
+  auto& w = wavesim::g_block->waves[wavesim::g_wave];
+  int l = wavesim::g_lane;
+  assert(((uintptr_t)p & 7) == 0 && "ds_read_b64_tr_b16 needs an 8-byte aligned address");
+  uint64_t addr = (uint64_t)(uintptr_t)p;
+  w.slot[l][0] = addr;
+  wave_barrier_();
+  int g = l & ~15, i = l & 15;
+  s16x4 r;
+  for (int q = 0; q < 4; ++q) {
+    int src_lane = g + 4 * q + (i >> 2);
+    const short* row = (const short*)(uintptr_t)w.slot[src_lane][0];
+    r[q] = row[i & 3];
+  }
+  wave_barrier_();
+  return r;
+}
+
+inline void atomic_add_f32(float* p, float v) {
+  std::atomic_ref<float> a(*p);
+  float old = a.load();
+  while (!a.compare_exchange_weak(old, old + v)) {
+  }
+}
+inline float atomicAdd(float* p, float v) {
+  std::atomic_ref<float> a(*p);
+  float old = a.load();
+  while (!a.compare_exchange_weak(old, old + v)) {
+  }
+  return old;
+}
+inline uint32_t umulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __expf(float x) { return expf(x); }
+inline float __logf(float x) { return logf(x); }
+
+#endif  // CLITE_WAVESIM_H
