@@ -29,10 +29,13 @@ ConvGeom geom_dense(int rows, int K) {  // [rows][K] row-major seen as a 1x1 win
 
 bool fits32(size_t elems, size_t esize) { return elems * esize < 0xF0000000ull; }
 
-typedef TileCfg<128, 128, 32, 64, 64> Cfg128;
-typedef TileCfg<256, 64, 32, 64, 64> Cfg256x64;
+template <typename T> struct Cfg {
+  static constexpr int BK = 64 / (int)sizeof(T);        // 64 bytes of K per tile row: bf16 -> 32, f32 -> 16
+  typedef TileCfg<128, 128, BK, 64, 64> C128;
+  typedef TileCfg<256, 64, BK, 64, 64> C256x64;
+};
 
-template <class CFG, class LA, class LB>
+template <typename T, class CFG, class LA, class LB>
 int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, int Ktot, int splits, hipStream_t st) {
   int ktiles = (Ktot + CFG::BK - 1) / CFG::BK;
   if (splits < 1) splits = 1;
@@ -40,12 +43,12 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
   int per = (ktiles + splits - 1) / splits;
   splits = (ktiles + per - 1) / per;
   int tiles = ((M + CFG::BM - 1) / CFG::BM) * ((N + CFG::BN - 1) / CFG::BN);
-  hipLaunchKernelGGL((igemm_kernel<CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, M, N, ktiles, per);
+  hipLaunchKernelGGL((igemm_kernel<T, CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, M, N, ktiles, per);
   return (int)hipGetLastError();
 }
 
-int pick_splits(int M, int N, int BM, int BN, int ktiles) {
-  long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+int pick_splits(int M, int N, int ktiles) {
+  long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
   long want = 1024 / tiles;      // ~4 workgroups per CU
   if (want < 1) want = 1;
   if (want > ktiles) want = ktiles;
@@ -59,59 +62,54 @@ int check_ep(const clite_epilogue* ep, int N) {
   return 0;
 }
 
-}  // namespace
-
-extern "C" int clite_abi_version(void) { return CLITE_ABI_VERSION; }
-
-extern "C" int clite_gemm_nt(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream) {
-  if (check_ep(ep, N) || M <= 0 || N <= 0 || K <= 0 || K % 8) return -1;
-  if (!fits32((size_t)M * K, 2) || !fits32((size_t)N * K, 2)) return -1;
-  hipStream_t st = (hipStream_t)stream;
-  int splits = ep->atomic ? pick_splits(M, N, 128, 128, (K + 31) / 32) : 1;
+template <typename T>
+int gemm_nt(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
+  uint32_t ab = (uint32_t)((size_t)M * K * sizeof(T)), bb = (uint32_t)((size_t)N * K * sizeof(T));
+  int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
   if (N <= 64) {
-    GatherKC<256, 32, false> la{A, (uint32_t)((size_t)M * K * 2), geom_dense(M, K)};
-    GatherKC<64, 32, false> lb{B, (uint32_t)((size_t)N * K * 2), geom_dense(N, K)};
-    return launch<Cfg256x64>(la, lb, *ep, M, N, K, splits, st);
+    GatherKC<T, 256, BK, false> la{A, ab, geom_dense(M, K)};
+    GatherKC<T, 64, BK, false> lb{B, bb, geom_dense(N, K)};
+    return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, N, K, splits, st);
   }
-  GatherKC<128, 32, false> la{A, (uint32_t)((size_t)M * K * 2), geom_dense(M, K)};
-  GatherKC<128, 32, false> lb{B, (uint32_t)((size_t)N * K * 2), geom_dense(N, K)};
-  return launch<Cfg128>(la, lb, *ep, M, N, K, splits, st);
+  GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K)};
+  GatherKC<T, 128, BK, false> lb{B, bb, geom_dense(N, K)};
+  return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, N, K, splits, st);
 }
 
-extern "C" int clite_gemm_nn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream) {
-  if (check_ep(ep, N) || M <= 0 || N <= 0 || K <= 0 || K % 8) return -1;
-  if (!fits32((size_t)M * K, 2) || !fits32((size_t)N * K, 2)) return -1;
-  hipStream_t st = (hipStream_t)stream;
-  int splits = ep->atomic ? pick_splits(M, N, 128, 128, (K + 31) / 32) : 1;
+template <typename T>
+int gemm_nn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
+  uint32_t ab = (uint32_t)((size_t)M * K * sizeof(T)), bb = (uint32_t)((size_t)N * K * sizeof(T));
+  int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
   if (N <= 64) {
-    GatherKC<256, 32, false> la{A, (uint32_t)((size_t)M * K * 2), geom_dense(M, K)};
-    StridedXC<64, 32> lb{B, (uint32_t)((size_t)N * K * 2), N, N, K, 1};
-    return launch<Cfg256x64>(la, lb, *ep, M, N, K, splits, st);
+    GatherKC<T, 256, BK, false> la{A, ab, geom_dense(M, K)};
+    StridedXC<T, 64, BK> lb{B, bb, N, N, K, 1};
+    return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, N, K, splits, st);
   }
-  GatherKC<128, 32, false> la{A, (uint32_t)((size_t)M * K * 2), geom_dense(M, K)};
-  StridedXC<128, 32> lb{B, (uint32_t)((size_t)N * K * 2), N, N, K, 1};
-  return launch<Cfg128>(la, lb, *ep, M, N, K, splits, st);
+  GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K)};
+  StridedXC<T, 128, BK> lb{B, bb, N, N, K, 1};
+  return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, N, K, splits, st);
 }
 
-extern "C" int clite_gemm_tn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream) {
-  if (check_ep(ep, N) || M <= 0 || N <= 0 || K <= 0 || M % 8 || N % 8) return -1;
-  if (!fits32((size_t)M * K, 2) || !fits32((size_t)N * K, 2)) return -1;
-  hipStream_t st = (hipStream_t)stream;
-  int splits = ep->atomic ? pick_splits(M, N, 128, 128, (K + 31) / 32) : 1;
-  StridedXC<128, 32> la{A, (uint32_t)((size_t)M * K * 2), M, M, K, 1};
-  StridedXC<128, 32> lb{B, (uint32_t)((size_t)N * K * 2), N, N, K, 1};
-  return launch<Cfg128>(la, lb, *ep, M, N, K, splits, st);
+template <typename T>
+int gemm_tn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
+  uint32_t ab = (uint32_t)((size_t)M * K * sizeof(T)), bb = (uint32_t)((size_t)N * K * sizeof(T));
+  int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
+  StridedXC<T, 128, BK> la{A, ab, M, M, K, 1};
+  StridedXC<T, 128, BK> lb{B, bb, N, N, K, 1};
+  return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, N, K, splits, st);
 }
 
-// ------------------------------------------------------------------------------------------------ conv
-namespace {
 int check_conv(const clite_conv* c) {
   if (!c) return -1;
+  if (c->dtype != CLITE_BF16 && c->dtype != CLITE_F32) return -1;
   if (c->C % 8 || c->K % 8) return -1;
   if (c->R * c->S > 1 && (c->C % 32 || c->K % 32)) return -1;   // a K tile must stay inside one (r,s)
   if (c->Ho != (c->H + 2 * c->pad - c->R) / c->stride + 1) return -1;
   if (c->Wo != (c->W + 2 * c->pad - c->S) / c->stride + 1) return -1;
-  if (!fits32((size_t)c->N * c->H * c->W * c->C, 2) || !fits32((size_t)c->N * c->Ho * c->Wo * c->K, 2)) return -1;
+  if (!fits32((size_t)c->N * c->H * c->W * c->C, 4) || !fits32((size_t)c->N * c->Ho * c->Wo * c->K, 4)) return -1;
   return 0;
 }
 ConvGeom geom_fwd(const clite_conv& c) {   // rows = output pixels, gather x
@@ -134,50 +132,82 @@ ConvGeom geom_dgrad(const clite_conv& c) {  // rows = input pixels, gather dy
   g.div_w = fastdiv_make(c.W);
   return g;
 }
-}  // namespace
 
-extern "C" int clite_conv_fwd(const void* x, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
-  if (check_conv(cv) || check_ep(ep, cv->K)) return -1;
-  const clite_conv& c = *cv;
-  hipStream_t st = (hipStream_t)stream;
+template <typename T>
+int conv_fwd(const void* x, const void* w, const clite_conv& c, const clite_epilogue* ep, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
   int M = c.N * c.Ho * c.Wo, Ktot = c.R * c.S * c.C;
-  uint32_t xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * 2), wb = (uint32_t)((size_t)c.K * Ktot * 2);
+  uint32_t xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * sizeof(T)), wb = (uint32_t)((size_t)c.K * Ktot * sizeof(T));
   if (c.K <= 64) {
-    GatherKC<256, 32, false> la{x, xb, geom_fwd(c)};
-    GatherKC<64, 32, false> lb{w, wb, geom_dense(c.K, Ktot)};
-    return launch<Cfg256x64>(la, lb, *ep, M, c.K, Ktot, 1, st);
+    GatherKC<T, 256, BK, false> la{x, xb, geom_fwd(c)};
+    GatherKC<T, 64, BK, false> lb{w, wb, geom_dense(c.K, Ktot)};
+    return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, c.K, Ktot, 1, st);
   }
-  GatherKC<128, 32, false> la{x, xb, geom_fwd(c)};
-  GatherKC<128, 32, false> lb{w, wb, geom_dense(c.K, Ktot)};
-  return launch<Cfg128>(la, lb, *ep, M, c.K, Ktot, 1, st);
+  GatherKC<T, 128, BK, false> la{x, xb, geom_fwd(c)};
+  GatherKC<T, 128, BK, false> lb{w, wb, geom_dense(c.K, Ktot)};
+  return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.K, Ktot, 1, st);
 }
 
-extern "C" int clite_conv_dgrad(const void* dy, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
-  if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
-  const clite_conv& c = *cv;
-  hipStream_t st = (hipStream_t)stream;
+template <typename T>
+int conv_dgrad(const void* dy, const void* w, const clite_conv& c, const clite_epilogue* ep, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
   int M = c.N * c.H * c.W, Ktot = c.R * c.S * c.K;
-  uint32_t yb = (uint32_t)((size_t)c.N * c.Ho * c.Wo * c.K * 2), wb = (uint32_t)((size_t)c.K * c.R * c.S * c.C * 2);
+  uint32_t yb = (uint32_t)((size_t)c.N * c.Ho * c.Wo * c.K * sizeof(T)), wb = (uint32_t)((size_t)c.K * c.R * c.S * c.C * sizeof(T));
   if (c.C <= 64) {
-    GatherKC<256, 32, true> la{dy, yb, geom_dgrad(c)};
-    StridedXC<64, 32> lb{w, wb, c.R * c.S * c.C, c.C, c.K, c.R * c.S};
-    return launch<Cfg256x64>(la, lb, *ep, M, c.C, Ktot, 1, st);
+    GatherKC<T, 256, BK, true> la{dy, yb, geom_dgrad(c)};
+    StridedXC<T, 64, BK> lb{w, wb, c.R * c.S * c.C, c.C, c.K, c.R * c.S};
+    return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, c.C, Ktot, 1, st);
   }
-  GatherKC<128, 32, true> la{dy, yb, geom_dgrad(c)};
-  StridedXC<128, 32> lb{w, wb, c.R * c.S * c.C, c.C, c.K, c.R * c.S};
-  return launch<Cfg128>(la, lb, *ep, M, c.C, Ktot, 1, st);
+  GatherKC<T, 128, BK, true> la{dy, yb, geom_dgrad(c)};
+  StridedXC<T, 128, BK> lb{w, wb, c.R * c.S * c.C, c.C, c.K, c.R * c.S};
+  return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.C, Ktot, 1, st);
 }
 
-extern "C" int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream) {
-  if (check_conv(cv) || !dw) return -1;
-  const clite_conv& c = *cv;
-  hipStream_t st = (hipStream_t)stream;
+template <typename T>
+int conv_wgrad(const void* dy, const void* x, const clite_conv& c, float* dw, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
   int P = c.N * c.Ho * c.Wo, Ncols = c.R * c.S * c.C;
-  uint32_t yb = (uint32_t)((size_t)P * c.K * 2), xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * 2);
+  uint32_t yb = (uint32_t)((size_t)P * c.K * sizeof(T)), xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * sizeof(T));
   clite_epilogue ep = {};
   ep.out = dw; ep.ldc = Ncols; ep.out_f32 = 1; ep.atomic = 1; ep.alpha = 1.f;
-  StridedXC<128, 32> la{dy, yb, c.K, c.K, P, 1};
-  GatherXC<128, 32> lb{x, xb, geom_fwd(c)};
-  int splits = pick_splits(c.K, Ncols, 128, 128, (P + 31) / 32);
-  return launch<Cfg128>(la, lb, ep, c.K, Ncols, P, splits, st);
+  StridedXC<T, 128, BK> la{dy, yb, c.K, c.K, P, 1};
+  GatherXC<T, 128, BK> lb{x, xb, geom_fwd(c)};
+  int splits = pick_splits(c.K, Ncols, (P + BK - 1) / BK);
+  return launch<T, typename Cfg<T>::C128>(la, lb, ep, c.K, Ncols, P, splits, st);
+}
+
+int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K) {
+  if (dtype != CLITE_BF16 && dtype != CLITE_F32) return -1;
+  if (M <= 0 || N <= 0 || K <= 0) return -1;
+  if (!fits32((size_t)M * K, 4) || !fits32((size_t)N * K, 4)) return -1;
+  return check_ep(ep, N);
+}
+
+}  // namespace
+
+extern "C" int clite_abi_version(void) { return CLITE_ABI_VERSION; }
+
+extern "C" int clite_gemm_nt(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
+  if (check_gemm(ep, dtype, M, N, K) || K % 8) return -1;
+  return dtype == CLITE_BF16 ? gemm_nt<bf16>(A, B, M, N, K, ep, (hipStream_t)stream) : gemm_nt<float>(A, B, M, N, K, ep, (hipStream_t)stream);
+}
+extern "C" int clite_gemm_nn(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
+  if (check_gemm(ep, dtype, M, N, K) || K % 8) return -1;
+  return dtype == CLITE_BF16 ? gemm_nn<bf16>(A, B, M, N, K, ep, (hipStream_t)stream) : gemm_nn<float>(A, B, M, N, K, ep, (hipStream_t)stream);
+}
+extern "C" int clite_gemm_tn(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
+  if (check_gemm(ep, dtype, M, N, K) || M % 8 || N % 8) return -1;
+  return dtype == CLITE_BF16 ? gemm_tn<bf16>(A, B, M, N, K, ep, (hipStream_t)stream) : gemm_tn<float>(A, B, M, N, K, ep, (hipStream_t)stream);
+}
+extern "C" int clite_conv_fwd(const void* x, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
+  if (check_conv(cv) || check_ep(ep, cv->K)) return -1;
+  return cv->dtype == CLITE_BF16 ? conv_fwd<bf16>(x, w, *cv, ep, (hipStream_t)stream) : conv_fwd<float>(x, w, *cv, ep, (hipStream_t)stream);
+}
+extern "C" int clite_conv_dgrad(const void* dy, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
+  if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
+  return cv->dtype == CLITE_BF16 ? conv_dgrad<bf16>(dy, w, *cv, ep, (hipStream_t)stream) : conv_dgrad<float>(dy, w, *cv, ep, (hipStream_t)stream);
+}
+extern "C" int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream) {
+  if (check_conv(cv) || !dw) return -1;
+  return cv->dtype == CLITE_BF16 ? conv_wgrad<bf16>(dy, x, *cv, dw, (hipStream_t)stream) : conv_wgrad<float>(dy, x, *cv, dw, (hipStream_t)stream);
 }

@@ -45,11 +45,12 @@ struct ConvGeom {
 // ------------------------------------------------------------------------------------------------
 // KC gather loader: rows = pixels of the row space, k = (r, s, c) with c contiguous.
 // DGRAD=false: hi = rh*stride - pad + r.   DGRAD=true: hi = (rh + pad - r) / stride when divisible.
-template <int ROWS, int BK, bool DGRAD>
+template <typename T, int ROWS, int BK, bool DGRAD>
 struct GatherKC {
-  static constexpr int CPR = BK / 8;                 // 16-B chunks per row
+  static constexpr int EPC = 16 / (int)sizeof(T);    // elements per 16-B chunk
+  static constexpr int CPR = BK / EPC;               // 16-B chunks per row
   static constexpr int NCH = ROWS * CPR / 256;       // chunks per thread
-  static constexpr int PITCH = BK * 2 + 16;
+  static constexpr int PITCH = BK * (int)sizeof(T) + 16;
   static constexpr int BYTES = ROWS * PITCH;
   static constexpr bool XC = false;
   const void* ptr;
@@ -64,7 +65,7 @@ struct GatherKC {
   };
   DEV void init(State& st, int row0, int tid, int t_begin) const {
     st.rs = make_rsrc(ptr, bytes);
-    st.kc8 = (tid % CPR) * 8;
+    st.kc8 = (tid % CPR) * EPC;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       int row = row0 + (tid + 256 * i) / CPR;
@@ -103,7 +104,7 @@ struct GatherKC {
         hi = st.h0[i] + st.r; wi = st.w0[i] + st.s;
       }
       v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-      uint32_t off = v ? (uint32_t)(st.base[i] + hi * g.sH + wi * g.sW + c) * 2u : OOB_OFF;
+      uint32_t off = v ? (uint32_t)(st.base[i] + hi * g.sH + wi * g.sW + c) * (uint32_t)sizeof(T) : OOB_OFF;
       regs[i] = buf_load16(st.rs, off);
     }
     st.c0 += BK;
@@ -116,11 +117,15 @@ struct GatherKC {
       *(u32x4*)(lds + (c / CPR) * PITCH + (c % CPR) * 16) = regs[i];
     }
   }
-  // MFMA 32x32x16 fragment for the 32-row block starting at x0, k-step ks (16 deep)
+  // bf16: MFMA 32x32x16 fragment for the 32-row block starting at x0, k-step ks (16 deep)
   DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
     Chunk16 ch;
     ch.u = *(const u32x4*)(lds + (x0 + (lane & 31)) * PITCH + (ks * 16 + 8 * (lane >> 5)) * 2);
     return ch.h;
+  }
+  // f32: MFMA 32x32x2 operand (one value per lane), k-step kk (2 deep)
+  DEV static float frag32(const char* lds, int x0, int kk, int lane) {
+    return *(const float*)(lds + (x0 + (lane & 31)) * PITCH + (kk * 2 + (lane >> 5)) * 4);
   }
 };
 
@@ -128,12 +133,13 @@ struct GatherKC {
 // XC strided loader: element (k, x) at ptr[(k0+krow)*ld + rs*Cx + x]; k = (rs, kk) with kk < Ck.
 // Serves: weights for dgrad (W[co][r][s][ci]: ld = R*S*Cin, Cx = Cin, Ck = Cout, RS = R*S),
 //         linear dgrad (W[n][k]: ld = K, Cx = K, Ck = N, RS = 1), wgrad's dY ([P][Cout]: ld = Cx = Cout, Ck = P).
-template <int COLS, int BK>
+template <typename T, int COLS, int BK>
 struct StridedXC {
-  static constexpr int CPR = COLS / 8;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  static constexpr int CPR = COLS / EPC;
   static constexpr int NCH = BK * CPR / 256;
   static constexpr int RPS = 256 / CPR;              // k-rows per sweep of the block
-  static constexpr int PITCH = COLS * 2 + 64;
+  static constexpr int PITCH = COLS * (int)sizeof(T) + 64;
   static constexpr int BYTES = BK * PITCH;
   static constexpr bool XC = true;
   const void* ptr;
@@ -148,7 +154,7 @@ struct StridedXC {
   };
   DEV void init(State& st, int x0, int tid, int t_begin) const {
     st.rs_ = make_rsrc(ptr, bytes);
-    st.x = x0 + (tid % CPR) * 8;
+    st.x = x0 + (tid % CPR) * EPC;
     st.xvalid = st.x < Cx;
     st.krow0 = tid / CPR;
     int kk = t_begin * BK;
@@ -160,7 +166,7 @@ struct StridedXC {
     for (int i = 0; i < NCH; ++i) {
       int k = st.k0 + st.krow0 + i * RPS;
       bool v = st.xvalid && k < Ck && st.rs < RS;
-      uint32_t off = v ? (uint32_t)(k * ld + st.rs * Cx + st.x) * 2u : OOB_OFF;
+      uint32_t off = v ? (uint32_t)(k * ld + st.rs * Cx + st.x) * (uint32_t)sizeof(T) : OOB_OFF;
       regs[i] = buf_load16(st.rs_, off);
     }
     st.k0 += BK;
@@ -182,16 +188,20 @@ struct StridedXC {
     u.v[0] = lo; u.v[1] = hi;
     return u.h;
   }
+  DEV static float frag32(const char* lds, int x0, int kk, int lane) {
+    return *(const float*)(lds + (kk * 2 + (lane >> 5)) * PITCH + (x0 + (lane & 31)) * 4);
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
 // XC gather loader (wgrad's activation operand): k = output pixel p -> (n, ho, wo); x = (r, s, ci).
-template <int COLS, int BK>
+template <typename T, int COLS, int BK>
 struct GatherXC {
-  static constexpr int CPR = COLS / 8;
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  static constexpr int CPR = COLS / EPC;
   static constexpr int NCH = BK * CPR / 256;
   static constexpr int RPS = 256 / CPR;
-  static constexpr int PITCH = COLS * 2 + 64;
+  static constexpr int PITCH = COLS * (int)sizeof(T) + 64;
   static constexpr int BYTES = BK * PITCH;
   static constexpr bool XC = true;
   const void* ptr;
@@ -206,7 +216,7 @@ struct GatherXC {
   };
   DEV void init(State& st, int x0, int tid, int t_begin) const {
     st.rs_ = make_rsrc(ptr, bytes);
-    int x = x0 + (tid % CPR) * 8;
+    int x = x0 + (tid % CPR) * EPC;
     int rs = x / g.C;
     int ci = x - rs * g.C;
     st.r = rs / g.S;
@@ -227,16 +237,19 @@ struct GatherXC {
       int hi = (int)ho * g.stride - g.pad + st.r;
       int wi = (int)wo * g.stride - g.pad + st.s;
       v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-      uint32_t off = v ? (uint32_t)((int)n * g.sN + hi * g.sH + wi * g.sW + st.xoff) * 2u : OOB_OFF;
+      uint32_t off = v ? (uint32_t)((int)n * g.sN + hi * g.sH + wi * g.sW + st.xoff) * (uint32_t)sizeof(T) : OOB_OFF;
       regs[i] = buf_load16(st.rs_, off);
     }
     st.p0 += BK;
   }
   DEV static void store(char* lds, int tid, const u32x4 (&regs)[NCH]) {
-    StridedXC<COLS, BK>::store(lds, tid, regs);
+    StridedXC<T, COLS, BK>::store(lds, tid, regs);
   }
   DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
-    return StridedXC<COLS, BK>::frag(lds, x0, ks, lane);
+    return StridedXC<T, COLS, BK>::frag(lds, x0, ks, lane);
+  }
+  DEV static float frag32(const char* lds, int x0, int kk, int lane) {
+    return StridedXC<T, COLS, BK>::frag32(lds, x0, kk, lane);
   }
 };
 
@@ -252,6 +265,32 @@ DEV float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// 8 consecutive elements <-> fp32 registers
+DEV void load8(const bf16* p, float (&v)[8]) {
+  Chunk16 c;
+  c.u = *(const u32x4*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(c.e[e]);
+}
+DEV void load8(const float* p, float (&v)[8]) {
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+DEV void store8(bf16* p, const float (&v)[8]) {
+  Chunk16 c;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c.e[e] = f2bf(v[e]);
+  *(u32x4*)p = c.u;
+}
+DEV void store8(float* p, const float (&v)[8]) {
+  *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+  *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+DEV void round8_bf16(float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+}
+
 template <int BM_, int BN_, int BK_, int WM_, int WN_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
@@ -262,7 +301,7 @@ struct TileCfg {
   static constexpr int EPI_BYTES = WM * EPI_PITCH;
 };
 
-template <class CFG, class LA, class LB>
+template <typename T, class CFG, class LA, class LB>
 __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, int M, int N, int ktiles, int ktiles_per_split) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
@@ -319,17 +358,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, i
     }
     const char* abuf = smem + cur * STAGE;
     const char* bbuf = abuf + LA::BYTES;
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 af[RM], bfr[RN];
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 af[RM], bfr[RN];
 #pragma unroll
-      for (int i = 0; i < RM; ++i) af[i] = LA::frag(abuf, wm0 + i * 32, ks, lane);
+        for (int i = 0; i < RM; ++i) af[i] = LA::frag(abuf, wm0 + i * 32, ks, lane);
 #pragma unroll
-      for (int j = 0; j < RN; ++j) bfr[j] = LB::frag(bbuf, wn0 + j * 32, ks, lane);
+        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag(bbuf, wn0 + j * 32, ks, lane);
 #pragma unroll
-      for (int i = 0; i < RM; ++i)
+        for (int i = 0; i < RM; ++i)
 #pragma unroll
-        for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+      }
+    } else {   // exact-f32 parity mode: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain per output
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float af[RM], bfr[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+      }
     }
     if (more) {
       char* nbuf = smem + (cur ^ 1) * STAGE;
@@ -393,12 +447,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, i
         size_t gidx = (size_t)grow * ep.ldc + gcol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
-        if (ep.preact) {
-          Chunk16 pc;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pc.e[e] = f2bf(v[e]);
-          *(u32x4*)((bf16*)ep.preact + gidx) = pc.u;
-        }
+        if (ep.preact) store8((T*)ep.preact + gidx, v);
         if (ep.act == ACT_RELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -410,11 +459,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, i
           for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
         }
         if (ep.dact_aux) {
-          Chunk16 ac;
-          ac.u = *(const u32x4*)((const bf16*)ep.dact_aux + gidx);
+          float av[8];
+          load8((const T*)ep.dact_aux + gidx, av);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float a = bf2f(ac.e[e]);
+            float a = av[e];
             float d = ep.dact == 1 ? (a > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_f(a) : (1.f - a * a);
             v[e] *= d;
           }
@@ -426,22 +475,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, i
           for (int e = 0; e < 8; ++e) v[e] = u[e] >= ep.drop_p ? v[e] * keep_scale : 0.f;
         }
         if (ep.residual) {
-          Chunk16 rc;
-          rc.u = *(const u32x4*)((const bf16*)ep.residual + gidx);
+          float rv[8];
+          load8((const T*)ep.residual + gidx, rv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bf2f(rc.e[e]);
+          for (int e = 0; e < 8; ++e) v[e] += rv[e];
         }
-        if (ep.out_f32) {
-          float* o = (float*)ep.out + gidx;
-          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
-          *(f32x4*)(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        if (ep.out_f32 || sizeof(T) == 4) {
+          store8((float*)ep.out + gidx, v);
         } else {
-          Chunk16 oc;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) oc.e[e] = f2bf(v[e]);
-          *(u32x4*)((bf16*)ep.out + gidx) = oc.u;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = bf2f(oc.e[e]);   // statistics of what was stored
+          store8((bf16*)ep.out + gidx, v);
+          round8_bf16(v);   // statistics of what was stored
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }

@@ -25,7 +25,7 @@ class Epilogue(C.Structure):
 
 
 class Conv(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo")]
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo")]
 
 
 _lib = None

@@ -26,30 +26,35 @@ extern "C" {
 #define CLITE_ABI_VERSION 1
 int clite_abi_version(void);
 
+/* storage type of activations / weights handed to a kernel. CLITE_F32 selects the exact-f32 parity mode
+ * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 MFMA rate). Accumulation is f32 in both. */
+enum { CLITE_BF16 = 0, CLITE_F32 = 1 };
+
 enum { CLITE_ACT_NONE = 0, CLITE_ACT_RELU = 1, CLITE_ACT_GELU = 2, CLITE_ACT_TANH = 3 };
 
 /* Fused GEMM epilogue. v = alpha*acc + bias; preact <- v; v = act(v); v *= act'(dact_aux);
  * v = dropout(v); v += residual; out <- v; colsum += (sum, sum of squares) of the stored values. */
 typedef struct clite_epilogue {
-  void* out;            /* [M][ldc] bf16 (out_f32 = 0) or f32 (out_f32 = 1) */
+  void* out;            /* [M][ldc] in the call's dtype, or f32 when out_f32 = 1 */
   int32_t ldc;
   int32_t out_f32;
   int32_t atomic;       /* 1: out (f32) += alpha*acc with float atomics (split-K / gradient accumulation) */
   float alpha;
   const float* bias;    /* [N] f32 or NULL */
   int32_t act;          /* CLITE_ACT_* */
-  void* preact;         /* bf16 [M][ldc] or NULL */
-  const void* dact_aux; /* bf16 [M][ldc] or NULL */
+  void* preact;         /* [M][ldc] in the call's dtype, or NULL */
+  const void* dact_aux; /* [M][ldc] in the call's dtype, or NULL */
   int32_t dact;         /* 1 relu' (aux = forward output), 2 gelu' (aux = pre-activation), 3 tanh' (aux = output) */
   float drop_p;
   uint64_t drop_seed;
   uint32_t drop_site;
-  const void* residual; /* bf16 [M][ldc] or NULL */
+  const void* residual; /* [M][ldc] in the call's dtype, or NULL */
   float* colsum;        /* f32 [2][N] or NULL */
 } clite_epilogue;
 
-/* NHWC convolution problem. x: [N][H][W][C] bf16, w: [K][R][S][C] bf16, y: [N][Ho][Wo][K] bf16. */
+/* NHWC convolution problem. x: [N][H][W][C], w: [K][R][S][C], y: [N][Ho][Wo][K], all of `dtype`. */
 typedef struct clite_conv {
+  int32_t dtype;
   int32_t N, H, W, C;
   int32_t K, R, S;
   int32_t stride, pad;
@@ -58,11 +63,11 @@ typedef struct clite_conv {
 
 /* C[M,N] = A[M,K] * B[N,K]^T  — nn.Linear forward (reference loss.py:16-22,46-48; HF BertModel linears
  * behind encoder.py:193). K % 8 == 0, N % 8 == 0. */
-int clite_gemm_nt(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream);
+int clite_gemm_nt(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
 /* C[M,N] = A[M,K] * B[K,N]       — nn.Linear input gradient (autograd of the same call sites). */
-int clite_gemm_nn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream);
+int clite_gemm_nn(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
 /* C[M,N] (+)= A[K,M]^T * B[K,N]  — nn.Linear weight gradient; ep->atomic selects f32 accumulation. */
-int clite_gemm_tn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, void* stream);
+int clite_gemm_tn(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
 
 /* y = conv(x, w): torchvision ResNet nn.Conv2d forward (reference encoder.py:36-38,63; block arithmetic as
  * restated in model_zoo/resnet.py:60-100). Epilogue applies to y viewed as [N*Ho*Wo][K]. */

@@ -1,0 +1,135 @@
+"""CPU-side check of the implicit-GEMM engine's index math: the same csrc/*.hip sources compiled against the
+lane-accurate wave simulator (tests/wavesim/), compared with numpy on small problems. Runs without a GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from simlib import Conv, bf16_round, from_bf16, lib, make_ep, ptr, to_bf16
+
+BF16, F32 = 0, 1
+
+
+def _prep(x, dtype):
+    """returns (exact value array the kernel sees, buffer to pass)"""
+    if dtype == BF16:
+        xr = bf16_round(x)
+        return xr, to_bf16(xr)
+    x = np.ascontiguousarray(x, np.float32)
+    return x, x
+
+
+def _close(got, ref, rel=2e-3):
+    assert np.abs(got - ref).max() <= rel * max(np.abs(ref).max(), 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 104), (300, 64, 32), (70, 1000, 200)])
+def test_gemm_nt_epilogue(dtype, M, N, K):
+    rng = np.random.default_rng(M + N)
+    A, Ab = _prep(rng.standard_normal((M, K), dtype=np.float32), dtype)
+    B, Bb = _prep(rng.standard_normal((N, K), dtype=np.float32), dtype)
+    R, Rb = _prep(rng.standard_normal((M, N), dtype=np.float32), dtype)
+    bias = rng.standard_normal(N).astype(np.float32)
+    out = np.zeros((M, N), np.float32)
+    pre = np.zeros((M, N), np.uint16 if dtype == BF16 else np.float32)
+    ep = make_ep(out, N, out_f32=True, bias=bias, act=2, preact=pre, residual=Rb)
+    assert lib().clite_gemm_nt(ptr(Ab), ptr(Bb), M, N, K, dtype, C.byref(ep), None) == 0
+    z = A @ B.T + bias
+    from scipy.special import erf
+    ref = 0.5 * z * (1 + erf(z / np.sqrt(2))) + R
+    _close(out, ref)
+    _close(from_bf16(pre) if dtype == BF16 else pre, z, 6e-3)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 104), (300, 64, 40)])
+def test_gemm_nn_dact(dtype, M, N, K):
+    rng = np.random.default_rng(M + K)
+    A, Ab = _prep(rng.standard_normal((M, K), dtype=np.float32), dtype)
+    B, Bb = _prep(rng.standard_normal((K, N), dtype=np.float32), dtype)
+    aux, auxb = _prep(rng.standard_normal((M, N), dtype=np.float32), dtype)
+    out = np.zeros((M, N), np.float32)
+    ep = make_ep(out, N, out_f32=True, dact_aux=auxb, dact=1)
+    assert lib().clite_gemm_nn(ptr(Ab), ptr(Bb), M, N, K, dtype, C.byref(ep), None) == 0
+    _close(out, (A @ B) * (aux > 0))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 136, 300), (256, 8, 1000)])
+def test_gemm_tn_atomic(dtype, M, N, K):
+    rng = np.random.default_rng(M + K)
+    A, Ab = _prep(rng.standard_normal((K, M), dtype=np.float32), dtype)
+    B, Bb = _prep(rng.standard_normal((K, N), dtype=np.float32), dtype)
+    out = np.ones((M, N), np.float32)
+    ep = make_ep(out, N, out_f32=True, atomic=True)
+    assert lib().clite_gemm_tn(ptr(Ab), ptr(Bb), M, N, K, dtype, C.byref(ep), None) == 0
+    _close(out, 1 + A.T @ B)
+
+
+def conv_ref(x, w, stride, pad):
+    N, H, W, Cc = x.shape
+    K, R, S, _ = w.shape
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - S) // stride + 1
+    xp = np.zeros((N, H + 2 * pad, W + 2 * pad, Cc), np.float32)
+    xp[:, pad:pad + H, pad:pad + W] = x
+    y = np.zeros((N, Ho, Wo, K), np.float32)
+    for r in range(R):
+        for s in range(S):
+            y += xp[:, r:r + stride * Ho:stride, s:s + stride * Wo:stride, :] @ w[:, r, s, :].T
+    return y
+
+
+def conv_dgrad_ref(dy, w, xshape, stride, pad):
+    N, H, W, Cc = xshape
+    K, R, S, _ = w.shape
+    _, Ho, Wo, _ = dy.shape
+    dxp = np.zeros((N, H + 2 * pad, W + 2 * pad, Cc), np.float32)
+    for r in range(R):
+        for s in range(S):
+            dxp[:, r:r + stride * Ho:stride, s:s + stride * Wo:stride, :] += dy @ w[:, r, s, :]
+    return dxp[:, pad:pad + H, pad:pad + W]
+
+
+def conv_wgrad_ref(dy, x, wshape, stride, pad):
+    N, H, W, Cc = x.shape
+    K, R, S, _ = wshape
+    _, Ho, Wo, _ = dy.shape
+    xp = np.zeros((N, H + 2 * pad, W + 2 * pad, Cc), np.float32)
+    xp[:, pad:pad + H, pad:pad + W] = x
+    dw = np.zeros(wshape, np.float32)
+    for r in range(R):
+        for s in range(S):
+            patch = xp[:, r:r + stride * Ho:stride, s:s + stride * Wo:stride, :]
+            dw[:, r, s, :] = dy.reshape(-1, K).T @ patch.reshape(-1, Cc)
+    return dw
+
+
+CASES = [(2, 8, 8, 32, 64, 3, 3, 1, 1), (2, 9, 7, 64, 32, 3, 3, 2, 1), (3, 6, 6, 64, 128, 1, 1, 1, 0),
+         (2, 8, 8, 32, 64, 1, 1, 2, 0), (1, 10, 10, 32, 160, 3, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("N,H,W,Cc,K,R,S,st,pad", CASES)
+def test_conv_fwd_dgrad_wgrad(dtype, N, H, W, Cc, K, R, S, st, pad):
+    rng = np.random.default_rng(H * W + K)
+    Ho = (H + 2 * pad - R) // st + 1
+    Wo = (W + 2 * pad - S) // st + 1
+    cv = Conv(dtype, N, H, W, Cc, K, R, S, st, pad, Ho, Wo)
+    x, xb = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), dtype)
+    w, wb = _prep(rng.standard_normal((K, R, S, Cc), dtype=np.float32) * 0.2, dtype)
+    dy, dyb = _prep(rng.standard_normal((N, Ho, Wo, K), dtype=np.float32), dtype)
+    y = np.zeros((N, Ho, Wo, K), np.float32)
+    cs = np.zeros((2, K), np.float32)
+    assert lib().clite_conv_fwd(ptr(xb), ptr(wb), C.byref(cv), C.byref(make_ep(y, K, out_f32=True, colsum=cs)), None) == 0
+    ref = conv_ref(x, w, st, pad)
+    _close(y, ref)
+    _close(cs[0], ref.reshape(-1, K).sum(0))
+    _close(cs[1], (ref.reshape(-1, K) ** 2).sum(0))
+    dx = np.zeros((N, H, W, Cc), np.float32)
+    assert lib().clite_conv_dgrad(ptr(dyb), ptr(wb), C.byref(cv), C.byref(make_ep(dx, Cc, out_f32=True)), None) == 0
+    _close(dx, conv_dgrad_ref(dy, w, x.shape, st, pad))
+    dw = np.zeros((K, R, S, Cc), np.float32)
+    assert lib().clite_conv_wgrad(ptr(dyb), ptr(xb), C.byref(cv), ptr(dw), None) == 0
+    _close(dw, conv_wgrad_ref(dy, x, w.shape, st, pad))
