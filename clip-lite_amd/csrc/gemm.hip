@@ -176,6 +176,59 @@ int conv_wgrad(const void* dy, const void* x, const clite_conv& c, float* dw, hi
   return launch<T, typename Cfg<T>::C128>(la, lb, ep, c.K, Ncols, P, splits, st);
 }
 
+// 7x7/2 stem on a pre-padded NHWC4 image [N][Hp][Wp][4]: a 7x1 window over 32 "virtual" channels (8 adjacent pixels
+// x 4 channels are contiguous), K = 7*32 = 224; weights packed as [64][7][8][4] with s=7 and c=3 zero.
+ConvGeom geom_stem(int N, int Hp, int Wp, int Ho, int Wo) {
+  ConvGeom g;
+  g.H = Hp; g.W = Wp; g.C = 32;
+  g.sN = Hp * Wp * 4; g.sH = Wp * 4; g.sW = 4;
+  g.RH = Ho; g.RW = Wo; g.R = 7; g.S = 1; g.stride = 2; g.pad = 0;
+  g.rows = N * Ho * Wo;
+  g.div_hw = fastdiv_make(Ho * Wo);
+  g.div_w = fastdiv_make(Wo);
+  return g;
+}
+int check_stem(int dtype, int N, int Hp, int Wp, int Ho, int Wo) {
+  if (dtype != CLITE_BF16 && dtype != CLITE_F32) return -1;
+  if (N <= 0 || Wp % 2 || 2 * (Ho - 1) + 7 > Hp || 2 * (Wo - 1) + 8 > Wp) return -1;
+  if (!fits32((size_t)N * Hp * Wp * 4, 4) || !fits32((size_t)N * Ho * Wo * 64, 4)) return -1;
+  return 0;
+}
+template <typename T>
+int stem_fwd(const void* xpad, const void* wv, int N, int Hp, int Wp, int Ho, int Wo, const clite_epilogue* ep, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
+  GatherKC<T, 256, BK, false> la{xpad, (uint32_t)((size_t)N * Hp * Wp * 4 * sizeof(T)), geom_stem(N, Hp, Wp, Ho, Wo)};
+  GatherKC<T, 64, BK, false> lb{wv, (uint32_t)(64 * 224 * sizeof(T)), geom_dense(64, 224)};
+  return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, N * Ho * Wo, 64, 224, 1, st);
+}
+template <typename T>
+int stem_wgrad(const void* dy, const void* xpad, int N, int Hp, int Wp, int Ho, int Wo, float* dwv, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
+  int P = N * Ho * Wo;
+  clite_epilogue ep = {};
+  ep.out = dwv; ep.ldc = 224; ep.out_f32 = 1; ep.atomic = 1; ep.alpha = 1.f;
+  StridedXC<T, 128, BK> la{dy, (uint32_t)((size_t)P * 64 * sizeof(T)), 64, 64, P, 1};
+  GatherXC<T, 128, BK> lb{xpad, (uint32_t)((size_t)N * Hp * Wp * 4 * sizeof(T)), geom_stem(N, Hp, Wp, Ho, Wo)};
+  int splits = pick_splits(64, 224, (P + BK - 1) / BK);
+  return launch<T, typename Cfg<T>::C128>(la, lb, ep, 64, 224, P, splits, st);
+}
+
+// w f32 [64][7][7][3] (KRSC) -> wv T [64][7][8][4]; dwv f32 [64][7][8][4] -> dw f32 [64][7][7][3] (+=)
+template <typename T>
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* w, T* wv) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 7 * 8 * 4) return;
+  int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % 7, k = i / 224;
+  float v = (c < 3 && s < 7) ? w[((k * 7 + r) * 7 + s) * 3 + c] : 0.f;
+  if constexpr (sizeof(T) == 2) wv[i] = f2bf(v); else wv[i] = v;
+}
+__global__ __launch_bounds__(256) void stem_unpack_kernel(const float* dwv, float* dw) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 7 * 7 * 3) return;
+  int c = i % 3, s = (i / 3) % 7, r = (i / 21) % 7, k = i / 147;
+  dw[i] += dwv[((k * 7 + r) * 8 + s) * 4 + c];
+}
+
 int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K) {
   if (dtype != CLITE_BF16 && dtype != CLITE_F32) return -1;
   if (M <= 0 || N <= 0 || K <= 0) return -1;
@@ -210,4 +263,27 @@ extern "C" int clite_conv_dgrad(const void* dy, const void* w, const clite_conv*
 extern "C" int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream) {
   if (check_conv(cv) || !dw) return -1;
   return cv->dtype == CLITE_BF16 ? conv_wgrad<bf16>(dy, x, *cv, dw, (hipStream_t)stream) : conv_wgrad<float>(dy, x, *cv, dw, (hipStream_t)stream);
+}
+
+extern "C" int clite_stem_fwd(const void* xpad, const void* wv, int dtype, int N, int Hp, int Wp, int Ho, int Wo, const clite_epilogue* ep, void* stream) {
+  if (check_stem(dtype, N, Hp, Wp, Ho, Wo) || check_ep(ep, 64)) return -1;
+  return dtype == CLITE_BF16 ? stem_fwd<bf16>(xpad, wv, N, Hp, Wp, Ho, Wo, ep, (hipStream_t)stream)
+                             : stem_fwd<float>(xpad, wv, N, Hp, Wp, Ho, Wo, ep, (hipStream_t)stream);
+}
+extern "C" int clite_stem_wgrad(const void* dy, const void* xpad, int dtype, int N, int Hp, int Wp, int Ho, int Wo, float* dwv, void* stream) {
+  if (check_stem(dtype, N, Hp, Wp, Ho, Wo) || !dwv) return -1;
+  return dtype == CLITE_BF16 ? stem_wgrad<bf16>(dy, xpad, N, Hp, Wp, Ho, Wo, dwv, (hipStream_t)stream)
+                             : stem_wgrad<float>(dy, xpad, N, Hp, Wp, Ho, Wo, dwv, (hipStream_t)stream);
+}
+extern "C" int clite_stem_pack(const float* w, void* wv, int dtype, void* stream) {
+  if (!w || !wv) return -1;
+  if (dtype == CLITE_BF16) hipLaunchKernelGGL(stem_pack_kernel<bf16>, dim3(56), dim3(256), 0, (hipStream_t)stream, w, (bf16*)wv);
+  else if (dtype == CLITE_F32) hipLaunchKernelGGL(stem_pack_kernel<float>, dim3(56), dim3(256), 0, (hipStream_t)stream, w, (float*)wv);
+  else return -1;
+  return (int)hipGetLastError();
+}
+extern "C" int clite_stem_unpack_grad(const float* dwv, float* dw, void* stream) {
+  if (!dwv || !dw) return -1;
+  hipLaunchKernelGGL(stem_unpack_kernel, dim3(37), dim3(256), 0, (hipStream_t)stream, dwv, dw);
+  return (int)hipGetLastError();
 }

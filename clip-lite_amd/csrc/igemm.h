@@ -20,6 +20,7 @@
 #define CLITE_IGEMM_H
 #include "intrin.h"
 #include "rng.h"
+#include "vec.h"
 #include "clite.h"
 
 namespace clite {
@@ -263,32 +264,6 @@ DEV float gelu_grad_f(float x) {
   float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
   float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
-}
-
-// 8 consecutive elements <-> fp32 registers
-DEV void load8(const bf16* p, float (&v)[8]) {
-  Chunk16 c;
-  c.u = *(const u32x4*)p;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = bf2f(c.e[e]);
-}
-DEV void load8(const float* p, float (&v)[8]) {
-  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-}
-DEV void store8(bf16* p, const float (&v)[8]) {
-  Chunk16 c;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) c.e[e] = f2bf(v[e]);
-  *(u32x4*)p = c.u;
-}
-DEV void store8(float* p, const float (&v)[8]) {
-  *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
-  *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
-}
-DEV void round8_bf16(float (&v)[8]) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
 }
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_>

@@ -1,0 +1,438 @@
+// HBM-bound kernels of the ResNet image encoder (reference encoder.py:36-65 -> torchvision ResNet; block
+// arithmetic restated in-repo at model_zoo/resnet.py:60-100): train-mode BatchNorm2d apply / backward,
+// 3x3/2 max-pool, global average pool, NCHW f32 -> padded NHWC image conversion for the 7x7 stem.
+// All tensors are NHWC with C % 8 == 0; each lane moves 16-byte (bf16) / 32-byte (f32) vectors; per-channel
+// reductions are folded through LDS and leave the workgroup as one float atomic per channel.
+#include "vec.h"
+#include "clite.h"
+
+using namespace clite;
+
+namespace {
+
+struct BnCoef { float a[8], b[8]; };
+
+// scale/shift of 8 channels from batch statistics (training) or running statistics (eval)
+DEV void bn_coef(const float* stats, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                 int training, float inv_count, float eps, int C, int c0, BnCoef& k, float (&mean)[8], float (&var)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = c0 + e;
+    if (training) {
+      mean[e] = stats[c] * inv_count;
+      var[e] = fmaxf(stats[C + c] * inv_count - mean[e] * mean[e], 0.f);
+    } else {
+      mean[e] = rmean[c];
+      var[e] = rvar[c];
+    }
+    float rstd = rsqrtf(var[e] + eps);
+    k.a[e] = gamma[c] * rstd;
+    k.b[e] = beta[c] - mean[e] * k.a[e];
+  }
+}
+
+// out = relu?( y*a + b  [+ res | + res*a' + b'] ).  Workgroup = 256 threads = (256/CPR) rows x CPR 8-channel chunks.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, const T* res, T* out, int rows_per_block) {
+  const int CPR = p.C / 8, RPS = 256 / CPR;
+  const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
+  const float inv_count = 1.0f / (float)p.M;
+  BnCoef k, kr;
+  float mean[8], var[8], mr[8], vr[8];
+  bn_coef(p.stats, p.gamma, p.beta, p.running_mean, p.running_var, p.training, inv_count, p.eps, p.C, c0, k, mean, var);
+  const bool res_affine = res && p.res_gamma;
+  if (res_affine)
+    bn_coef(p.res_stats, p.res_gamma, p.res_beta, p.res_running_mean, p.res_running_var, p.training, inv_count, p.eps, p.C, c0, kr, mr, vr);
+  if (blockIdx.x == 0 && r0 == 0 && p.training && p.update_running) {
+    float unb = p.M > 1 ? (float)p.M / (float)(p.M - 1) : 1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      p.running_mean[c0 + e] = (1.f - p.momentum) * p.running_mean[c0 + e] + p.momentum * mean[e];
+      p.running_var[c0 + e] = (1.f - p.momentum) * p.running_var[c0 + e] + p.momentum * var[e] * unb;
+      if (res_affine) {
+        p.res_running_mean[c0 + e] = (1.f - p.momentum) * p.res_running_mean[c0 + e] + p.momentum * mr[e];
+        p.res_running_var[c0 + e] = (1.f - p.momentum) * p.res_running_var[c0 + e] + p.momentum * vr[e] * unb;
+      }
+    }
+  }
+  int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
+  if (row_end > p.M) row_end = p.M;
+  for (int r = row_begin + r0; r < row_end; r += RPS) {
+    size_t idx = (size_t)r * p.C + c0;
+    float v[8];
+    load8(y + idx, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = v[e] * k.a[e] + k.b[e];
+    if (res) {
+      float rv[8];
+      load8(res + idx, rv);
+      if (res_affine) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e] * kr.a[e] + kr.b[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    store8(out + idx, v);
+  }
+}
+
+// dstats[0][c] += sum dz, dstats[1][c] += sum dz*y, with dz = dout * (mask > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const T* mask, const T* y, float* dstats, int M, int C, int rows_per_block) {
+  __shared__ float red[256 * 16];
+  const int CPR = C / 8, RPS = 256 / CPR;
+  const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
+  float s1[8], s2[8];
+  zero8(s1); zero8(s2);
+  int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
+  if (row_end > M) row_end = M;
+  for (int r = row_begin + r0; r < row_end; r += RPS) {
+    size_t idx = (size_t)r * C + c0;
+    float d[8], yv[8];
+    load8(dout + idx, d);
+    load8(y + idx, yv);
+    if (mask) {
+      float m[8];
+      load8(mask + idx, m);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] += d[e]; s2[e] += d[e] * yv[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
+  __syncthreads();
+  if (r0 == 0) {
+    for (int e = 0; e < 16; ++e) {
+      float s = 0.f;
+      for (int r = 0; r < RPS; ++r) s += red[(r * CPR + cc) * 16 + e];
+      atomic_add_f32(dstats + (e >= 8 ? C : 0) + c0 + (e & 7), s);
+    }
+  }
+}
+
+// dy = gamma*rstd*(dz - S1/M - xhat*G/M), G = sum dz*xhat = rstd*(S2 - mean*S1); dgamma += G, dbeta += S1
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* dout, const T* mask, const T* y, const float* dstats,
+                                                           T* dy, T* dz_out, float* dgamma, float* dbeta, int rows_per_block) {
+  const int CPR = p.C / 8, RPS = 256 / CPR;
+  const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
+  const float inv_count = 1.0f / (float)p.M;
+  float mean[8], rstd[8], ka[8], kb[8], kc[8];   // dy = ka*dz + kb + kc*y
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int c = c0 + e;
+    mean[e] = p.stats[c] * inv_count;
+    float var = fmaxf(p.stats[p.C + c] * inv_count - mean[e] * mean[e], 0.f);
+    rstd[e] = rsqrtf(var + p.eps);
+    float S1 = dstats[c], S2 = dstats[p.C + c];
+    float G = rstd[e] * (S2 - mean[e] * S1);
+    float a = p.gamma[c] * rstd[e];
+    // dy = a*(dz - S1/M - (y-mean)*rstd*G/M)
+    ka[e] = a;
+    kc[e] = -a * rstd[e] * G * inv_count;
+    kb[e] = -a * S1 * inv_count - kc[e] * mean[e];
+    if (blockIdx.x == 0 && r0 == 0) {
+      if (dgamma) dgamma[c] += G;
+      if (dbeta) dbeta[c] += S1;
+    }
+  }
+  int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
+  if (row_end > p.M) row_end = p.M;
+  for (int r = row_begin + r0; r < row_end; r += RPS) {
+    size_t idx = (size_t)r * p.C + c0;
+    float d[8], yv[8];
+    load8(dout + idx, d);
+    load8(y + idx, yv);
+    if (mask) {
+      float m[8];
+      load8(mask + idx, m);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
+    }
+    if (dz_out) store8(dz_out + idx, d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] = ka[e] * d[e] + kb[e] + kc[e] * yv[e];
+    store8(dy + idx, d);
+  }
+}
+
+int bn_grid(int M, int C, int* rows_per_block) {
+  int CPR = C / 8, RPS = 256 / CPR;
+  int sweeps = (M + RPS - 1) / RPS;
+  int grid = sweeps < 2048 ? sweeps : 2048;
+  int spb = (sweeps + grid - 1) / grid;
+  *rows_per_block = spb * RPS;
+  return (M + *rows_per_block - 1) / *rows_per_block;
+}
+int bn_ok(int M, int C) { return M > 0 && C >= 8 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0; }
+
+// ------------------------------------------------------------------------------------------------ pooling
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, uint8_t* idx, int N, int H, int W, int C, int Ho, int Wo) {
+  const int CPR = C / 8;
+  size_t total = (size_t)N * Ho * Wo * CPR;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int cc = (int)(i % CPR);
+    size_t pix = i / CPR;
+    int wo = (int)(pix % Wo);
+    int ho = (int)((pix / Wo) % Ho);
+    int n = (int)(pix / ((size_t)Wo * Ho));
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+    for (int r = 0; r < 3; ++r)
+      for (int s = 0; s < 3; ++s) {
+        int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s;
+        if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) continue;
+        float v[8];
+        load8(x + (((size_t)n * H + hi) * W + wi) * C + cc * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (v[e] > best[e] || bi[e] < 0) { best[e] = v[e]; bi[e] = r * 3 + s; }   // first maximum in scan order wins
+      }
+    store8(out + pix * C + cc * 8, best);
+    uint8_t* ip = idx + pix * C + cc * 8;
+    uint32_t lo = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    uint32_t hi4 = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+    *(u32x2*)ip = u32x2{lo, hi4};
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const uint8_t* idx, T* dx, int N, int H, int W, int C, int Ho, int Wo) {
+  const int CPR = C / 8;
+  size_t total = (size_t)N * H * W * CPR;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int cc = (int)(i % CPR);
+    size_t pix = i / CPR;
+    int wi = (int)(pix % W);
+    int hi = (int)((pix / W) % H);
+    int n = (int)(pix / ((size_t)W * H));
+    float acc[8];
+    zero8(acc);
+    for (int r = 0; r < 3; ++r) {
+      int hh = hi + 1 - r;
+      if (hh < 0 || (hh & 1)) continue;
+      int ho = hh >> 1;
+      if (ho >= Ho) continue;
+      for (int s = 0; s < 3; ++s) {
+        int ww = wi + 1 - s;
+        if (ww < 0 || (ww & 1)) continue;
+        int wo = ww >> 1;
+        if (wo >= Wo) continue;
+        size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + cc * 8;
+        u32x2 ib = *(const u32x2*)(idx + o);
+        float d[8];
+        load8(dout + o, d);
+        uint32_t code = (uint32_t)(r * 3 + s);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          uint32_t b = ((e < 4 ? ib[0] : ib[1]) >> (8 * (e & 3))) & 0xFFu;
+          if (b == code) acc[e] += d[e];
+        }
+      }
+    }
+    store8(dx + pix * C + cc * 8, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* x, T* out, int N, int HW, int C) {
+  const int CPR = C / 8;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * CPR) return;
+  int n = i / CPR, cc = i % CPR;
+  float acc[8];
+  zero8(acc);
+  for (int p = 0; p < HW; ++p) {
+    float v[8];
+    load8(x + ((size_t)n * HW + p) * C + cc * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+  }
+  float inv = 1.0f / (float)HW;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] *= inv;
+  store8(out + (size_t)n * C + cc * 8, acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* dout, T* dx, int N, int HW, int C) {
+  const int CPR = C / 8;
+  size_t total = (size_t)N * HW * CPR;
+  float inv = 1.0f / (float)HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int cc = (int)(i % CPR);
+    size_t pix = i / CPR;
+    int n = (int)(pix / HW);
+    float v[8];
+    load8(dout + (size_t)n * C + cc * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= inv;
+    store8(dx + pix * C + cc * 8, v);
+  }
+}
+
+// image f32 NCHW [N][3][H][W] -> T [N][H+2*pad][Wp][4], zero padded (channel 3 = 0)
+template <typename T>
+__global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* img, T* out, int N, int H, int W, int pad, int Hp, int Wp) {
+  size_t total = (size_t)N * Hp * Wp;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int wp = (int)(i % Wp);
+    int hp = (int)((i / Wp) % Hp);
+    int n = (int)(i / ((size_t)Wp * Hp));
+    int h = hp - pad, w = wp - pad;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = img[(((size_t)n * 3 + c) * H + h) * W + w];
+    }
+    if constexpr (sizeof(T) == 2) {
+      union { bf16 e[4]; u32x2 u; } pk;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pk.e[c] = f2bf(v[c]);
+      *(u32x2*)(out + i * 4) = pk.u;
+    } else {
+      *(f32x4*)(out + i * 4) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+}
+
+// out[c] += sum_m x[m][c]  (bias gradients). grid = (ceil(N/8/256), row slabs)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int M, int N, int rows_per_block) {
+  int chunk = blockIdx.x * 256 + threadIdx.x;
+  if (chunk >= N / 8) return;
+  int row_begin = blockIdx.y * rows_per_block, row_end = row_begin + rows_per_block;
+  if (row_end > M) row_end = M;
+  float acc[8];
+  zero8(acc);
+  for (int r = row_begin; r < row_end; ++r) {
+    float v[8];
+    load8(x + (size_t)r * N + chunk * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomic_add_f32(out + chunk * 8 + e, acc[e]);
+}
+
+int ew_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 4096 ? (g ? g : 1) : 4096);
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, CALL_BF16, CALL_F32) \
+  if ((dtype) == CLITE_BF16) { CALL_BF16; } else if ((dtype) == CLITE_F32) { CALL_F32; } else return -1;
+
+extern "C" int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const void* res, void* out, void* stream) {
+  if (!p || !bn_ok(p->M, p->C) || !y || !out) return -1;
+  int rpb;
+  int grid = bn_grid(p->M, p->C, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb),
+           hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *p, (const float*)y, (const float*)res, (float*)out, rpb));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, float* dstats, int M, int C, void* stream) {
+  if (!bn_ok(M, C) || !dout || !y || !dstats) return -1;
+  int rpb;
+  int grid = bn_grid(M, C, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, dstats, M, C, rpb),
+           hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, dstats, M, C, rpb));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const void* y, const float* dstats,
+                                  void* dy, void* dz, float* dgamma, float* dbeta, void* stream) {
+  if (!p || !bn_ok(p->M, p->C) || !dout || !y || !dstats || !dy) return -1;
+  int rpb;
+  int grid = bn_grid(p->M, p->C, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),
+           hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *p, (const float*)dout, (const float*)mask, (const float*)y, dstats, (float*)dy, (float*)dz, dgamma, dbeta, rpb));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_maxpool3x3s2_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
+  if (C % 8 || N <= 0) return -1;
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  int grid = ew_grid((size_t)N * Ho * Wo * (C / 8));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)out, idx, N, H, W, C, Ho, Wo),
+           hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, idx, N, H, W, C, Ho, Wo));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream) {
+  if (C % 8 || N <= 0) return -1;
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  int grid = ew_grid((size_t)N * H * W * (C / 8));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, N, H, W, C, Ho, Wo),
+           hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, idx, (float*)dx, N, H, W, C, Ho, Wo));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream) {
+  if (C % 8 || N <= 0) return -1;
+  int grid = (N * (C / 8) + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(avgpool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)out, N, HW, C),
+           hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, N, HW, C));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_avgpool_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, void* stream) {
+  if (C % 8 || N <= 0) return -1;
+  int grid = ew_grid((size_t)N * HW * (C / 8));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, (bf16*)dx, N, HW, C),
+           hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (float*)dx, N, HW, C));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_image_to_nhwc4(int dtype, const float* img, void* out, int N, int H, int W, int pad, int Hp, int Wp, void* stream) {
+  if (N <= 0 || Hp < H + 2 * pad || Wp < W + 2 * pad) return -1;
+  int grid = ew_grid((size_t)N * Hp * Wp);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(image_to_nhwc4_kernel<bf16>, dim3(grid), dim3(256), 0, st, img, (bf16*)out, N, H, W, pad, Hp, Wp),
+           hipLaunchKernelGGL(image_to_nhwc4_kernel<float>, dim3(grid), dim3(256), 0, st, img, (float*)out, N, H, W, pad, Hp, Wp));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_colsum(int dtype, const void* x, float* out, int M, int N, void* stream) {
+  if (M <= 0 || N <= 0 || N % 8) return -1;
+  int gx = (N / 8 + 255) / 256;
+  int slabs = 512 / gx;
+  if (slabs < 1) slabs = 1;
+  if (slabs > M) slabs = M;
+  int rpb = (M + slabs - 1) / slabs;
+  slabs = (M + rpb - 1) / rpb;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(gx, slabs), dim3(256), 0, st, (const bf16*)x, out, M, N, rpb),
+           hipLaunchKernelGGL(colsum_kernel<float>, dim3(gx, slabs), dim3(256), 0, st, (const float*)x, out, M, N, rpb));
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,45 @@
+// 8-element vector load/store helpers shared by all kernels: activations are stored as bf16 (production) or f32
+// (exact parity mode); all arithmetic happens in f32 registers.
+#ifndef CLITE_VEC_H
+#define CLITE_VEC_H
+#include "intrin.h"
+
+namespace clite {
+
+// 8 consecutive elements <-> fp32 registers
+DEV void load8(const bf16* p, float (&v)[8]) {
+  Chunk16 c;
+  c.u = *(const u32x4*)p;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(c.e[e]);
+}
+DEV void load8(const float* p, float (&v)[8]) {
+  f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+DEV void store8(bf16* p, const float (&v)[8]) {
+  Chunk16 c;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c.e[e] = f2bf(v[e]);
+  *(u32x4*)p = c.u;
+}
+DEV void store8(float* p, const float (&v)[8]) {
+  *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+  *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+DEV void round8_bf16(float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+}
+
+DEV void zero8(float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+}
+
+template <typename T> struct DType;
+template <> struct DType<bf16> { static constexpr int id = 0; };
+template <> struct DType<float> { static constexpr int id = 1; };
+
+}  // namespace clite
+#endif

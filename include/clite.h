@@ -77,6 +77,56 @@ int clite_conv_dgrad(const void* dy, const void* w, const clite_conv* cv, const 
 /* dw[K][R][S][C] (f32) += dy^T * im2col(x): autograd of the same call; float-atomic split-K. */
 int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream);
 
+/* ResNet stem conv1 = nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (torchvision, reference encoder.py:36-38) on the
+ * pre-padded NHWC4 image from clite_image_to_nhwc4 (Hp >= 2*(Ho-1)+7, Wp >= 2*(Wo-1)+8, Wp even). wv is the weight packed
+ * as [64][7][8][4] (clite_stem_pack from f32 [64][7][7][3]); clite_stem_unpack_grad folds the packed gradient back (+=). */
+int clite_stem_fwd(const void* xpad, const void* wv, int dtype, int N, int Hp, int Wp, int Ho, int Wo, const clite_epilogue* ep, void* stream);
+int clite_stem_wgrad(const void* dy, const void* xpad, int dtype, int N, int Hp, int Wp, int Ho, int Wo, float* dwv, void* stream);
+int clite_stem_pack(const float* w, void* wv, int dtype, void* stream);
+int clite_stem_unpack_grad(const float* dwv, float* dw, void* stream);
+
+/* ---- BatchNorm2d / BatchNorm1d, train-mode batch statistics (torchvision ResNet BN behind reference
+ * encoder.py:36-65; nn.BatchNorm1d at loss.py:18). Tensors are [M][C] (NHWC flattened), C % 8 == 0, C/8 divides 256.
+ * `stats` = per-channel (sum, sum of squares) [2][C] f32 over the M rows, produced by the conv/GEMM epilogue
+ * (clite_epilogue.colsum). Biased variance normalises; unbiased variance goes into running_var. */
+typedef struct clite_bn {
+  int32_t M, C;
+  const float* stats;        /* [2][C] */
+  const float* gamma;        /* [C] */
+  const float* beta;         /* [C] */
+  float* running_mean;       /* [C] */
+  float* running_var;        /* [C] */
+  int32_t training;          /* 1: batch statistics; 0: running statistics (eval) */
+  int32_t update_running;    /* 1: workgroup 0 updates running_* with `momentum` */
+  float momentum, eps;
+  int32_t relu;              /* apply ReLU at the end */
+  /* optional second BN applied to the residual operand (the 1x1/stride downsample branch of a block) */
+  const float* res_stats;
+  const float* res_gamma;
+  const float* res_beta;
+  float* res_running_mean;
+  float* res_running_var;
+} clite_bn;
+
+/* out = relu?( bn(y) + [res | bn_res(res)] ) */
+int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const void* res, void* out, void* stream);
+/* dstats[0][c] += sum dz, dstats[1][c] += sum dz*y, dz = dout * (mask > 0) (mask NULL: dz = dout). dstats pre-zeroed. */
+int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, float* dstats, int M, int C, void* stream);
+/* dy = BN backward of dz through batch statistics; dz (optional) <- masked dout; dgamma/dbeta (optional) += . */
+int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const void* y, const float* dstats,
+                       void* dy, void* dz, float* dgamma, float* dbeta, void* stream);
+
+/* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem; idx holds the window position (0..8) of the first maximum. */
+int clite_maxpool3x3s2_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
+int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream);
+/* nn.AdaptiveAvgPool2d((1,1)) + view (reference encoder.py:63-65): [N][HW][C] -> [N][C] */
+int clite_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream);
+int clite_avgpool_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, void* stream);
+/* batch["image"] f32 NCHW [N][3][H][W] -> zero-padded NHWC4 [N][Hp][Wp][4] (the layout the 7x7 stem conv gathers from) */
+int clite_image_to_nhwc4(int dtype, const float* img, void* out, int N, int H, int W, int pad, int Hp, int Wp, void* stream);
+/* out[n] += sum_m x[m][n]  — bias gradients */
+int clite_colsum(int dtype, const void* x, float* out, int M, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

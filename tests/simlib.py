@@ -70,3 +70,30 @@ def make_ep(out, ldc, out_f32=False, atomic=False, alpha=1.0, bias=None, act=0, 
     ep.drop_p = drop_p; ep.drop_seed = drop_seed; ep.drop_site = drop_site
     ep.residual = ptr(residual); ep.colsum = ptr(colsum)
     return ep
+
+
+class Bn(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("C", C.c_int32), ("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("training", C.c_int32),
+        ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32),
+        ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
+        ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p),
+    ]
+
+
+def prep(x, dtype):
+    """(values the kernel sees as f32, buffer to pass) for dtype 0 = bf16, 1 = f32"""
+    if dtype == 0:
+        xr = bf16_round(x)
+        return xr, to_bf16(xr)
+    x = np.ascontiguousarray(x, np.float32)
+    return x, x
+
+
+def outbuf(shape, dtype):
+    return np.zeros(shape, np.uint16 if dtype == 0 else np.float32)
+
+
+def val(buf, dtype):
+    return from_bf16(buf) if dtype == 0 else buf

@@ -133,3 +133,31 @@ def test_conv_fwd_dgrad_wgrad(dtype, N, H, W, Cc, K, R, S, st, pad):
     dw = np.zeros((K, R, S, Cc), np.float32)
     assert lib().clite_conv_wgrad(ptr(dyb), ptr(xb), C.byref(cv), ptr(dw), None) == 0
     _close(dw, conv_wgrad_ref(dy, x, w.shape, st, pad))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_stem_conv7x7(dtype):
+    """7x7/2 pad-3 stem expressed as a 7x1 window over 32 virtual channels of the pre-padded NHWC4 image."""
+    rng = np.random.default_rng(7)
+    N, H, W = 2, 20, 18
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = H + 6, W + 6 + 2
+    Wp += Wp % 2
+    img = rng.standard_normal((N, 3, H, W), dtype=np.float32)
+    w = (rng.standard_normal((64, 7, 7, 3), dtype=np.float32) * 0.1)
+    xpad = np.zeros((N, Hp, Wp, 4), np.uint16 if dtype == BF16 else np.float32)
+    assert lib().clite_image_to_nhwc4(dtype, ptr(img), ptr(xpad), N, H, W, 3, Hp, Wp, None) == 0
+    wv = np.zeros((64, 7, 8, 4), np.uint16 if dtype == BF16 else np.float32)
+    assert lib().clite_stem_pack(ptr(w), ptr(wv), dtype, None) == 0
+    imgr = bf16_round(img) if dtype == BF16 else img
+    wr = bf16_round(w) if dtype == BF16 else w
+    y = np.zeros((N, Ho, Wo, 64), np.float32)
+    assert lib().clite_stem_fwd(ptr(xpad), ptr(wv), dtype, N, Hp, Wp, Ho, Wo, C.byref(make_ep(y, 64, out_f32=True)), None) == 0
+    ref = conv_ref(imgr.transpose(0, 2, 3, 1), wr, 2, 3)
+    _close(y, ref)
+    dy, dyb = _prep(rng.standard_normal((N, Ho, Wo, 64), dtype=np.float32), dtype)
+    dwv = np.zeros((64, 7, 8, 4), np.float32)
+    assert lib().clite_stem_wgrad(ptr(dyb), ptr(xpad), dtype, N, Hp, Wp, Ho, Wo, ptr(dwv), None) == 0
+    dw = np.ones((64, 7, 7, 3), np.float32)
+    assert lib().clite_stem_unpack_grad(ptr(dwv), ptr(dw), None) == 0
+    _close(dw, 1 + conv_wgrad_ref(dy, imgr.transpose(0, 2, 3, 1), w.shape, 2, 3))
