@@ -1,0 +1,420 @@
+// Kernels of the BERT text encoder outside the GEMMs (reference encoder.py:165-196 -> transformers.BertModel,
+// BertConfig defaults: hidden 768, 12 heads x 64, LayerNorm eps 1e-12, dropout 0.1, additive attention mask,
+// pooler = tanh(W h_CLS + b)): embedding gather, LayerNorm forward/backward (also nn.LayerNorm of the MI heads,
+// loss.py:23), per-head attention forward/backward for captions of <= 32 tokens (config.py:69: 30).
+#include "vec.h"
+#include "rng.h"
+#include "clite.h"
+
+using namespace clite;
+
+namespace {
+
+constexpr int LN_MAXCH = 4;   // 8-element chunks per lane: C <= 64*4*8 = 2048
+
+struct Drop { float p; uint64_t seed; uint32_t site; };
+
+DEV void apply_dropout8(const Drop& d, size_t idx, float (&v)[8]) {
+  float u[8];
+  dropout_uniform8(d.seed, d.site, idx, u);
+  float ks = 1.0f / (1.0f - d.p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = u[e] >= d.p ? v[e] * ks : 0.f;
+}
+
+// one wave per row; out = dropout((x - mean) * rstd * gamma + beta); stats[row] = (mean, rstd)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, float eps, T* out,
+                                                            float* stats, int M, int C, Drop drop) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = C / 8;
+  const float invC = 1.0f / (float)C;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float v[LN_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+        load8(x + (size_t)row * C + c * 8, v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    float mean = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = v[i][e] - mean; q += d * d; }
+      }
+    }
+    float rstd = rsqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+        float g[8], b[8], o[8];
+        load8(gamma + c * 8, g);
+        load8(beta + c * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+        size_t idx = (size_t)row * C + c * 8;
+        if (drop.p > 0.f) apply_dropout8(drop, idx, o);
+        store8(out + idx, o);
+      }
+    }
+    if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  }
+}
+
+// dy' = dropout_mask_in(dy); dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy'*gamma; dgamma += sum dy'*xhat; dbeta += sum dy'
+// optional second output dx_masked = dropout_mask_out(dx)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_masked,
+                                                            float* dgamma, float* dbeta, int M, int C, Drop drop_in, Drop drop_out) {
+  __shared__ float red[4][64 * LN_MAXCH * 8];   // [wave][per-lane partials], used once for dgamma and once for dbeta
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = C / 8;
+  const float invC = 1.0f / (float)C;
+  float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAXCH; ++i) { zero8(ag[i]); zero8(ab[i]); }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float d[LN_MAXCH][8], xh[LN_MAXCH][8], g[LN_MAXCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+        size_t idx = (size_t)row * C + c * 8;
+        load8(dy + idx, d[i]);
+        if (drop_in.p > 0.f) apply_dropout8(drop_in, idx, d[i]);
+        float xv[8], gm[8];
+        load8(x + idx, xv);
+        load8(gamma + c * 8, gm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (xv[e] - mean) * rstd;
+          g[i][e] = d[i][e] * gm[e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+          ag[i][e] += d[i][e] * xh[i][e];
+          ab[i][e] += d[i][e];
+        }
+      }
+    }
+    float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+        size_t idx = (size_t)row * C + c * 8;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - m1 - xh[i][e] * m2);
+        store8(dx + idx, o);
+        if (dx_masked) {
+          if (drop_out.p > 0.f) apply_dropout8(drop_out, idx, o);
+          store8(dx_masked + idx, o);
+        }
+      }
+    }
+  }
+  // fold the 4 waves' partial dgamma/dbeta through LDS (two passes to bound LDS), one atomic per column per block
+  for (int which = 0; which < 2; ++which) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < LN_MAXCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][(i * 64 + lane) * 8 + e] = which == 0 ? ag[i][e] : ab[i][e];
+    __syncthreads();
+    float* dst = which == 0 ? dgamma : dbeta;
+    if (dst) {
+      for (int j = threadIdx.x; j < LN_MAXCH * 64 * 8; j += 256) {
+        int i = j / 512, l = (j / 8) % 64, e = j % 8;
+        int c = l + 64 * i;
+        if (c < nchunk) atomic_add_f32(dst + c * 8 + e, red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+      }
+    }
+  }
+}
+
+// s0[row] = word[ids[row]] + pos[row % L] + type[0]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* ids, const T* word, const T* pos, const T* type, T* out, int M, int L, int C, int vocab) {
+  const int nchunk = C / 8;
+  size_t total = (size_t)M * nchunk;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % nchunk);
+    int row = (int)(i / nchunk);
+    int64_t id = ids[row];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    float a[8], b[8], t[8];
+    load8(word + (size_t)id * C + c * 8, a);
+    load8(pos + (size_t)(row % L) * C + c * 8, b);
+    load8(type + c * 8, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e] + t[e];
+    store8(out + (size_t)row * C + c * 8, a);
+  }
+}
+
+// dword[ids[row]] += d[row] (float atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* d, float* dword, int M, int C, int vocab) {
+  const int nchunk = C / 8;
+  size_t total = (size_t)M * nchunk;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int c = (int)(i % nchunk);
+    int row = (int)(i / nchunk);
+    int64_t id = ids[row];
+    if (id < 0) id = 0;
+    if (id >= vocab) id = vocab - 1;
+    float v[8];
+    load8(d + (size_t)row * C + c * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomic_add_f32(dword + (size_t)id * C + c * 8 + e, v[e]);
+  }
+}
+// dpos[l] += sum_b d[b*L + l]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* d, float* dpos, int B, int L, int C) {
+  const int nchunk = C / 8;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= L * nchunk) return;
+  int c = i % nchunk, l = i / nchunk;
+  float acc[8];
+  zero8(acc);
+  for (int b = 0; b < B; ++b) {
+    float v[8];
+    load8(d + ((size_t)b * L + l) * C + c * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dpos[(size_t)l * C + c * 8 + e] += acc[e];
+}
+
+// ------------------------------------------------------------------------------------------------ attention, L <= 32
+// One wave per (batch, head). qkv: [B*L][3*H*64] (q | k | v, head h at columns h*64..). ctx: [B*L][H*64].
+constexpr int AT_L = 32, AT_D = 64, AT_PQ = AT_D + 1, AT_PP = AT_L + 1;
+#define AT_NEG (-3.4028234663852886e38f)
+
+struct AttnSmem {
+  float q[AT_L * AT_PQ], k[AT_L * AT_PQ], v[AT_L * AT_PQ], p[AT_L * AT_PP];
+  float m[AT_L * AT_PP];   // dropout multiplier of p[i][j]: 0 or 1/(1-p)
+};
+
+// m[i][j] for one (batch, head): element index ((bh*32 + i)*32 + j); each lane draws 4 consecutive j per Philox call
+DEV void attn_dropmask(AttnSmem& sm, const Drop& drop, int bh, int lane) {
+  const float ks = drop.p > 0.f ? 1.0f / (1.0f - drop.p) : 1.f;
+  for (int q4 = lane; q4 < AT_L * AT_L / 4; q4 += 64) {
+    int i = q4 >> 3, j0 = (q4 & 7) * 4;
+    float u[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop.p > 0.f) rng_uniform4(drop.seed, drop.site, ((size_t)bh * AT_L + i) * AT_L + j0, u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm.m[i * AT_PP + j0 + e] = u[e] >= drop.p ? ks : 0.f;
+  }
+}
+
+template <typename T>
+DEV void attn_load_rows(const T* base, size_t row_stride, int L, float* dst, int lane) {
+  // L rows x 64 values; 8 lanes per row, 8 rows per pass
+  for (int r0 = 0; r0 < AT_L; r0 += 8) {
+    int r = r0 + (lane >> 3), c = (lane & 7) * 8;
+    float v[8];
+    if (r < L) load8(base + (size_t)r * row_stride + c, v); else zero8(v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[r * AT_PQ + c + e] = v[e];
+  }
+}
+
+// scores + softmax for all rows: p[i][j] (un-dropped probabilities), i,j < 32 (rows/cols >= L are zero)
+DEV void attn_probs(AttnSmem& sm, const int64_t* mask_row, int L, int lane) {
+  const int j = lane & 31, half = lane >> 5;
+  const bool jvalid = j < L;
+  float madd = 0.f;
+  if (jvalid && mask_row) madd = mask_row[j] != 0 ? 0.f : AT_NEG;
+  for (int i0 = 0; i0 < AT_L; i0 += 2) {
+    int i = i0 + half;
+    float s = 0.f;
+#pragma unroll 16
+    for (int d = 0; d < AT_D; ++d) s += sm.q[i * AT_PQ + d] * sm.k[j * AT_PQ + d];
+    s = s * 0.125f + madd;
+    if (!jvalid) s = -INFINITY;
+    float mx = s;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) mx = fmaxf(mx, wave_shfl_xor(mx, m));
+    float e = jvalid ? __expf(s - mx) : 0.f;
+    float den = e;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) den += wave_shfl_xor(den, m);
+    sm.p[i * AT_PP + j] = (i < L) ? e / den : 0.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attention_fwd_kernel(const T* qkv, const int64_t* mask, T* ctx, int B, int L, int H, Drop drop) {
+  __shared__ AttnSmem sm;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t ld = (size_t)3 * H * AT_D;
+  const T* base = qkv + (size_t)b * L * ld + h * AT_D;
+  attn_load_rows(base, ld, L, sm.q, lane);
+  attn_load_rows(base + H * AT_D, ld, L, sm.k, lane);
+  attn_load_rows(base + 2 * H * AT_D, ld, L, sm.v, lane);
+  __syncthreads();
+  attn_probs(sm, mask ? mask + (size_t)b * L : nullptr, L, lane);
+  attn_dropmask(sm, drop, b * H + h, lane);
+  __syncthreads();
+  for (int i = 0; i < L; ++i) {
+    float o = 0.f;
+    for (int j = 0; j < L; ++j) o += sm.p[i * AT_PP + j] * sm.m[i * AT_PP + j] * sm.v[j * AT_PQ + lane];
+    size_t oi = ((size_t)b * L + i) * ((size_t)H * AT_D) + h * AT_D + lane;
+    if constexpr (sizeof(T) == 2) ctx[oi] = f2bf(o); else ctx[oi] = o;
+  }
+}
+
+struct AttnBwdSmem {
+  AttnSmem f;
+  float dO[AT_L * AT_PQ], dS[AT_L * AT_PP];
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void attention_bwd_kernel(const T* qkv, const int64_t* mask, const T* dctx, T* dqkv, int B, int L, int H, Drop drop) {
+  __shared__ AttnBwdSmem sm;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const size_t ld = (size_t)3 * H * AT_D;
+  const T* base = qkv + (size_t)b * L * ld + h * AT_D;
+  attn_load_rows(base, ld, L, sm.f.q, lane);
+  attn_load_rows(base + H * AT_D, ld, L, sm.f.k, lane);
+  attn_load_rows(base + 2 * H * AT_D, ld, L, sm.f.v, lane);
+  attn_load_rows(dctx + (size_t)b * L * ((size_t)H * AT_D) + h * AT_D, (size_t)H * AT_D, L, sm.dO, lane);
+  __syncthreads();
+  attn_probs(sm.f, mask ? mask + (size_t)b * L : nullptr, L, lane);
+  attn_dropmask(sm.f, drop, b * H + h, lane);
+  __syncthreads();
+  const int j = lane & 31, half = lane >> 5;
+  // dP[i][j] = keep[i][j]*ks * sum_d dO[i][d] V[j][d];  dS = P * (dP - sum_j dP*P)
+  for (int i0 = 0; i0 < AT_L; i0 += 2) {
+    int i = i0 + half;
+    float dp = 0.f;
+#pragma unroll 16
+    for (int d = 0; d < AT_D; ++d) dp += sm.dO[i * AT_PQ + d] * sm.f.v[j * AT_PQ + d];
+    dp *= sm.f.m[i * AT_PP + j];
+    float pij = sm.f.p[i * AT_PP + j];
+    float t = dp * pij;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) t += wave_shfl_xor(t, m);
+    sm.dS[i * AT_PP + j] = pij * (dp - t);
+  }
+  __syncthreads();
+  // lane = d.  dV[j][d] = sum_i Pd[i][j] dO[i][d];  dK[j][d] = sum_i dS[i][j] Q[i][d] / 8;  dQ[i][d] = sum_j dS[i][j] K[j][d] / 8
+  T* obase = dqkv + (size_t)b * L * ld + h * AT_D;
+  for (int r = 0; r < L; ++r) {
+    float dq = 0.f, dk = 0.f, dv = 0.f;
+    for (int t = 0; t < L; ++t) {
+      dq += sm.dS[r * AT_PP + t] * sm.f.k[t * AT_PQ + lane];
+      dk += sm.dS[t * AT_PP + r] * sm.f.q[t * AT_PQ + lane];
+      dv += sm.f.p[t * AT_PP + r] * sm.f.m[t * AT_PP + r] * sm.dO[t * AT_PQ + lane];
+    }
+    dq *= 0.125f; dk *= 0.125f;
+    T* o = obase + (size_t)r * ld + lane;
+    if constexpr (sizeof(T) == 2) { o[0] = f2bf(dq); o[H * AT_D] = f2bf(dk); o[2 * H * AT_D] = f2bf(dv); }
+    else { o[0] = dq; o[H * AT_D] = dk; o[2 * H * AT_D] = dv; }
+  }
+}
+
+int ew_grid(size_t total) {
+  size_t g = (total + 255) / 256;
+  return (int)(g < 4096 ? (g ? g : 1) : 4096);
+}
+int ln_ok(int M, int C) { return M > 0 && C % 8 == 0 && C >= 8 && C <= 64 * LN_MAXCH * 8; }
+
+}  // namespace
+
+#define DISPATCH(dtype, CALL_BF16, CALL_F32) \
+  if ((dtype) == CLITE_BF16) { CALL_BF16; } else if ((dtype) == CLITE_F32) { CALL_F32; } else return -1;
+
+extern "C" int clite_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* out, float* stats,
+                                   int M, int C, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream) {
+  if (!ln_ok(M, C) || !x || !out) return -1;
+  int grid = (M + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  Drop d{drop_p, drop_seed, drop_site};
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d),
+           hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, eps, (float*)out, stats, M, C, d));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx, void* dx_masked,
+                                   float* dgamma, float* dbeta, int M, int C, float in_p, uint64_t in_seed, uint32_t in_site,
+                                   float out_p, uint64_t out_seed, uint32_t out_site, void* stream) {
+  if (!ln_ok(M, C) || !dy || !x || !stats || !dx) return -1;
+  int grid = (M + 3) / 4;
+  if (grid > 512) grid = 512;
+  Drop di{in_p, in_seed, in_site}, dout{out_p, out_seed, out_site};
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
+           hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_embed_fwd(int dtype, const int64_t* ids, const void* word, const void* pos, const void* type, void* out,
+                               int M, int L, int C, int vocab, void* stream) {
+  if (M <= 0 || L <= 0 || C % 8 || !ids || !out) return -1;
+  int grid = ew_grid((size_t)M * (C / 8));
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(embed_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, ids, (const bf16*)word, (const bf16*)pos, (const bf16*)type, (bf16*)out, M, L, C, vocab),
+           hipLaunchKernelGGL(embed_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, ids, (const float*)word, (const float*)pos, (const float*)type, (float*)out, M, L, C, vocab));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_embed_bwd(int dtype, const int64_t* ids, const void* d, float* dword, float* dpos, int M, int L, int C, int vocab, void* stream) {
+  if (M <= 0 || L <= 0 || M % L || C % 8 || !ids || !d) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  int g1 = ew_grid((size_t)M * (C / 8)), g2 = (L * (C / 8) + 255) / 256;
+  if (dword) {
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(embed_bwd_word_kernel<bf16>, dim3(g1), dim3(256), 0, st, ids, (const bf16*)d, dword, M, C, vocab),
+             hipLaunchKernelGGL(embed_bwd_word_kernel<float>, dim3(g1), dim3(256), 0, st, ids, (const float*)d, dword, M, C, vocab));
+  }
+  if (dpos) {
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(embed_bwd_pos_kernel<bf16>, dim3(g2), dim3(256), 0, st, (const bf16*)d, dpos, M / L, L, C),
+             hipLaunchKernelGGL(embed_bwd_pos_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)d, dpos, M / L, L, C));
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_attention_fwd(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int H,
+                                   float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream) {
+  if (B <= 0 || L <= 0 || L > AT_L || H <= 0 || !qkv || !ctx) return -1;
+  Drop d{drop_p, drop_seed, drop_site};
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(attention_fwd_kernel<bf16>, dim3(B * H), dim3(64), 0, st, (const bf16*)qkv, mask, (bf16*)ctx, B, L, H, d),
+           hipLaunchKernelGGL(attention_fwd_kernel<float>, dim3(B * H), dim3(64), 0, st, (const float*)qkv, mask, (float*)ctx, B, L, H, d));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_attention_bwd(int dtype, const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int H,
+                                   float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream) {
+  if (B <= 0 || L <= 0 || L > AT_L || H <= 0 || !qkv || !dctx || !dqkv) return -1;
+  Drop d{drop_p, drop_seed, drop_site};
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(attention_bwd_kernel<bf16>, dim3(B * H), dim3(64), 0, st, (const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, H, d),
+           hipLaunchKernelGGL(attention_bwd_kernel<float>, dim3(B * H), dim3(64), 0, st, (const float*)qkv, mask, (const float*)dctx, (float*)dqkv, B, L, H, d));
+  return (int)hipGetLastError();
+}

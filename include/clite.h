@@ -127,6 +127,27 @@ int clite_image_to_nhwc4(int dtype, const float* img, void* out, int N, int H, i
 /* out[n] += sum_m x[m][n]  — bias gradients */
 int clite_colsum(int dtype, const void* x, float* out, int M, int N, void* stream);
 
+/* ---- BERT text encoder pieces outside the GEMMs (transformers.BertModel behind reference encoder.py:165-196).
+ * Dropout masks are a pure function of (seed, site, element index) so backward regenerates them (csrc/rng.h). */
+/* out = dropout(LayerNorm(x)); stats[row] = (mean, rstd) f32. C % 8 == 0, C <= 2048. Also nn.LayerNorm at loss.py:23. */
+int clite_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* out, float* stats,
+                        int M, int C, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream);
+/* dx = LayerNorm backward of dropout_in(dy); dx_masked (optional) = dropout_out(dx); dgamma/dbeta (optional) += . */
+int clite_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx, void* dx_masked,
+                        float* dgamma, float* dbeta, int M, int C, float in_p, uint64_t in_seed, uint32_t in_site,
+                        float out_p, uint64_t out_seed, uint32_t out_site, void* stream);
+/* BertEmbeddings sum: out[row] = word[ids[row]] + pos[row % L] + type[0] (token_type_ids = 0, position_ids = arange(L)) */
+int clite_embed_fwd(int dtype, const int64_t* ids, const void* word, const void* pos, const void* type, void* out,
+                    int M, int L, int C, int vocab, void* stream);
+/* dword[ids[row]] += d[row] (float atomics); dpos[l] += sum_b d[b*L+l]. Either may be NULL. */
+int clite_embed_bwd(int dtype, const int64_t* ids, const void* d, float* dword, float* dpos, int M, int L, int C, int vocab, void* stream);
+/* BertSelfAttention core for L <= 32, head size 64: qkv [B*L][3*H*64] (q|k|v), mask int64 [B][L] (1 = attend) or NULL,
+ * ctx [B*L][H*64] = dropout(softmax(q k^T / 8 + (1-mask)*finfo.min)) v */
+int clite_attention_fwd(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int H,
+                        float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream);
+int clite_attention_bwd(int dtype, const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int H,
+                        float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

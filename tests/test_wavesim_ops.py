@@ -110,3 +110,107 @@ def test_pools_and_image(dtype):
     cs = np.ones(Cc, np.float32)
     assert lib().clite_colsum(dtype, ptr(xb), ptr(cs), N * H * W, Cc, None) == 0
     _close(cs, 1 + x.reshape(-1, Cc).sum(0), 1e-4)
+
+
+def _ln_ref(x, g, b, eps):
+    mean = x.mean(1, keepdims=True); var = x.var(1, keepdims=True)
+    xh = (x - mean) / np.sqrt(var + eps)
+    return xh * g + b, xh, 1 / np.sqrt(var + eps)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("M,Cc", [(9, 768), (5, 2048), (3, 64)])
+def test_layernorm_fwd_bwd(dtype, M, Cc):
+    rng = np.random.default_rng(Cc)
+    x, xb = prep(rng.standard_normal((M, Cc), dtype=np.float32) * 1.5 + 0.3, dtype)
+    g = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    out = outbuf((M, Cc), dtype); stats = np.zeros((M, 2), np.float32)
+    L = lib()
+    L.clite_layernorm_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
+    assert L.clite_layernorm_fwd(dtype, ptr(xb), ptr(g), ptr(b), 1e-12, ptr(out), ptr(stats), M, Cc, 0.0, 0, 0, None) == 0
+    ref, xh, rstd = _ln_ref(x, g, b, 1e-12)
+    _close(val(out, dtype), ref, _tol(dtype))
+    _close(stats[:, 0], x.mean(1), 1e-5)
+    dy, dyb = prep(rng.standard_normal((M, Cc), dtype=np.float32), dtype)
+    dx = outbuf((M, Cc), dtype); dg = np.ones(Cc, np.float32); db = np.ones(Cc, np.float32)
+    L.clite_layernorm_bwd.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
+    assert L.clite_layernorm_bwd(dtype, ptr(dyb), ptr(xb), ptr(stats), ptr(g), ptr(dx), None, ptr(dg), ptr(db), M, Cc, 0.0, 0, 0, 0.0, 0, 0, None) == 0
+    gg = dy * g
+    dxref = rstd * (gg - gg.mean(1, keepdims=True) - xh * (gg * xh).mean(1, keepdims=True))
+    _close(val(dx, dtype), dxref, _tol(dtype))
+    _close(dg, 1 + (dy * xh).sum(0), 1e-3)
+    _close(db, 1 + dy.sum(0), 1e-3)
+    # dropout: forward output mask == backward input mask == backward dx_masked mask for equal (seed, site)
+    outd = outbuf((M, Cc), dtype)
+    assert L.clite_layernorm_fwd(dtype, ptr(xb), ptr(g), ptr(b), 1e-12, ptr(outd), ptr(stats), M, Cc, 0.25, 1234, 7, None) == 0
+    od = val(outd, dtype)
+    keep = od != 0
+    assert abs(keep.mean() - 0.75) < 0.05
+    _close(od[keep], (ref / 0.75)[keep], _tol(dtype))
+    dxm = outbuf((M, Cc), dtype)
+    assert L.clite_layernorm_bwd(dtype, ptr(dyb), ptr(xb), ptr(stats), ptr(g), ptr(dx), ptr(dxm), None, None, M, Cc, 0.0, 0, 0, 0.25, 1234, 7, None) == 0
+    assert np.array_equal(val(dxm, dtype) != 0, keep & (val(dx, dtype) != 0))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_embedding_fwd_bwd(dtype):
+    rng = np.random.default_rng(5)
+    B, Ls, Cc, V = 3, 7, 64, 50
+    ids = rng.integers(0, V, (B, Ls)).astype(np.int64)
+    word, wb = prep(rng.standard_normal((V, Cc), dtype=np.float32), dtype)
+    pos, pb = prep(rng.standard_normal((16, Cc), dtype=np.float32), dtype)
+    typ, tb = prep(rng.standard_normal((2, Cc), dtype=np.float32), dtype)
+    out = outbuf((B * Ls, Cc), dtype)
+    assert lib().clite_embed_fwd(dtype, ptr(ids), ptr(wb), ptr(pb), ptr(tb), ptr(out), B * Ls, Ls, Cc, V, None) == 0
+    ref = word[ids.reshape(-1)] + np.tile(pos[:Ls], (B, 1)) + typ[0]
+    _close(val(out, dtype), ref, _tol(dtype))
+    d, dbuf = prep(rng.standard_normal((B * Ls, Cc), dtype=np.float32), dtype)
+    dword = np.zeros((V, Cc), np.float32); dpos = np.zeros((16, Cc), np.float32)
+    assert lib().clite_embed_bwd(dtype, ptr(ids), ptr(dbuf), ptr(dword), ptr(dpos), B * Ls, Ls, Cc, V, None) == 0
+    rw = np.zeros((V, Cc), np.float32)
+    np.add.at(rw, ids.reshape(-1), d)
+    _close(dword, rw, 1e-5)
+    _close(dpos[:Ls], d.reshape(B, Ls, Cc).sum(0), 1e-5)
+
+
+def _attn_ref(qkv, mask, B, Ls, H):
+    q, k, v = [qkv.reshape(B, Ls, 3, H, 64)[:, :, i].transpose(0, 2, 1, 3) for i in range(3)]   # [B,H,L,64]
+    s = q @ k.transpose(0, 1, 3, 2) / 8.0 + ((1 - mask)[:, None, None, :] * np.finfo(np.float32).min)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s); p /= p.sum(-1, keepdims=True)
+    return q, k, v, p, (p @ v)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("Ls", [7, 30])
+def test_attention_fwd_bwd(dtype, Ls):
+    rng = np.random.default_rng(Ls)
+    B, H = 2, 2
+    qkv, qb = prep(rng.standard_normal((B * Ls, 3 * H * 64), dtype=np.float32), dtype)
+    mask = np.ones((B, Ls), np.int64); mask[1, Ls - 2:] = 0
+    L = lib()
+    sig = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.clite_attention_fwd.argtypes = sig
+    L.clite_attention_bwd.argtypes = sig[:4] + [C.c_void_p] + sig[4:]
+    ctx = outbuf((B * Ls, H * 64), dtype)
+    assert L.clite_attention_fwd(dtype, ptr(qb), ptr(mask), ptr(ctx), B, Ls, H, 0.0, 0, 0, None) == 0
+    q, k, v, p, o = _attn_ref(qkv, mask.astype(np.float32), B, Ls, H)
+    _close(val(ctx, dtype), o.transpose(0, 2, 1, 3).reshape(B * Ls, H * 64), _tol(dtype))
+    do, dob = prep(rng.standard_normal((B * Ls, H * 64), dtype=np.float32), dtype)
+    dqkv = outbuf((B * Ls, 3 * H * 64), dtype)
+    assert L.clite_attention_bwd(dtype, ptr(qb), ptr(mask), ptr(dob), ptr(dqkv), B, Ls, H, 0.0, 0, 0, None) == 0
+    dO = do.reshape(B, Ls, H, 64).transpose(0, 2, 1, 3)
+    dv = p.transpose(0, 1, 3, 2) @ dO
+    dp = dO @ v.transpose(0, 1, 3, 2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True))
+    dq = ds @ k / 8.0
+    dk = ds.transpose(0, 1, 3, 2) @ q / 8.0
+    ref = np.stack([dq, dk, dv], 2).transpose(0, 3, 2, 1, 4).reshape(B * Ls, 3 * H * 64)   # [B,H,3,L,64] -> [B,L,3,H,64]
+    _close(val(dqkv, dtype), ref, 2 * _tol(dtype))
+    # dropout on: output is a valid convex-ish combination; mean keep fraction sanity via forward of constant v
+    ones, ob = prep(np.concatenate([qkv.reshape(B * Ls, 3, H * 64)[:, :2], np.ones((B * Ls, 1, H * 64), np.float32)], 1).reshape(B * Ls, -1), dtype)
+    ctxd = outbuf((B * Ls, H * 64), dtype)
+    assert L.clite_attention_fwd(dtype, ptr(ob), ptr(mask), ptr(ctxd), B, Ls, H, 0.5, 99, 3, None) == 0
+    assert abs(val(ctxd, dtype).mean() - 1.0) < 0.15   # E[dropout(p) @ 1] = 1
