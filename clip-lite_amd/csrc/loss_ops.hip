@@ -1,0 +1,225 @@
+// JSD mutual-information loss of CLIP-Lite (reference loss.py): the dot-product critic of
+// GlobalDiscriminatorDot.forward (loss.py:84-107: L2-normalise both projections, row-wise dot, * exp(temperature)),
+// the softplus Jensen-Shannon estimator with roll-by-one negatives (loss.py:206-222,254), the last layer + log terms
+// of PriorDiscriminator (loss.py:43-53,188-200) and the total (loss.py:302-305). Reductions are wavefront shuffles;
+// one wave owns one sample.
+#include "vec.h"
+#include "rng.h"
+#include "clite.h"
+
+using namespace clite;
+
+namespace {
+
+DEV float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch F.softplus (beta 1, threshold 20)
+DEV float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+constexpr int CR_MAXCH = 4;   // D <= 2048
+
+template <typename T>
+DEV void load_row(const T* p, int nchunk, int lane, float (&v)[CR_MAXCH][8]) {
+#pragma unroll
+  for (int i = 0; i < CR_MAXCH; ++i) {
+    int c = lane + 64 * i;
+    if (c < nchunk) load8(p + c * 8, v[i]); else zero8(v[i]);
+  }
+}
+DEV float dot_rows(const float (&a)[CR_MAXCH][8], const float (&b)[CR_MAXCH][8]) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CR_MAXCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += a[i][e] * b[i][e];
+  return wave_sum(s);
+}
+
+// work[n] = { |a_n|, |b_n|, |b_{n+1}|, cos+, cos-, o+, o-, 0 } ; acc[0] += softplus(-o+)/B ; acc[1] += softplus(o-)/B
+template <typename T>
+__global__ __launch_bounds__(256) void critic_fwd_kernel(const T* f1, const T* f2, const float* temperature, int B, int D, float* work, float* acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D / 8;
+  const float tscale = expf(temperature[0]);
+  for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
+    int n1 = n + 1 == B ? 0 : n + 1;
+    float a[CR_MAXCH][8], b[CR_MAXCH][8], c[CR_MAXCH][8];
+    load_row(f1 + (size_t)n * D, nchunk, lane, a);
+    load_row(f2 + (size_t)n * D, nchunk, lane, b);
+    load_row(f2 + (size_t)n1 * D, nchunk, lane, c);
+    float na = fmaxf(sqrtf(dot_rows(a, a)), 1e-12f);
+    float nb = fmaxf(sqrtf(dot_rows(b, b)), 1e-12f);
+    float nc = fmaxf(sqrtf(dot_rows(c, c)), 1e-12f);
+    float cp = dot_rows(a, b) / (na * nb);
+    float cn = dot_rows(a, c) / (na * nc);
+    float op = cp * tscale, on = cn * tscale;
+    if (lane == 0) {
+      float* w = work + (size_t)n * 8;
+      w[0] = na; w[1] = nb; w[2] = nc; w[3] = cp; w[4] = cn; w[5] = op; w[6] = on; w[7] = 0.f;
+      atomic_add_f32(acc + 0, softplus_f(-op) / (float)B);
+      atomic_add_f32(acc + 1, softplus_f(on) / (float)B);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void critic_bwd_kernel(const T* f1, const T* f2, const float* temperature, const float* work, const float* gout, float scale,
+                                                         int B, int D, T* df1, T* df2, float* dtemp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D / 8;
+  const float tscale = expf(temperature[0]);
+  const float g = gout[0] * scale / (float)B;
+  for (int m = blockIdx.x * 4 + wave; m < B; m += gridDim.x * 4) {
+    int m1 = m + 1 == B ? 0 : m + 1, mp = m == 0 ? B - 1 : m - 1;
+    const float* w = work + (size_t)m * 8;
+    const float* wp = work + (size_t)mp * 8;
+    float na = w[0], nb = w[1], nc = w[2], cp = w[3], cn = w[4];
+    float gp = -sigmoid_f(-w[5]) * g, gn = sigmoid_f(w[6]) * g;          // d/do+ , d/do- for sample m
+    float gnp = sigmoid_f(wp[6]) * g, cnp = wp[4], nap = wp[0];           // negative pair (m-1, m)
+    float a[CR_MAXCH][8], b[CR_MAXCH][8], c[CR_MAXCH][8], ap[CR_MAXCH][8];
+    load_row(f1 + (size_t)m * D, nchunk, lane, a);
+    load_row(f2 + (size_t)m * D, nchunk, lane, b);
+    load_row(f2 + (size_t)m1 * D, nchunk, lane, c);
+    load_row(f1 + (size_t)mp * D, nchunk, lane, ap);
+#pragma unroll
+    for (int i = 0; i < CR_MAXCH; ++i) {
+      int ch = lane + 64 * i;
+      if (ch < nchunk) {
+        float o1[8], o2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float ah = a[i][e] / na, bh = b[i][e] / nb, chh = c[i][e] / nc, aph = ap[i][e] / nap;
+          o1[e] = tscale / na * (gp * (bh - cp * ah) + gn * (chh - cn * ah));
+          o2[e] = tscale / nb * (gp * (ah - cp * bh) + gnp * (aph - cnp * bh));
+        }
+        store8(df1 + (size_t)m * D + ch * 8, o1);
+        store8(df2 + (size_t)m * D + ch * 8, o2);
+      }
+    }
+    if (lane == 0 && dtemp) atomic_add_f32(dtemp, gp * w[5] + gn * w[6]);
+  }
+}
+
+// PriorDiscriminator tail on stacked rows [noise u (B rows); features f (B rows)]: logit = h1 . w2 + b2, D = sigmoid(logit)
+// acc += -( mean log D(u) + mean log(1 - D(f)) )
+template <typename T>
+__global__ __launch_bounds__(256) void prior_tail_fwd_kernel(const T* h1, const float* w2, const float* b2, int B, int K, float* logit, float* acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = K / 8;
+  for (int r = blockIdx.x * 4 + wave; r < 2 * B; r += gridDim.x * 4) {
+    float s = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+      float h[8], w[8];
+      load8(h1 + (size_t)r * K + c * 8, h);
+      load8(w2 + c * 8, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += h[e] * w[e];
+    }
+    s = wave_sum(s) + b2[0];
+    if (lane == 0) {
+      logit[r] = s;
+      float d = sigmoid_f(s);
+      float term = r < B ? logf(d) : logf(1.f - d);
+      atomic_add_f32(acc, -term / (float)B);
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void prior_tail_bwd_kernel(const T* h1, const float* w2, const float* logit, const float* gout, float scale, int B, int K,
+                                                             T* dh1, float* dw2, float* db2) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = K / 8;
+  const float g = gout[0] * scale / (float)B;
+  for (int r = blockIdx.x * 4 + wave; r < 2 * B; r += gridDim.x * 4) {
+    float d = sigmoid_f(logit[r]);
+    float gl = r < B ? -(1.f - d) * g : d * g;       // d(-log D) = -(1-D), d(-log(1-D)) = D
+    for (int c = lane; c < nchunk; c += 64) {
+      float h[8], w[8], o[8];
+      load8(h1 + (size_t)r * K + c * 8, h);
+      load8(w2 + c * 8, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = h[e] > 0.f ? gl * w[e] : 0.f;          // through the ReLU that produced h1
+        if (dw2) atomic_add_f32(dw2 + c * 8 + e, gl * h[e]);
+      }
+      store8(dh1 + (size_t)r * K + c * 8, o);
+    }
+    if (lane == 0 && db2) atomic_add_f32(db2, gl);
+  }
+}
+
+// out[0] = total = (1-w)*cross + w*prior, out[1] = cross, out[2] = prior, out[3] = 0  (acc: [-Ej, Em, img prior, text prior])
+__global__ void loss_finalize_kernel(const float* acc, float prior_weight, float* out) {
+  if (threadIdx.x == 0) {
+    float cross = acc[0] + acc[1], prior = acc[2] + acc[3];
+    out[0] = (1.f - prior_weight) * cross + prior_weight * prior;
+    out[1] = cross; out[2] = prior; out[3] = 0.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void uniform_fill_kernel(T* out, size_t n, uint64_t seed, uint32_t site) {
+  size_t nch = n / 8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nch; i += (size_t)gridDim.x * 256) {
+    float u[8];
+    dropout_uniform8(seed, site, i * 8, u);
+    store8(out + i * 8, u);
+  }
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, CALL_BF16, CALL_F32) \
+  if ((dtype) == CLITE_BF16) { CALL_BF16; } else if ((dtype) == CLITE_F32) { CALL_F32; } else return -1;
+
+extern "C" int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, const float* temperature, int B, int D, float* work, float* acc, void* stream) {
+  if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !f1 || !f2 || !work || !acc) return -1;
+  int grid = (B + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(critic_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, B, D, work, acc),
+           hipLaunchKernelGGL(critic_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, B, D, work, acc));
+  return (int)hipGetLastError();
+}
+extern "C" int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, const float* temperature, const float* work, const float* gout, float scale,
+                                    int B, int D, void* df1, void* df2, float* dtemp, void* stream) {
+  if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !f1 || !f2 || !work || !gout || !df1 || !df2) return -1;
+  int grid = (B + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(critic_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, work, gout, scale, B, D, (bf16*)df1, (bf16*)df2, dtemp),
+           hipLaunchKernelGGL(critic_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, work, gout, scale, B, D, (float*)df1, (float*)df2, dtemp));
+  return (int)hipGetLastError();
+}
+extern "C" int clite_prior_tail_fwd(int dtype, const void* h1, const float* w2, const float* b2, int B, int K, float* logit, float* acc, void* stream) {
+  if (B <= 0 || K % 8 || !h1 || !w2 || !b2 || !logit || !acc) return -1;
+  int grid = (2 * B + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(prior_tail_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)h1, w2, b2, B, K, logit, acc),
+           hipLaunchKernelGGL(prior_tail_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)h1, w2, b2, B, K, logit, acc));
+  return (int)hipGetLastError();
+}
+extern "C" int clite_prior_tail_bwd(int dtype, const void* h1, const float* w2, const float* logit, const float* gout, float scale, int B, int K,
+                                    void* dh1, float* dw2, float* db2, void* stream) {
+  if (B <= 0 || K % 8 || !h1 || !w2 || !logit || !gout || !dh1) return -1;
+  int grid = (2 * B + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(prior_tail_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)h1, w2, logit, gout, scale, B, K, (bf16*)dh1, dw2, db2),
+           hipLaunchKernelGGL(prior_tail_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)h1, w2, logit, gout, scale, B, K, (float*)dh1, dw2, db2));
+  return (int)hipGetLastError();
+}
+extern "C" int clite_loss_finalize(const float* acc, float prior_weight, float* out, void* stream) {
+  if (!acc || !out) return -1;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, prior_weight, out);
+  return (int)hipGetLastError();
+}
+extern "C" int clite_uniform_fill(int dtype, void* out, uint64_t n, uint64_t seed, uint32_t site, void* stream) {
+  if (!out || n % 8) return -1;
+  size_t g = (n / 8 + 255) / 256;
+  int grid = (int)(g < 2048 ? (g ? g : 1) : 2048);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(uniform_fill_kernel<bf16>, dim3(grid), dim3(256), 0, st, (bf16*)out, (size_t)n, seed, site),
+           hipLaunchKernelGGL(uniform_fill_kernel<float>, dim3(grid), dim3(256), 0, st, (float*)out, (size_t)n, seed, site));
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,106 @@
+// Parameter-update path of the train step (reference train.py:221-226): global-norm gradient clipping
+// (torch.nn.utils.clip_grad_norm_), torch.optim.SGD with momentum + weight decay and one (lr, wd) pair per
+// parameter tensor (factories.py:464-482), the Lookahead slow/fast interpolation every k-th step
+// (optim/lookahead.py:88-101), and the bf16 weight copy the next forward reads — one pass over flat buffers.
+// Pure HBM streaming: per element 4 f32 reads (p, g, v, slow on sync steps) and up to 4 writes.
+#include "vec.h"
+#include "clite.h"
+
+using namespace clite;
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, size_t n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 v = *(const f32x4*)(x + i * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t i = n4 * 4; i < n; ++i) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_add_f32(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+// hp: [0] lr multiplier (schedule), [1] momentum, [2] max grad norm (<= 0: no clipping), [3] lookahead sync flag,
+//     [4] lookahead alpha, [5] gradient pre-scale (1/world_size after a SUM all-reduce, 1/loss_scale, ...)
+template <typename T, bool CAST>
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* p, float* g, float* v, float* slow, T* cast, const clite_optim_item* items,
+                                                       const float* hp, const float* sumsq) {
+  const clite_optim_item it = items[blockIdx.x];
+  const float lr = it.lr * hp[0], wd = it.wd, mu = hp[1], max_norm = hp[2], alpha = hp[4], gs = hp[5];
+  const bool sync = hp[3] != 0.f;
+  float clip = 1.f;
+  if (max_norm > 0.f) {
+    float total = sqrtf(sumsq[0]) * gs;
+    clip = fminf(max_norm / (total + 1e-6f), 1.f);
+  }
+  const float gmul = gs * clip;
+  for (uint32_t i = threadIdx.x * 4; i < it.count; i += 1024) {
+    size_t o = (size_t)it.start + i;
+    f32x4 pv = *(const f32x4*)(p + o), gv = *(const f32x4*)(g + o), vv = *(const f32x4*)(v + o);
+    f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+    if (sync) sv = *(const f32x4*)(slow + o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ge = gv[e] * gmul + wd * pv[e];
+      vv[e] = mu * vv[e] + ge;
+      pv[e] = pv[e] - lr * vv[e];
+      if (sync) { pv[e] = alpha * pv[e] + (1.f - alpha) * sv[e]; sv[e] = pv[e]; }
+    }
+    *(f32x4*)(p + o) = pv;
+    *(f32x4*)(v + o) = vv;
+    *(f32x4*)(g + o) = f32x4{0.f, 0.f, 0.f, 0.f};      // zero_grad for the next step
+    if (sync) *(f32x4*)(slow + o) = sv;
+    if (CAST) {
+      union { bf16 e[4]; u32x2 u; } pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk.e[e] = f2bf(pv[e]);
+      *(u32x2*)((bf16*)cast + o) = pk.u;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16* dst, size_t n) {
+  size_t n8 = n / 8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    load8(src + i * 8, v);
+    store8(dst + i * 8, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (size_t i = n8 * 8; i < n; ++i) dst[i] = f2bf(src[i]);
+}
+
+}  // namespace
+
+extern "C" int clite_sumsq(const float* x, uint64_t n, float* out, void* stream) {
+  if (!x || !out) return -1;
+  size_t g = (n / 4 + 255) / 256;
+  int grid = (int)(g < 2048 ? (g ? g : 1) : 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_sgd_step(float* p, float* g, float* v, float* slow, void* cast_bf16, const clite_optim_item* items, int n_items,
+                              const float* hp, const float* sumsq, void* stream) {
+  if (!p || !g || !v || !slow || !items || n_items <= 0 || !hp || !sumsq) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (cast_bf16)
+    hipLaunchKernelGGL((sgd_step_kernel<bf16, true>), dim3(n_items), dim3(256), 0, st, p, g, v, slow, (bf16*)cast_bf16, items, hp, sumsq);
+  else
+    hipLaunchKernelGGL((sgd_step_kernel<bf16, false>), dim3(n_items), dim3(256), 0, st, p, g, v, slow, (bf16*)nullptr, items, hp, sumsq);
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_cast_bf16(const float* src, void* dst, uint64_t n, void* stream) {
+  if (!src || !dst) return -1;
+  size_t g = (n / 8 + 255) / 256;
+  int grid = (int)(g < 4096 ? (g ? g : 1) : 4096);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (size_t)n);
+  return (int)hipGetLastError();
+}

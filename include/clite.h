@@ -148,6 +148,42 @@ int clite_attention_fwd(int dtype, const void* qkv, const int64_t* mask, void* c
 int clite_attention_bwd(int dtype, const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int H,
                         float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream);
 
+/* ---- JSD mutual-information loss (reference loss.py). f1 = img_block(image_features), f2 = text_block(text_features),
+ * both [B][D], D % 8 == 0, D <= 2048. Negatives are roll-by-one inside the batch: pair (n, n+1 mod B) (loss.py:214-216).
+ * work: f32 [B][8] per-sample scratch kept for backward. acc: f32 [4] accumulators, pre-zeroed:
+ *   acc[0] += mean softplus(-o+) (= -Ej), acc[1] += mean softplus(o-) (= Em), acc[2]/acc[3]: image/text prior terms. */
+int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, const float* temperature, int B, int D, float* work, float* acc, void* stream);
+/* gout: device scalar dL/d(total); scale = (1 - prior_weight). df1/df2 in dtype; dtemp (f32 scalar) += . */
+int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, const float* temperature, const float* work, const float* gout, float scale,
+                         int B, int D, void* df1, void* df2, float* dtemp, void* stream);
+/* PriorDiscriminator.l2 + sigmoid + log terms (loss.py:49-53,189-193) on h1 = relu(l1(relu(l0([u; f])))) stacked [2B][K]:
+ * acc += -(mean log D(u) + mean log(1 - D(f))). K % 8 == 0. logit: f32 [2B] kept for backward. */
+int clite_prior_tail_fwd(int dtype, const void* h1, const float* w2, const float* b2, int B, int K, float* logit, float* acc, void* stream);
+/* dh1 = gradient w.r.t. l1's pre-activation (ReLU mask applied); dw2/db2 (f32) += ; scale = prior_weight. */
+int clite_prior_tail_bwd(int dtype, const void* h1, const float* w2, const float* logit, const float* gout, float scale, int B, int K,
+                         void* dh1, float* dw2, float* db2, void* stream);
+/* out[0] = (1-w)*cross + w*prior (loss.py:302-305), out[1] = cross = Em - Ej, out[2] = prior, out[3] = 0 */
+int clite_loss_finalize(const float* acc, float prior_weight, float* out, void* stream);
+/* torch.rand_like replacement for the prior noise (loss.py:189,196): U[0,1) from Philox(seed, site, index). n % 8 == 0. */
+int clite_uniform_fill(int dtype, void* out, uint64_t n, uint64_t seed, uint32_t site, void* stream);
+
+/* ---- Update path (reference train.py:221-226, factories.py:464-482, optim/lookahead.py:88-101) over flat f32 buffers. */
+typedef struct clite_optim_item {   /* one workgroup's slice of one parameter tensor (never straddles tensors) */
+  uint64_t start;                   /* element offset into the flat buffers, multiple of 4 */
+  uint32_t count;                   /* elements, multiple of 4 */
+  float lr;                         /* base learning rate of the owning tensor's param group */
+  float wd;                         /* weight decay of the owning tensor's param group */
+  uint32_t reserved;
+} clite_optim_item;
+/* out (f32 scalar, pre-zeroed) += sum x^2 — the global gradient norm of clip_grad_norm_ */
+int clite_sumsq(const float* x, uint64_t n, float* out, void* stream);
+/* hp (device f32[6]): lr multiplier, momentum, max grad norm (<=0 off), lookahead-sync flag, lookahead alpha, grad pre-scale.
+ * g' = g*prescale*clip + wd*p; v = mu*v + g'; p -= lr*mult*v; on sync steps p = alpha*p + (1-alpha)*slow, slow = p.
+ * g is zeroed; cast_bf16 (optional) receives the bf16 copy of p at the same offsets. */
+int clite_sgd_step(float* p, float* g, float* v, float* slow, void* cast_bf16, const clite_optim_item* items, int n_items,
+                   const float* hp, const float* sumsq, void* stream);
+int clite_cast_bf16(const float* src, void* dst, uint64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

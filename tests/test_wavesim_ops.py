@@ -214,3 +214,119 @@ def test_attention_fwd_bwd(dtype, Ls):
     ctxd = outbuf((B * Ls, H * 64), dtype)
     assert L.clite_attention_fwd(dtype, ptr(ob), ptr(mask), ptr(ctxd), B, Ls, H, 0.5, 99, 3, None) == 0
     assert abs(val(ctxd, dtype).mean() - 1.0) < 0.15   # E[dropout(p) @ 1] = 1
+
+
+def _softplus(x):
+    return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_critic_jsd_fwd_bwd(dtype):
+    """Against a numpy restatement of GlobalDiscriminatorDot + the JSD estimator (reference loss.py:84-107,206-222,254)
+    with central finite differences for the gradient."""
+    rng = np.random.default_rng(11)
+    B, D = 6, 128
+    f1, f1b = prep(rng.standard_normal((B, D), dtype=np.float32), dtype)
+    f2, f2b = prep(rng.standard_normal((B, D), dtype=np.float32), dtype)
+    temp = np.array([np.log(1 / 0.07)], np.float32)
+
+    def loss(a, b, t):
+        a = a.astype(np.float64); b = b.astype(np.float64)
+        an = a / np.linalg.norm(a, axis=1, keepdims=True); bn = b / np.linalg.norm(b, axis=1, keepdims=True)
+        op = (an * bn).sum(1) * np.exp(t); on = (an * np.roll(bn, -1, 0)).sum(1) * np.exp(t)
+        return _softplus(-op).mean(), _softplus(on).mean()
+
+    L = lib()
+    L.clite_critic_jsd_bwd.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4
+    work = np.zeros((B, 8), np.float32); acc = np.zeros(4, np.float32)
+    assert L.clite_critic_jsd_fwd(dtype, ptr(f1b), ptr(f2b), ptr(temp), B, D, ptr(work), ptr(acc), None) == 0
+    l0, l1 = loss(f1, f2, float(temp[0]))
+    assert abs(acc[0] - l0) < 1e-5 and abs(acc[1] - l1) < 1e-5
+    gout = np.array([1.7], np.float32)
+    df1 = outbuf((B, D), dtype); df2 = outbuf((B, D), dtype); dt = np.zeros(1, np.float32)
+    assert L.clite_critic_jsd_bwd(dtype, ptr(f1b), ptr(f2b), ptr(temp), ptr(work), ptr(gout), 0.9, B, D, ptr(df1), ptr(df2), ptr(dt), None) == 0
+    tot = lambda a, b, t: 1.7 * 0.9 * sum(loss(a, b, t))
+    eps = 1e-3
+    for (i, j) in [(0, 0), (2, 5), (5, 127), (3, 64)]:
+        for which, got in ((0, val(df1, dtype)), (1, val(df2, dtype))):
+            ap, am = f1.astype(np.float64).copy(), f1.astype(np.float64).copy()
+            bp, bm = f2.astype(np.float64).copy(), f2.astype(np.float64).copy()
+            (ap if which == 0 else bp)[i, j] += eps
+            (am if which == 0 else bm)[i, j] -= eps
+            fd = (tot(ap, bp, float(temp[0])) - tot(am, bm, float(temp[0]))) / (2 * eps)
+            assert abs(got[i, j] - fd) < (2e-2 if dtype == BF16 else 1e-4) * max(1.0, abs(fd)), (which, i, j, got[i, j], fd)
+    fdt = (tot(f1, f2, float(temp[0]) + eps) - tot(f1, f2, float(temp[0]) - eps)) / (2 * eps)
+    assert abs(dt[0] - fdt) < 1e-3 * max(1.0, abs(fdt))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_prior_tail_and_finalize(dtype):
+    rng = np.random.default_rng(13)
+    B, K = 5, 200
+    h1, hb = prep(np.maximum(rng.standard_normal((2 * B, K), dtype=np.float32), 0), dtype)
+    w2 = (rng.standard_normal(K) * 0.1).astype(np.float32); b2 = np.array([0.05], np.float32)
+    logit = np.zeros(2 * B, np.float32); acc = np.zeros(4, np.float32)
+    L = lib()
+    L.clite_prior_tail_bwd.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4
+    L.clite_loss_finalize.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    assert L.clite_prior_tail_fwd(dtype, ptr(hb), ptr(w2), ptr(b2), B, K, ptr(logit), ptr(acc[2:]), None) == 0
+    z = h1 @ w2 + b2[0]
+    d = 1 / (1 + np.exp(-z))
+    ref = -(np.log(d[:B]).mean() + np.log(1 - d[B:]).mean())
+    assert abs(acc[2] - ref) < 1e-5
+    gout = np.array([2.0], np.float32)
+    dh = outbuf((2 * B, K), dtype); dw = np.zeros(K, np.float32); db = np.zeros(1, np.float32)
+    assert L.clite_prior_tail_bwd(dtype, ptr(hb), ptr(w2), ptr(logit), ptr(gout), 0.1, B, K, ptr(dh), ptr(dw), ptr(db), None) == 0
+    gl = np.concatenate([-(1 - d[:B]), d[B:]]) * 2.0 * 0.1 / B
+    _close(val(dh, dtype), gl[:, None] * w2[None, :] * (h1 > 0), _tol(dtype))
+    _close(dw, (gl[:, None] * h1).sum(0), 1e-4)
+    assert abs(db[0] - gl.sum()) < 1e-6
+    acc[:] = [0.3, 0.4, 1.0, 2.0]
+    out = np.zeros(4, np.float32)
+    assert L.clite_loss_finalize(ptr(acc), 0.1, ptr(out), None) == 0
+    assert np.allclose(out, [0.9 * 0.7 + 0.1 * 3.0, 0.7, 3.0, 0.0], atol=1e-6)
+
+
+def test_uniform_and_optimizer():
+    L = lib()
+    L.clite_uniform_fill.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p]
+    u = np.zeros(4096, np.float32)
+    assert L.clite_uniform_fill(F32, ptr(u), 4096, 42, 1, None) == 0
+    assert 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.03 and abs(u.var() - 1 / 12) < 0.01
+    u2 = np.zeros(4096, np.float32)
+    L.clite_uniform_fill(F32, ptr(u2), 4096, 42, 1, None)
+    assert np.array_equal(u, u2)
+
+    class Item(C.Structure):
+        _fields_ = [("start", C.c_uint64), ("count", C.c_uint32), ("lr", C.c_float), ("wd", C.c_float), ("reserved", C.c_uint32)]
+
+    rng = np.random.default_rng(17)
+    n = 2048 + 512
+    p = rng.standard_normal(n).astype(np.float32); g = rng.standard_normal(n).astype(np.float32)
+    v = rng.standard_normal(n).astype(np.float32); slow = rng.standard_normal(n).astype(np.float32)
+    p0, g0, v0, s0 = p.copy(), g.copy(), v.copy(), slow.copy()
+    items = (Item * 3)(Item(0, 1024, 0.2, 1e-4, 0), Item(1024, 1024, 0.2, 1e-4, 0), Item(2048, 512, 1e-3, 0.0, 0))
+    L.clite_sumsq.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    ss = np.zeros(1, np.float32)
+    assert L.clite_sumsq(ptr(g), n, ptr(ss), None) == 0
+    assert abs(ss[0] - (g0.astype(np.float64) ** 2).sum()) < 1e-2
+    cast = np.zeros(n, np.uint16)
+    for sync in (0.0, 1.0):
+        p[:] = p0; g[:] = g0; v[:] = v0; slow[:] = s0
+        hp = np.array([0.5, 0.9, 10.0, sync, 0.5, 0.25], np.float32)
+        assert L.clite_sgd_step(ptr(p), ptr(g), ptr(v), ptr(slow), ptr(cast), items, 3, ptr(hp), ptr(ss), None) == 0
+        total = np.sqrt(ss[0]) * 0.25
+        clip = min(10.0 / (total + 1e-6), 1.0)
+        lr = np.concatenate([np.full(2048, 0.2), np.full(512, 1e-3)]).astype(np.float32) * 0.5
+        wd = np.concatenate([np.full(2048, 1e-4), np.zeros(512)]).astype(np.float32)
+        ge = g0 * 0.25 * clip + wd * p0
+        vr = 0.9 * v0 + ge
+        pr = p0 - lr * vr
+        sr = s0.copy()
+        if sync:
+            pr = 0.5 * pr + 0.5 * s0
+            sr = pr
+        assert np.allclose(p, pr, atol=1e-6) and np.allclose(v, vr, atol=1e-6) and np.allclose(slow, sr, atol=1e-6)
+        assert not g.any()
+        from simlib import from_bf16, to_bf16
+        assert np.array_equal(cast, to_bf16(p))
