@@ -1,0 +1,197 @@
+"""Headline benchmark: image-caption pairs/sec of the full CLIP-Lite pretraining step (BASELINE.json configs[1]/[2]):
+ResNet-50 + BERT-base (12 layers), JSD-MI loss with both priors, per-GPU batch 128, bf16 storage + bf16 MFMA, synthetic
+224x224 images and 30-token captions, dropout and prior noise ON; step = zero_grad, forward, backward, gradient mean over
+ranks, global-norm clip, SGD(momentum, wd, per-tensor lr) + Lookahead, LR schedule (reference train.py:211-226).
+
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 run under `python -m torch.distributed.run --nproc-per-node N`.
+Rank 0 prints ONE JSON line. Weak scaling: per-GPU batch fixed at 128, `value` = N * 128 * K / time (max over ranks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as tdist  # noqa: E402
+
+FLOP_PER_PAIR = 40.19e9            # 6.699 GMAC fwd x 2 x 3 (fwd + dgrad + wgrad), ResNet-50 + BERT-base L=30 + heads
+MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def build(args, device):
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    from clip_lite_amd.optim import FusedSGD, Lookahead
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    torch.manual_seed(1234)
+    ie = ImageEncoder(args.visual)
+    te = TextEncoder(mode="train_sbert", num_hidden_layers=args.layers)
+    loss = JSDInfoMaxLoss(ie.img_encoder.out_dim, 768, "dot", 0.1, True, True)
+    model = VLInfoModel(te, ie, loss, "train_sbert", is_amp=not args.f32).to(device).train()
+    groups = []
+    for name, p in model.named_parameters():      # reference factories.py:464-482
+        lr = 0.2 if "image_encoder" in name else 1e-3
+        groups.append({"params": [p], "lr": lr, "weight_decay": 1e-4})
+    opt = Lookahead(FusedSGD(groups, momentum=0.9), k=5, alpha=0.5)
+    sched = LinearWarmupCosineAnnealingLR(opt, total_steps=250000, warmup_steps=10000)
+    return model, opt, sched
+
+
+def synthetic_batches(args, device, rank, n=2):
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    out = []
+    for _ in range(n):
+        img = torch.randn(args.batch, 3, 224, 224, device=device, generator=g)
+        ids = torch.randint(1000, 30522, (args.batch, 30), device=device, generator=g)
+        ids[:, 0], ids[:, -1] = 101, 102
+        out.append({"image": img, "input_ids": ids, "attention_mask": torch.ones(args.batch, 30, dtype=torch.long, device=device)})
+    return out
+
+
+def cpu_baseline(args):
+    """The oracle's fp32 CPU train step (the restatement of the reference's own step) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import ref_model as O
+    torch.manual_seed(1234)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    B = 8
+    M = O.build_oracle_model(args.visual, "train_sbert", args.layers).train()
+    opt = O.build_optimizer(M.named_parameters())
+    batch = {"image": torch.randn(B, 3, 224, 224), "input_ids": torch.randint(1000, 30522, (B, 30)), "attention_mask": torch.ones(B, 30, dtype=torch.long)}
+    O.train_step(M, opt, batch, 0)
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < 10 and n < 10):
+        O.train_step(M, opt, batch, n + 1)
+        n += 1
+    dt = time.time() - t0
+    return {"value": B * n / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n} fp32 train steps of the same model at batch {B} (oracle/ref_model.py, torch CPU)"}
+
+
+def kernel_roofline(step_fn, batches, steps=3):
+    """Average duration of the dominant kernel family (the implicit-GEMM engine: every conv / linear forward, dgrad and wgrad launch),
+    measured with events recorded on the stream the kernels are launched on, against its algorithmic FLOPs."""
+    from clip_lite_amd import hip
+    names = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_wgrad", "clite_stem_fwd", "clite_stem_wgrad")
+    lib = hip.lib()
+    events, originals = [], {}
+
+    def wrap(name):
+        fn = getattr(lib, name)
+        originals[name] = fn
+
+        def timed(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            events.append((e0, e1))
+            return rc
+        return timed
+
+    class Proxy:
+        def __getattr__(self, k):
+            return wrapped.get(k) or getattr(lib, k)
+    wrapped = {n: wrap(n) for n in names}
+    hip._lib = Proxy()
+    try:
+        for i in range(steps):
+            step_fn(batches[i % len(batches)])
+        torch.cuda.synchronize()
+    finally:
+        hip._lib = lib
+    total_ms = sum(e0.elapsed_time(e1) for e0, e1 in events)
+    return total_ms / steps, len(events) // steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--visual", default="resnet50")
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--f32", action="store_true", help="exact-f32 parity kernels instead of bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        tdist.init_process_group(backend="nccl", init_method="env://")
+
+    from clip_lite_amd.train_loop import TrainStep
+    from clip_lite_amd.utils import distributed as cdist
+    from clip_lite_amd.utils.common import GradScaler
+    model, opt, sched = build(args, device)
+    cdist.broadcast_parameters(model)
+    exchange = None
+    if world > 1:
+        exchange = cdist.GradientExchange(model.runtime.arena)
+        model.runtime.exchange = exchange
+    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange)
+    batches = synthetic_batches(args, device, rank)
+
+    for i in range(args.warmup):
+        step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(batches[i % len(batches)])
+    torch.cuda.synchronize()
+    if world > 1:
+        tdist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = t.item()
+    loss = out["loss"].item()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * args.steps / dt
+        gemm_ms, n_launch = kernel_roofline(step, batches)
+        gemm_tflops = FLOP_PER_PAIR * args.batch / (gemm_ms * 1e-3) / 1e12 if args.visual == "resnet50" and args.layers == 12 else None
+        res = {
+            "metric": "image-caption pairs/sec (global batch) — ResNet-50+BERT bs1024, 1/2/4/8 MI355X",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.f32 else "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.visual} + BERT-base({args.layers}L) + JSD-MI heads/priors, per-GPU batch {args.batch}, 224x224 images, "
+                                   f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+            "loss": loss,
+            "roofline": {"bound": "mfma", "kernel": "clite::igemm_kernel (all conv/linear fwd+dgrad+wgrad launches of one step)",
+                         "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": None,
+                         "launches_per_step": n_launch, "kernel_ms_per_step": gemm_ms,
+                         "whole_step_frac": FLOP_PER_PAIR * args.batch / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if gemm_tflops else None},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(res))
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

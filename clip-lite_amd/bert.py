@@ -1,0 +1,244 @@
+"""BERT text encoder on the HIP kernels: module tree with transformers.BertModel's parameter names (what reference
+encoder.py:165-170 builds with BertConfig(num_hidden_layers=n)) and the hand-scheduled forward/backward executor.
+
+Per layer: one fused QKV GEMM ([3*768] outputs; q/k/v weights are adjacent in the parameter arena), per-head attention
+kernel (L <= 32), output projection with bias + dropout + residual in the GEMM epilogue, LayerNorm, FFN with the GELU
+(and its saved pre-activation) in the epilogue, second LayerNorm. Dropout masks are regenerated from (seed, site, index).
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+
+
+class LinearParams(nn.Module):
+    def __init__(self, cin, cout, bias=True, std=None):
+        super().__init__()
+        self.in_features, self.out_features = cin, cout
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        if std is None:                      # nn.Linear default init (reference loss.py heads)
+            nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+            if bias:
+                bound = 1 / cin ** 0.5
+                nn.init.uniform_(self.bias, -bound, bound)
+        else:                                # BertPreTrainedModel._init_weights
+            self.weight.data.normal_(0.0, std)
+
+
+class LayerNormParams(nn.Module):
+    def __init__(self, c, eps):
+        super().__init__()
+        self.normalized_shape, self.eps = (c,), eps
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class EmbeddingParams(nn.Module):
+    def __init__(self, n, c, std=0.02, padding_idx=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(n, c).normal_(0.0, std))
+        if padding_idx is not None:
+            self.weight.data[padding_idx].zero_()
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.query, self.key, self.value = LinearParams(h, h, std=0.02), LinearParams(h, h, std=0.02), LinearParams(h, h, std=0.02)
+
+
+class _SelfOutput(nn.Module):
+    def __init__(self, cin, h, eps):
+        super().__init__()
+        self.dense = LinearParams(cin, h, std=0.02)
+        self.LayerNorm = LayerNormParams(h, eps)
+
+
+class _Attention(nn.Module):
+    def __init__(self, h, eps):
+        super().__init__()
+        self.self = _SelfAttention(h)
+        self.output = _SelfOutput(h, h, eps)
+
+
+class _Intermediate(nn.Module):
+    def __init__(self, h, inner):
+        super().__init__()
+        self.dense = LinearParams(h, inner, std=0.02)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, h, inner, eps):
+        super().__init__()
+        self.attention = _Attention(h, eps)
+        self.intermediate = _Intermediate(h, inner)
+        self.output = _SelfOutput(inner, h, eps)
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, vocab, h, max_pos, eps):
+        super().__init__()
+        self.word_embeddings = EmbeddingParams(vocab, h, padding_idx=0)
+        self.position_embeddings = EmbeddingParams(max_pos, h)
+        self.token_type_embeddings = EmbeddingParams(2, h)
+        self.LayerNorm = LayerNormParams(h, eps)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n, h, inner, eps):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(h, inner, eps) for _ in range(n)])
+
+
+class _Pooler(nn.Module):
+    def __init__(self, h):
+        super().__init__()
+        self.dense = LinearParams(h, h, std=0.02)
+
+
+class BertModel(nn.Module):
+    """BertConfig defaults (transformers): hidden 768, 12 heads, intermediate 3072, vocab 30522, 512 positions, GELU(erf),
+    LayerNorm eps 1e-12, hidden/attention dropout 0.1."""
+
+    def __init__(self, num_hidden_layers=12, hidden=768, heads=12, inner=3072, vocab=30522, max_pos=512, dropout=0.1, eps=1e-12):
+        super().__init__()
+        assert hidden == heads * 64, "the attention kernel is built for head size 64"
+        self.hidden, self.heads, self.inner, self.vocab, self.max_pos = hidden, heads, inner, vocab, max_pos
+        self.hidden_dropout_prob = self.attention_probs_dropout_prob = dropout
+        self.embeddings = _Embeddings(vocab, hidden, max_pos, eps)
+        self.encoder = _Encoder(num_hidden_layers, hidden, inner, eps)
+        self.pooler = _Pooler(hidden)
+
+    def contiguous_groups(self, prefix):
+        """q/k/v weights (and biases) must be adjacent in the arena so one GEMM computes all three projections."""
+        groups = []
+        for i in range(len(self.encoder.layer)):
+            base = f"{prefix}encoder.layer.{i}.attention.self."
+            groups.append([base + "query.weight", base + "key.weight", base + "value.weight"])
+            groups.append([base + "query.bias", base + "key.bias", base + "value.bias"])
+        return groups
+
+
+# ---------------------------------------------------------------------------------------------------- executor
+def _alloc(rt, *shape):
+    return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
+
+
+def _linear_grads(rt, lin, dy, x, M, dw=None, db=None):
+    """dW[N][K] += dy^T x ; db += colsum(dy) for a LinearParams (or explicit arena views for fused q/k/v)."""
+    N, K = dy.shape[1], x.shape[1]
+    if dw is None:
+        dw = rt.arena.g(lin.weight) if lin.weight.requires_grad else None
+        db = rt.arena.g(lin.bias) if (lin.bias is not None and lin.bias.requires_grad) else None
+    if dw is not None:
+        hip.gemm_tn(rt.dt, dy, x, N, K, M, hip.epilogue(dw, K, atomic=True, out_f32=True))
+    if db is not None:
+        hip.colsum(rt.dt, dy, db, M, N)
+
+
+def bert_forward(rt, net, input_ids, attention_mask, step):
+    """input_ids/attention_mask: int64 [B][L] on the device, L <= 32. Returns (pooler_output [B][H], ctx)."""
+    B, L = input_ids.shape
+    if L > 32:
+        raise RuntimeError("clip_lite_amd: the attention kernel supports captions of at most 32 tokens (reference config.py:69: 30)")
+    dt, A = rt.dt, rt.arena
+    Hd, heads, inner = net.hidden, net.heads, net.inner
+    M = B * L
+    training = step.training
+    p_h = net.hidden_dropout_prob if training else 0.0
+    p_a = net.attention_probs_dropout_prob if training else 0.0
+    drop = lambda p: (p, step.seed, step.site()) if p > 0 else hip.NO_DROP
+    ids = input_ids.contiguous()
+    mask = attention_mask.contiguous().to(torch.int64)
+    emb = net.embeddings
+    s0 = _alloc(rt, M, Hd)
+    hip.embed_fwd(dt, ids, A.w(emb.word_embeddings.weight), A.w(emb.position_embeddings.weight), A.w(emb.token_type_embeddings.weight),
+                  s0, M, L, Hd, net.vocab)
+    h = _alloc(rt, M, Hd)
+    st0 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
+    d0 = drop(p_h)
+    hip.layernorm_fwd(dt, s0, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, h, st0, M, Hd, d0)
+    ctx = {"B": B, "L": L, "ids": ids, "mask": mask, "s0": s0, "st0": st0, "d0": d0, "layers": []}
+    for layer in net.encoder.layer:
+        sa, so = layer.attention.self, layer.attention.output
+        wqkv = A.span([sa.query.weight, sa.key.weight, sa.value.weight])
+        bqkv = A.span([sa.query.bias, sa.key.bias, sa.value.bias], lowp=False)
+        qkv = _alloc(rt, M, 3 * Hd)
+        hip.gemm_nt(dt, h, wqkv, M, 3 * Hd, Hd, hip.epilogue(qkv, 3 * Hd, bias=bqkv))
+        ctxt = _alloc(rt, M, Hd)
+        da = drop(p_a)
+        hip.attention_fwd(dt, qkv, mask, ctxt, B, L, heads, da)
+        s1 = _alloc(rt, M, Hd)
+        d1 = drop(p_h)
+        hip.gemm_nt(dt, ctxt, A.w(so.dense.weight), M, Hd, Hd, hip.epilogue(s1, Hd, bias=so.dense.bias, drop=d1, residual=h))
+        h1 = _alloc(rt, M, Hd)
+        st1 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
+        hip.layernorm_fwd(dt, s1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, h1, st1, M, Hd)
+        f = _alloc(rt, M, inner)      # FFN pre-activation (kept for GELU')
+        g = _alloc(rt, M, inner)
+        hip.gemm_nt(dt, h1, A.w(layer.intermediate.dense.weight), M, inner, Hd,
+                    hip.epilogue(g, inner, bias=layer.intermediate.dense.bias, act=hip.ACT_GELU, preact=f))
+        s2 = _alloc(rt, M, Hd)
+        d2 = drop(p_h)
+        hip.gemm_nt(dt, g, A.w(layer.output.dense.weight), M, Hd, inner, hip.epilogue(s2, Hd, bias=layer.output.dense.bias, drop=d2, residual=h1))
+        h2 = _alloc(rt, M, Hd)
+        st2 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
+        hip.layernorm_fwd(dt, s2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, h2, st2, M, Hd)
+        ctx["layers"].append((layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2))
+        h = h2
+    pooled = _alloc(rt, B, Hd)
+    hip.gemm_nt(dt, h, A.w(net.pooler.dense.weight), B, Hd, Hd, hip.epilogue(pooled, Hd, bias=net.pooler.dense.bias, act=hip.ACT_TANH), lda=L * Hd)
+    ctx["h_last"], ctx["pooled"] = h, pooled
+    return pooled, ctx
+
+
+def bert_backward(rt, net, ctx, dpooled):
+    dt, A = rt.dt, rt.arena
+    B, L = ctx["B"], ctx["L"]
+    Hd, heads, inner = net.hidden, net.heads, net.inner
+    M = B * L
+    # pooler: dpre = dpooled * (1 - y^2); h[:, 0] rows only
+    dpre = _alloc(rt, B, Hd)
+    hip.tanh_bwd(dt, dpooled, ctx["pooled"], dpre, B * Hd)
+    pw = net.pooler.dense
+    if pw.weight.requires_grad:
+        hip.gemm_tn(dt, dpre, ctx["h_last"], Hd, Hd, B, hip.epilogue(A.g(pw.weight), Hd, atomic=True, out_f32=True), ldb=L * Hd)
+        hip.colsum(dt, dpre, A.g(pw.bias), B, Hd)
+    dh = torch.zeros(M, Hd, device=rt.device, dtype=rt.tdtype)
+    hip.gemm_nn(dt, dpre, A.w(pw.weight), B, Hd, Hd, hip.epilogue(dh, L * Hd))
+    for (layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2) in reversed(ctx["layers"]):
+        sa, so, out = layer.attention.self, layer.attention.output, layer.output
+        # LayerNorm 2 -> (dropout) -> FFN
+        ds2 = _alloc(rt, M, Hd)
+        ds2m = _alloc(rt, M, Hd) if d2[0] > 0 else None
+        hip.layernorm_bwd(dt, dh, s2, st2, out.LayerNorm.weight, ds2, ds2m, A.g(out.LayerNorm.weight), A.g(out.LayerNorm.bias), M, Hd, drop_out=d2)
+        dz2 = ds2m if ds2m is not None else ds2
+        _linear_grads(rt, out.dense, dz2, g, M)
+        df = _alloc(rt, M, inner)
+        hip.gemm_nn(dt, dz2, A.w(out.dense.weight), M, inner, Hd, hip.epilogue(df, inner, dact_aux=f, dact=hip.DACT_GELU))
+        _linear_grads(rt, layer.intermediate.dense, df, h1, M)
+        dh1 = _alloc(rt, M, Hd)
+        hip.gemm_nn(dt, df, A.w(layer.intermediate.dense.weight), M, Hd, inner, hip.epilogue(dh1, Hd, residual=ds2))
+        # LayerNorm 1 -> (dropout) -> attention output projection
+        ds1 = _alloc(rt, M, Hd)
+        ds1m = _alloc(rt, M, Hd) if d1[0] > 0 else None
+        hip.layernorm_bwd(dt, dh1, s1, st1, so.LayerNorm.weight, ds1, ds1m, A.g(so.LayerNorm.weight), A.g(so.LayerNorm.bias), M, Hd, drop_out=d1)
+        dz1 = ds1m if ds1m is not None else ds1
+        _linear_grads(rt, so.dense, dz1, ctxt, M)
+        dctx = _alloc(rt, M, Hd)
+        hip.gemm_nn(dt, dz1, A.w(so.dense.weight), M, Hd, Hd, hip.epilogue(dctx, Hd))
+        dqkv = _alloc(rt, M, 3 * Hd)
+        hip.attention_bwd(dt, qkv, ctx["mask"], dctx, dqkv, B, L, heads, da)
+        wqkv = A.span([sa.query.weight, sa.key.weight, sa.value.weight])
+        _linear_grads(rt, None, dqkv, h, M, dw=A.span([sa.query.weight, sa.key.weight, sa.value.weight], grad=True).view(3 * Hd, Hd),
+                      db=A.span([sa.query.bias, sa.key.bias, sa.value.bias], grad=True))
+        dhp = _alloc(rt, M, Hd)
+        hip.gemm_nn(dt, dqkv, wqkv, M, Hd, 3 * Hd, hip.epilogue(dhp, Hd, residual=ds1))
+        dh = dhp
+    emb = net.embeddings
+    ds0 = _alloc(rt, M, Hd)
+    hip.layernorm_bwd(dt, dh, ctx["s0"], ctx["st0"], emb.LayerNorm.weight, ds0, None, A.g(emb.LayerNorm.weight), A.g(emb.LayerNorm.bias), M, Hd,
+                      drop_in=ctx["d0"])
+    hip.embed_bwd(dt, ctx["ids"], ds0, A.g(emb.word_embeddings.weight), A.g(emb.position_embeddings.weight), M, L, Hd, net.vocab)
+    hip.colsum(dt, ds0, A.g(emb.token_type_embeddings.weight)[0], M, Hd)

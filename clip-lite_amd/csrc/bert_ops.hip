@@ -331,6 +331,19 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(const T* qkv, const i
   }
 }
 
+// BertPooler backward through tanh: out = dy * (1 - y^2)
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* dy, const T* y, T* out, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float d[8], v[8];
+    load8(dy + i * 8, d);
+    load8(y + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d[e] *= 1.f - v[e] * v[e];
+    store8(out + i * 8, d);
+  }
+}
+
 int ew_grid(size_t total) {
   size_t g = (total + 255) / 256;
   return (int)(g < 4096 ? (g ? g : 1) : 4096);
@@ -416,5 +429,15 @@ extern "C" int clite_attention_bwd(int dtype, const void* qkv, const int64_t* ma
   DISPATCH(dtype,
            hipLaunchKernelGGL(attention_bwd_kernel<bf16>, dim3(B * H), dim3(64), 0, st, (const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, H, d),
            hipLaunchKernelGGL(attention_bwd_kernel<float>, dim3(B * H), dim3(64), 0, st, (const float*)qkv, mask, (const float*)dctx, (float*)dqkv, B, L, H, d));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_tanh_bwd(int dtype, const void* dy, const void* y, void* out, uint64_t n, void* stream) {
+  if (!dy || !y || !out || n % 8) return -1;
+  int grid = ew_grid(n / 8);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(tanh_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (bf16*)out, (size_t)(n / 8)),
+           hipLaunchKernelGGL(tanh_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)y, (float*)out, (size_t)(n / 8)));
   return (int)hipGetLastError();
 }

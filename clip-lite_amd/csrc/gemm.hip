@@ -16,10 +16,10 @@ FastDiv fastdiv_make(uint32_t d) {
   return f;
 }
 
-ConvGeom geom_dense(int rows, int K) {  // [rows][K] row-major seen as a 1x1 window over a rows x 1 x 1 image
+ConvGeom geom_dense(int rows, int K, int ld = 0) {  // [rows][K] (row stride ld) seen as a 1x1 window over a rows x 1 x 1 image
   ConvGeom g;
   g.H = 1; g.W = 1; g.C = K;
-  g.sN = K; g.sH = 0; g.sW = 0;
+  g.sN = ld ? ld : K; g.sH = 0; g.sW = 0;
   g.RH = 1; g.RW = 1; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0;
   g.rows = rows;
   g.div_hw = fastdiv_make(1);
@@ -62,43 +62,45 @@ int check_ep(const clite_epilogue* ep, int N) {
   return 0;
 }
 
+uint32_t span_bytes(int rows, int cols, int ld, size_t es) { return (uint32_t)(((size_t)(rows - 1) * ld + cols) * es); }
+
 template <typename T>
-int gemm_nt(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
+int gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
   constexpr int BK = Cfg<T>::BK;
-  uint32_t ab = (uint32_t)((size_t)M * K * sizeof(T)), bb = (uint32_t)((size_t)N * K * sizeof(T));
+  uint32_t ab = span_bytes(M, K, lda, sizeof(T)), bb = span_bytes(N, K, ldb, sizeof(T));
   int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
   if (N <= 64) {
-    GatherKC<T, 256, BK, false> la{A, ab, geom_dense(M, K)};
-    GatherKC<T, 64, BK, false> lb{B, bb, geom_dense(N, K)};
+    GatherKC<T, 256, BK, false> la{A, ab, geom_dense(M, K, lda)};
+    GatherKC<T, 64, BK, false> lb{B, bb, geom_dense(N, K, ldb)};
     return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, N, K, splits, st);
   }
-  GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K)};
-  GatherKC<T, 128, BK, false> lb{B, bb, geom_dense(N, K)};
+  GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K, lda)};
+  GatherKC<T, 128, BK, false> lb{B, bb, geom_dense(N, K, ldb)};
   return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, N, K, splits, st);
 }
 
 template <typename T>
-int gemm_nn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
+int gemm_nn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
   constexpr int BK = Cfg<T>::BK;
-  uint32_t ab = (uint32_t)((size_t)M * K * sizeof(T)), bb = (uint32_t)((size_t)N * K * sizeof(T));
+  uint32_t ab = span_bytes(M, K, lda, sizeof(T)), bb = span_bytes(K, N, ldb, sizeof(T));
   int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
   if (N <= 64) {
-    GatherKC<T, 256, BK, false> la{A, ab, geom_dense(M, K)};
-    StridedXC<T, 64, BK> lb{B, bb, N, N, K, 1};
+    GatherKC<T, 256, BK, false> la{A, ab, geom_dense(M, K, lda)};
+    StridedXC<T, 64, BK> lb{B, bb, ldb, N, K, 1};
     return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, N, K, splits, st);
   }
-  GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K)};
-  StridedXC<T, 128, BK> lb{B, bb, N, N, K, 1};
+  GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K, lda)};
+  StridedXC<T, 128, BK> lb{B, bb, ldb, N, K, 1};
   return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, N, K, splits, st);
 }
 
 template <typename T>
-int gemm_tn(const void* A, const void* B, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
+int gemm_tn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
   constexpr int BK = Cfg<T>::BK;
-  uint32_t ab = (uint32_t)((size_t)M * K * sizeof(T)), bb = (uint32_t)((size_t)N * K * sizeof(T));
+  uint32_t ab = span_bytes(K, M, lda, sizeof(T)), bb = span_bytes(K, N, ldb, sizeof(T));
   int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
-  StridedXC<T, 128, BK> la{A, ab, M, M, K, 1};
-  StridedXC<T, 128, BK> lb{B, bb, N, N, K, 1};
+  StridedXC<T, 128, BK> la{A, ab, lda, M, K, 1};
+  StridedXC<T, 128, BK> lb{B, bb, ldb, N, K, 1};
   return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, N, K, splits, st);
 }
 
@@ -229,10 +231,10 @@ __global__ __launch_bounds__(256) void stem_unpack_kernel(const float* dwv, floa
   dw[i] += dwv[((k * 7 + r) * 8 + s) * 4 + c];
 }
 
-int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K) {
+int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K, int lda, int ldb, int rows_a, int rows_b) {
   if (dtype != CLITE_BF16 && dtype != CLITE_F32) return -1;
-  if (M <= 0 || N <= 0 || K <= 0) return -1;
-  if (!fits32((size_t)M * K, 4) || !fits32((size_t)N * K, 4)) return -1;
+  if (M <= 0 || N <= 0 || K <= 0 || lda % 8 || ldb % 8) return -1;
+  if (!fits32((size_t)rows_a * lda, 4) || !fits32((size_t)rows_b * ldb, 4)) return -1;
   return check_ep(ep, N);
 }
 
@@ -240,17 +242,17 @@ int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K) {
 
 extern "C" int clite_abi_version(void) { return CLITE_ABI_VERSION; }
 
-extern "C" int clite_gemm_nt(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
-  if (check_gemm(ep, dtype, M, N, K) || K % 8) return -1;
-  return dtype == CLITE_BF16 ? gemm_nt<bf16>(A, B, M, N, K, ep, (hipStream_t)stream) : gemm_nt<float>(A, B, M, N, K, ep, (hipStream_t)stream);
+extern "C" int clite_gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
+  if (check_gemm(ep, dtype, M, N, K, lda, ldb, M, N) || K % 8 || lda < K || ldb < K) return -1;
+  return dtype == CLITE_BF16 ? gemm_nt<bf16>(A, lda, B, ldb, M, N, K, ep, (hipStream_t)stream) : gemm_nt<float>(A, lda, B, ldb, M, N, K, ep, (hipStream_t)stream);
 }
-extern "C" int clite_gemm_nn(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
-  if (check_gemm(ep, dtype, M, N, K) || K % 8) return -1;
-  return dtype == CLITE_BF16 ? gemm_nn<bf16>(A, B, M, N, K, ep, (hipStream_t)stream) : gemm_nn<float>(A, B, M, N, K, ep, (hipStream_t)stream);
+extern "C" int clite_gemm_nn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
+  if (check_gemm(ep, dtype, M, N, K, lda, ldb, M, K) || K % 8 || lda < K || ldb < N) return -1;
+  return dtype == CLITE_BF16 ? gemm_nn<bf16>(A, lda, B, ldb, M, N, K, ep, (hipStream_t)stream) : gemm_nn<float>(A, lda, B, ldb, M, N, K, ep, (hipStream_t)stream);
 }
-extern "C" int clite_gemm_tn(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
-  if (check_gemm(ep, dtype, M, N, K) || M % 8 || N % 8) return -1;
-  return dtype == CLITE_BF16 ? gemm_tn<bf16>(A, B, M, N, K, ep, (hipStream_t)stream) : gemm_tn<float>(A, B, M, N, K, ep, (hipStream_t)stream);
+extern "C" int clite_gemm_tn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
+  if (check_gemm(ep, dtype, M, N, K, lda, ldb, K, K) || M % 8 || N % 8 || lda < M || ldb < N) return -1;
+  return dtype == CLITE_BF16 ? gemm_tn<bf16>(A, lda, B, ldb, M, N, K, ep, (hipStream_t)stream) : gemm_tn<float>(A, lda, B, ldb, M, N, K, ep, (hipStream_t)stream);
 }
 extern "C" int clite_conv_fwd(const void* x, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
   if (check_conv(cv) || check_ep(ep, cv->K)) return -1;

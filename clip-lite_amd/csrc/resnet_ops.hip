@@ -14,13 +14,15 @@ struct BnCoef { float a[8], b[8]; };
 
 // scale/shift of 8 channels from batch statistics (training) or running statistics (eval)
 DEV void bn_coef(const float* stats, const float* gamma, const float* beta, const float* rmean, const float* rvar,
-                 int training, float inv_count, float eps, int C, int c0, BnCoef& k, float (&mean)[8], float (&var)[8]) {
+                 int training, int centered, float inv_count, float eps, int C, int c0, BnCoef& k, float (&mean)[8], float (&var)[8]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     int c = c0 + e;
     if (training) {
       mean[e] = stats[c] * inv_count;
-      var[e] = fmaxf(stats[C + c] * inv_count - mean[e] * mean[e], 0.f);
+      // single-pass E[x^2]-E[x]^2 (sums from the conv epilogue), or the two-pass sum of squared deviations when a
+      // centered pass (clite_bn_centered_var) filled stats[2][C]
+      var[e] = centered ? stats[2 * C + c] * inv_count : fmaxf(stats[C + c] * inv_count - mean[e] * mean[e], 0.f);
     } else {
       mean[e] = rmean[c];
       var[e] = rvar[c];
@@ -39,10 +41,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, c
   const float inv_count = 1.0f / (float)p.M;
   BnCoef k, kr;
   float mean[8], var[8], mr[8], vr[8];
-  bn_coef(p.stats, p.gamma, p.beta, p.running_mean, p.running_var, p.training, inv_count, p.eps, p.C, c0, k, mean, var);
+  bn_coef(p.stats, p.gamma, p.beta, p.running_mean, p.running_var, p.training, p.centered, inv_count, p.eps, p.C, c0, k, mean, var);
   const bool res_affine = res && p.res_gamma;
   if (res_affine)
-    bn_coef(p.res_stats, p.res_gamma, p.res_beta, p.res_running_mean, p.res_running_var, p.training, inv_count, p.eps, p.C, c0, kr, mr, vr);
+    bn_coef(p.res_stats, p.res_gamma, p.res_beta, p.res_running_mean, p.res_running_var, p.training, p.centered, inv_count, p.eps, p.C, c0, kr, mr, vr);
   if (blockIdx.x == 0 && r0 == 0 && p.training && p.update_running) {
     float unb = p.M > 1 ? (float)p.M / (float)(p.M - 1) : 1.f;
 #pragma unroll
@@ -118,6 +120,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const
   }
 }
 
+// second pass of a two-pass variance: stats[2][c] += sum (y - mean_c)^2 with mean_c = stats[0][c] / M
+template <typename T>
+__global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* y, float* stats, int M, int C, int rows_per_block) {
+  __shared__ float red[256 * 8];
+  const int CPR = C / 8, RPS = 256 / CPR;
+  const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
+  float mean[8], s[8];
+  const float inv_count = 1.0f / (float)M;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { mean[e] = stats[c0 + e] * inv_count; s[e] = 0.f; }
+  int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
+  if (row_end > M) row_end = M;
+  for (int r = row_begin + r0; r < row_end; r += RPS) {
+    float v[8];
+    load8(y + (size_t)r * C + c0, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { float d = v[e] - mean[e]; s[e] += d * d; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = s[e];
+  __syncthreads();
+  if (r0 == 0) {
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      for (int r = 0; r < RPS; ++r) t += red[(r * CPR + cc) * 8 + e];
+      atomic_add_f32(stats + 2 * C + c0 + e, t);
+    }
+  }
+}
+
 // dy = gamma*rstd*(dz - S1/M - xhat*G/M), G = sum dz*xhat = rstd*(S2 - mean*S1); dgamma += G, dbeta += S1
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* dout, const T* mask, const T* y, const float* dstats,
@@ -130,7 +162,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
   for (int e = 0; e < 8; ++e) {
     int c = c0 + e;
     mean[e] = p.stats[c] * inv_count;
-    float var = fmaxf(p.stats[p.C + c] * inv_count - mean[e] * mean[e], 0.f);
+    float var = p.centered ? p.stats[2 * p.C + c] * inv_count : fmaxf(p.stats[p.C + c] * inv_count - mean[e] * mean[e], 0.f);
     rstd[e] = rsqrtf(var + p.eps);
     float S1 = dstats[c], S2 = dstats[p.C + c];
     float G = rstd[e] * (S2 - mean[e] * S1);
@@ -344,6 +376,17 @@ extern "C" int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const
   DISPATCH(dtype,
            hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb),
            hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *p, (const float*)y, (const float*)res, (float*)out, rpb));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_bn_centered_var(int dtype, const void* y, float* stats, int M, int C, void* stream) {
+  if (!bn_ok(M, C) || !y || !stats) return -1;
+  int rpb;
+  int grid = bn_grid(M, C, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(bn_centered_var_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, stats, M, C, rpb),
+           hipLaunchKernelGGL(bn_centered_var_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, stats, M, C, rpb));
   return (int)hipGetLastError();
 }
 

@@ -12,7 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libclite_hip.so")
 ABI_VERSION = 1
 
+BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
+DACT_RELU, DACT_GELU, DACT_TANH = 1, 2, 3
+
+TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
 
 
 class Epilogue(C.Structure):
@@ -28,7 +32,71 @@ class Conv(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dtype", "N", "H", "W", "C", "K", "R", "S", "stride", "pad", "Ho", "Wo")]
 
 
+class Bn(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("C", C.c_int32), ("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("training", C.c_int32),
+        ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32), ("centered", C.c_int32),
+        ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
+        ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p),
+    ]
+
+
+class OptimItem(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("count", C.c_uint32), ("lr", C.c_float), ("wd", C.c_float), ("reserved", C.c_uint32)]
+
+
+_V, _I, _F, _U64, _U32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
+_SIGNATURES = {
+    "clite_abi_version": [],
+    "clite_gemm_nt": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
+    "clite_gemm_nn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
+    "clite_gemm_tn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
+    "clite_conv_fwd": [_V, _V, _V, _V, _V],
+    "clite_conv_dgrad": [_V, _V, _V, _V, _V],
+    "clite_conv_wgrad": [_V, _V, _V, _V, _V],
+    "clite_stem_fwd": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
+    "clite_stem_wgrad": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
+    "clite_stem_pack": [_V, _V, _I, _V],
+    "clite_stem_unpack_grad": [_V, _V, _V],
+    "clite_bn_apply": [_V, _I, _V, _V, _V, _V],
+    "clite_bn_centered_var": [_I, _V, _V, _I, _I, _V],
+    "clite_bn_bwd_reduce": [_I, _V, _V, _V, _V, _I, _I, _V],
+    "clite_bn_bwd_apply": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V],
+    "clite_maxpool3x3s2_fwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
+    "clite_maxpool3x3s2_bwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
+    "clite_avgpool_fwd": [_I, _V, _V, _I, _I, _I, _V],
+    "clite_avgpool_bwd": [_I, _V, _V, _I, _I, _I, _V],
+    "clite_image_to_nhwc4": [_I, _V, _V, _I, _I, _I, _I, _I, _I, _V],
+    "clite_colsum": [_I, _V, _V, _I, _I, _V],
+    "clite_layernorm_fwd": [_I, _V, _V, _V, _F, _V, _V, _I, _I, _F, _U64, _U32, _V],
+    "clite_layernorm_bwd": [_I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _F, _U64, _U32, _F, _U64, _U32, _V],
+    "clite_embed_fwd": [_I, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V],
+    "clite_embed_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _I, _V],
+    "clite_attention_fwd": [_I, _V, _V, _V, _I, _I, _I, _F, _U64, _U32, _V],
+    "clite_attention_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _F, _U64, _U32, _V],
+    "clite_tanh_bwd": [_I, _V, _V, _V, _U64, _V],
+    "clite_critic_jsd_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V],
+    "clite_critic_jsd_bwd": [_I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V],
+    "clite_prior_tail_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V],
+    "clite_prior_tail_bwd": [_I, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V],
+    "clite_loss_finalize": [_V, _F, _V, _V],
+    "clite_uniform_fill": [_I, _V, _U64, _U64, _U32, _V],
+    "clite_sumsq": [_V, _U64, _V, _V],
+    "clite_sgd_step": [_V, _V, _V, _V, _V, _V, _I, _V, _V, _V],
+    "clite_cast_bf16": [_V, _V, _U64, _V],
+}
+
 _lib = None
+_allow_host_tensors = False   # set only by tests that inject the wave-simulator build of the same sources
+
+
+def _bind(l):
+    for name, args in _SIGNATURES.items():
+        fn = getattr(l, name)        # AttributeError here = the library does not export what include/clite.h declares
+        fn.argtypes = args
+        fn.restype = C.c_int
+    return l
 
 
 def lib():
@@ -39,21 +107,30 @@ def lib():
             raise RuntimeError(
                 f"clip_lite_amd: {LIB_PATH} not found. Build it with `make hip` (or __graft_entry__.build()); "
                 "this package has no fallback path.")
-        l = C.CDLL(LIB_PATH)
-        l.clite_abi_version.restype = C.c_int
+        l = _bind(C.CDLL(LIB_PATH))
         if l.clite_abi_version() != ABI_VERSION:
             raise RuntimeError("clip_lite_amd: libclite_hip.so ABI version mismatch; rebuild with `make hip`")
         _lib = l
     return _lib
 
 
-def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def stream_ptr(t=None):
+    if t is not None and not t.is_cuda:
+        return None
+    return torch.cuda.current_stream().cuda_stream
 
 
 def p(t):
-    """Device pointer of a tensor (None -> NULL). The tensor must be contiguous in the layout the kernel expects."""
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda and not _allow_host_tensors:
+        raise RuntimeError("clip_lite_amd: kernels need CUDA/HIP device tensors; this package has no CPU path")
+    return t.data_ptr()
 
 
 def check(rc, what):
@@ -61,19 +138,194 @@ def check(rc, what):
         raise RuntimeError(f"clip_lite_amd: {what} failed with code {rc}")
 
 
-def epilogue(out, ldc, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
-             drop_p=0.0, drop_seed=0, drop_site=0, residual=None, colsum=None):
+def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
+             drop=None, residual=None, colsum=None, out_f32=None):
     ep = Epilogue()
-    ep.out = out.data_ptr(); ep.ldc = ldc
-    ep.out_f32 = int(out.dtype == torch.float32)
-    assert out.dtype in (torch.float32, torch.bfloat16)
-    ep.atomic = int(atomic); ep.alpha = alpha
-    ep.bias = None if bias is None else bias.data_ptr()
+    ep.out = p(out)
+    ep.ldc = ldc if ldc is not None else out.shape[-1]
+    ep.out_f32 = int(out.dtype == torch.float32) if out_f32 is None else int(out_f32)
+    ep.atomic = int(atomic)
+    ep.alpha = alpha
+    ep.bias = p(bias)
     ep.act = act
-    ep.preact = None if preact is None else preact.data_ptr()
-    ep.dact_aux = None if dact_aux is None else dact_aux.data_ptr()
+    ep.preact = p(preact)
+    ep.dact_aux = p(dact_aux)
     ep.dact = dact
-    ep.drop_p = drop_p; ep.drop_seed = drop_seed; ep.drop_site = drop_site
-    ep.residual = None if residual is None else residual.data_ptr()
-    ep.colsum = None if colsum is None else colsum.data_ptr()
+    if drop is not None and drop[0] > 0.0:
+        ep.drop_p, ep.drop_seed, ep.drop_site = drop
+    ep.residual = p(residual)
+    ep.colsum = p(colsum)
     return ep
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / conv
+def gemm_nt(dt, A, B, M, N, K, ep, lda=None, ldb=None):
+    check(lib().clite_gemm_nt(p(A), lda or K, p(B), ldb or K, M, N, K, dt, C.byref(ep), stream_ptr(A)), "gemm_nt")
+
+
+def gemm_nn(dt, A, B, M, N, K, ep, lda=None, ldb=None):
+    check(lib().clite_gemm_nn(p(A), lda or K, p(B), ldb or N, M, N, K, dt, C.byref(ep), stream_ptr(A)), "gemm_nn")
+
+
+def gemm_tn(dt, A, B, M, N, K, ep, lda=None, ldb=None):
+    check(lib().clite_gemm_tn(p(A), lda or M, p(B), ldb or N, M, N, K, dt, C.byref(ep), stream_ptr(A)), "gemm_tn")
+
+
+def conv_desc(dt, N, H, W, Cin, K, R, S, stride, pad):
+    Ho = (H + 2 * pad - R) // stride + 1
+    Wo = (W + 2 * pad - S) // stride + 1
+    return Conv(dt, N, H, W, Cin, K, R, S, stride, pad, Ho, Wo)
+
+
+def conv_fwd(x, w, cv, ep):
+    check(lib().clite_conv_fwd(p(x), p(w), C.byref(cv), C.byref(ep), stream_ptr(x)), "conv_fwd")
+
+
+def conv_dgrad(dy, w, cv, ep):
+    check(lib().clite_conv_dgrad(p(dy), p(w), C.byref(cv), C.byref(ep), stream_ptr(dy)), "conv_dgrad")
+
+
+def conv_wgrad(dy, x, cv, dw):
+    check(lib().clite_conv_wgrad(p(dy), p(x), C.byref(cv), p(dw), stream_ptr(dy)), "conv_wgrad")
+
+
+def stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, ep):
+    check(lib().clite_stem_fwd(p(xpad), p(wv), dt, N, Hp, Wp, Ho, Wo, C.byref(ep), stream_ptr(xpad)), "stem_fwd")
+
+
+def stem_wgrad(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dwv):
+    check(lib().clite_stem_wgrad(p(dy), p(xpad), dt, N, Hp, Wp, Ho, Wo, p(dwv), stream_ptr(dy)), "stem_wgrad")
+
+
+def stem_pack(dt, w, wv):
+    check(lib().clite_stem_pack(p(w), p(wv), dt, stream_ptr(w)), "stem_pack")
+
+
+def stem_unpack_grad(dwv, dw):
+    check(lib().clite_stem_unpack_grad(p(dwv), p(dw), stream_ptr(dwv)), "stem_unpack_grad")
+
+
+# ------------------------------------------------------------------------------------------------ BN / pools
+def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, eps, relu, res_bn=None, centered=False):
+    b = Bn()
+    b.M, b.C = M, Cc
+    b.centered = int(centered)
+    b.stats, b.gamma, b.beta, b.running_mean, b.running_var = p(stats), p(gamma), p(beta), p(rmean), p(rvar)
+    b.training, b.update_running, b.momentum, b.eps, b.relu = int(training), int(update), momentum, eps, int(relu)
+    if res_bn is not None:
+        rs, rg, rb, rrm, rrv = res_bn
+        b.res_stats, b.res_gamma, b.res_beta, b.res_running_mean, b.res_running_var = p(rs), p(rg), p(rb), p(rrm), p(rrv)
+    return b
+
+
+def bn_centered_var(dt, y, stats, M, Cc):
+    check(lib().clite_bn_centered_var(dt, p(y), p(stats), M, Cc, stream_ptr(y)), "bn_centered_var")
+
+
+def bn_apply(dt, bn, y, res, out):
+    check(lib().clite_bn_apply(C.byref(bn), dt, p(y), p(res), p(out), stream_ptr(y)), "bn_apply")
+
+
+def bn_bwd_reduce(dt, dout, mask, y, dstats, M, Cc):
+    check(lib().clite_bn_bwd_reduce(dt, p(dout), p(mask), p(y), p(dstats), M, Cc, stream_ptr(y)), "bn_bwd_reduce")
+
+
+def bn_bwd_apply(dt, bn, dout, mask, y, dstats, dy, dz, dgamma, dbeta):
+    check(lib().clite_bn_bwd_apply(C.byref(bn), dt, p(dout), p(mask), p(y), p(dstats), p(dy), p(dz), p(dgamma), p(dbeta), stream_ptr(y)),
+          "bn_bwd_apply")
+
+
+def maxpool_fwd(dt, x, out, idx, N, H, W, Cc):
+    check(lib().clite_maxpool3x3s2_fwd(dt, p(x), p(out), p(idx), N, H, W, Cc, stream_ptr(x)), "maxpool_fwd")
+
+
+def maxpool_bwd(dt, dout, idx, dx, N, H, W, Cc):
+    check(lib().clite_maxpool3x3s2_bwd(dt, p(dout), p(idx), p(dx), N, H, W, Cc, stream_ptr(dout)), "maxpool_bwd")
+
+
+def avgpool_fwd(dt, x, out, N, HW, Cc):
+    check(lib().clite_avgpool_fwd(dt, p(x), p(out), N, HW, Cc, stream_ptr(x)), "avgpool_fwd")
+
+
+def avgpool_bwd(dt, dout, dx, N, HW, Cc):
+    check(lib().clite_avgpool_bwd(dt, p(dout), p(dx), N, HW, Cc, stream_ptr(dout)), "avgpool_bwd")
+
+
+def image_to_nhwc4(dt, img, out, N, H, W, pad, Hp, Wp):
+    check(lib().clite_image_to_nhwc4(dt, p(img), p(out), N, H, W, pad, Hp, Wp, stream_ptr(img)), "image_to_nhwc4")
+
+
+def colsum(dt, x, out, M, N):
+    check(lib().clite_colsum(dt, p(x), p(out), M, N, stream_ptr(x)), "colsum")
+
+
+# ------------------------------------------------------------------------------------------------ BERT pieces
+NO_DROP = (0.0, 0, 0)
+
+
+def layernorm_fwd(dt, x, gamma, beta, eps, out, stats, M, Cc, drop=NO_DROP):
+    check(lib().clite_layernorm_fwd(dt, p(x), p(gamma), p(beta), eps, p(out), p(stats), M, Cc, drop[0], drop[1], drop[2], stream_ptr(x)),
+          "layernorm_fwd")
+
+
+def layernorm_bwd(dt, dy, x, stats, gamma, dx, dx_masked, dgamma, dbeta, M, Cc, drop_in=NO_DROP, drop_out=NO_DROP):
+    check(lib().clite_layernorm_bwd(dt, p(dy), p(x), p(stats), p(gamma), p(dx), p(dx_masked), p(dgamma), p(dbeta), M, Cc,
+                                    drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2], stream_ptr(x)), "layernorm_bwd")
+
+
+def embed_fwd(dt, ids, word, pos, typ, out, M, L, Cc, vocab):
+    check(lib().clite_embed_fwd(dt, p(ids), p(word), p(pos), p(typ), p(out), M, L, Cc, vocab, stream_ptr(out)), "embed_fwd")
+
+
+def embed_bwd(dt, ids, d, dword, dpos, M, L, Cc, vocab):
+    check(lib().clite_embed_bwd(dt, p(ids), p(d), p(dword), p(dpos), M, L, Cc, vocab, stream_ptr(d)), "embed_bwd")
+
+
+def attention_fwd(dt, qkv, mask, ctx, B, L, H, drop=NO_DROP):
+    check(lib().clite_attention_fwd(dt, p(qkv), p(mask), p(ctx), B, L, H, drop[0], drop[1], drop[2], stream_ptr(qkv)), "attention_fwd")
+
+
+def attention_bwd(dt, qkv, mask, dctx, dqkv, B, L, H, drop=NO_DROP):
+    check(lib().clite_attention_bwd(dt, p(qkv), p(mask), p(dctx), p(dqkv), B, L, H, drop[0], drop[1], drop[2], stream_ptr(qkv)), "attention_bwd")
+
+
+def tanh_bwd(dt, dy, y, out, n):
+    check(lib().clite_tanh_bwd(dt, p(dy), p(y), p(out), n, stream_ptr(dy)), "tanh_bwd")
+
+
+# ------------------------------------------------------------------------------------------------ loss / update
+def critic_jsd_fwd(dt, f1, f2, temperature, B, D, work, acc):
+    check(lib().clite_critic_jsd_fwd(dt, p(f1), p(f2), p(temperature), B, D, p(work), p(acc), stream_ptr(f1)), "critic_jsd_fwd")
+
+
+def critic_jsd_bwd(dt, f1, f2, temperature, work, gout, scale, B, D, df1, df2, dtemp):
+    check(lib().clite_critic_jsd_bwd(dt, p(f1), p(f2), p(temperature), p(work), p(gout), scale, B, D, p(df1), p(df2), p(dtemp), stream_ptr(f1)),
+          "critic_jsd_bwd")
+
+
+def prior_tail_fwd(dt, h1, w2, b2, B, K, logit, acc):
+    check(lib().clite_prior_tail_fwd(dt, p(h1), p(w2), p(b2), B, K, p(logit), p(acc), stream_ptr(h1)), "prior_tail_fwd")
+
+
+def prior_tail_bwd(dt, h1, w2, logit, gout, scale, B, K, dh1, dw2, db2):
+    check(lib().clite_prior_tail_bwd(dt, p(h1), p(w2), p(logit), p(gout), scale, B, K, p(dh1), p(dw2), p(db2), stream_ptr(h1)), "prior_tail_bwd")
+
+
+def loss_finalize(acc, prior_weight, out):
+    check(lib().clite_loss_finalize(p(acc), prior_weight, p(out), stream_ptr(acc)), "loss_finalize")
+
+
+def uniform_fill(dt, out, n, seed, site):
+    check(lib().clite_uniform_fill(dt, p(out), n, seed, site, stream_ptr(out)), "uniform_fill")
+
+
+def sumsq(x, n, out):
+    check(lib().clite_sumsq(p(x), n, p(out), stream_ptr(x)), "sumsq")
+
+
+def sgd_step(pf, gf, vf, slow, cast, items_ptr, n_items, hp, ss):
+    check(lib().clite_sgd_step(p(pf), p(gf), p(vf), p(slow), p(cast), items_ptr, n_items, p(hp), p(ss), stream_ptr(pf)), "sgd_step")
+
+
+def cast_bf16(src, dst, n):
+    check(lib().clite_cast_bf16(p(src), p(dst), n, stream_ptr(src)), "cast_bf16")

@@ -1,0 +1,250 @@
+"""JSD mutual-information loss on the HIP kernels — the call surface of reference loss.py (MILinearBlock :12-40,
+PriorDiscriminator :43-53, GlobalDiscriminatorDot :76-107, JSDInfoMaxLoss :110-314) with identical attribute names and
+state_dict keys (`global_d.{img_block,text_block,temperature}`, `prior_d`, `text_prior_d`; the eval CLIs reach into
+`loss.global_d.img_block` / `text_block`, reference retrieval.py:70-74).
+
+Scheduling notes: the reference runs both MI blocks twice per step (positive pairs, then negatives with
+the text batch rolled by one). BatchNorm batch statistics are permutation-invariant and the image input is identical in both
+calls, so the projections are computed ONCE and the critic kernel pairs sample n with n+1; to stay checkpoint-compatible the
+BatchNorm1d running statistics are still updated twice and num_batches_tracked advances by 2.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .bert import LayerNormParams, LinearParams
+from .resnet import BatchNormParams
+
+
+class MILinearBlock(nn.Module):
+    def __init__(self, feature_sz, units=2048, bln=True):
+        super().__init__()
+        self.feature_nonlinear = nn.Sequential(LinearParams(feature_sz, units, bias=False), BatchNormParams(units), nn.Identity(),
+                                               LinearParams(units, units))
+        self.feature_shortcut = LinearParams(feature_sz, units)
+        self.feature_block_ln = LayerNormParams(units, 1e-5)
+        # "initialize the initial projection to a sort of noisy copy" (reference loss.py:25-32)
+        eye = torch.zeros(units, feature_sz, dtype=torch.bool)
+        i = torch.arange(min(units, feature_sz))
+        eye[i, i] = True
+        self.feature_shortcut.weight.data.uniform_(-0.01, 0.01)
+        self.feature_shortcut.weight.data.masked_fill_(eye, 1.0)
+        self.bln = bln
+        self.feature_sz, self.units = feature_sz, units
+
+    def forward(self, feat):
+        """Stand-alone projection (used by the eval CLIs as `projector(encoder(x))`); no gradient."""
+        rt = _runtime_of(self)
+        x = feat.to(rt.tdtype).contiguous()
+        out, _ = mi_block_forward(rt, self, x, self.training, updates=1)
+        return out
+
+
+class PriorDiscriminator(nn.Module):
+    def __init__(self, sz):
+        super().__init__()
+        self.l0 = LinearParams(sz, 1000)
+        self.l1 = LinearParams(1000, 200)
+        self.l2 = LinearParams(200, 1)
+        self.sz = sz
+
+
+class GlobalDiscriminatorDot(nn.Module):
+    def __init__(self, image_sz, text_sz, units=2048, bln=True):
+        super().__init__()
+        self.img_block = MILinearBlock(image_sz, units=units, bln=bln)
+        self.text_block = MILinearBlock(text_sz, units=units, bln=bln)
+        self.temperature = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+
+
+class JSDInfoMaxLoss(nn.Module):
+    def __init__(self, image_dim=2048, text_dim=768, type="dot", prior_weight=0.1, image_prior=True, text_prior=False,
+                 visual_self_supervised=False, textual_self_supervised=False):
+        super().__init__()
+        if type != "dot":
+            raise NotImplementedError(f"critic type {type!r}: only the 'dot' critic (every shipped YAML) is built on the HIP path")
+        if visual_self_supervised or textual_self_supervised:
+            raise NotImplementedError("visual/textual self-supervised terms are outside the accelerated hot path")
+        self.prior_weight, self.image_prior, self.text_prior = prior_weight, image_prior, text_prior
+        self.image_dim, self.text_dim = image_dim, text_dim
+        self.global_d = GlobalDiscriminatorDot(image_sz=image_dim, text_sz=text_dim)
+        if image_prior:
+            self.prior_d = PriorDiscriminator(sz=image_dim)
+        if text_prior:
+            self.text_prior_d = PriorDiscriminator(sz=text_dim)
+        self._noise = None      # test hook: pins the two rand_like draws (image, text)
+
+    def set_prior_noise(self, image_noise, text_noise):
+        """Pin the prior noise (reference loss.py:189,196 draws torch.rand_like(image) then (text)); parity tests only."""
+        self._noise = (image_noise, text_noise)
+
+    def forward(self, image_features, text_features, neg_image_features=None, neg_text_features=None,
+                aug_image_features=None, aug_text_features=None):
+        if any(t is not None for t in (neg_image_features, neg_text_features, aug_image_features, aug_text_features)):
+            raise NotImplementedError("cluster negatives / augmented views are outside the accelerated hot path")
+        rt = _runtime_of(self)
+        total, comps = _JSDLossFn.apply(image_features, text_features, self, rt, rt.next_step(self.training))
+        zero = comps[3]
+        return {"total_loss": total, "cross_modal_loss": comps[1], "visual_loss": zero, "textual_loss": zero}
+
+
+def _runtime_of(module):
+    rt = getattr(module, "_clite_rt", None)
+    if rt is None:
+        raise RuntimeError("clip_lite_amd: module is not attached to a device runtime; build it through VLInfoModel and move it to "
+                           "the GPU with .to(device) (there is no CPU path)")
+    return rt
+
+
+# ---------------------------------------------------------------------------------------------------- executors
+def _alloc(rt, *shape):
+    return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
+
+
+def mi_block_forward(rt, blk, x, training, updates=2):
+    """x: [B][F] compute dtype. Returns (LN(W2 relu(bn(W1 x)) + b2 + Ws x + bs), ctx)."""
+    dt, A = rt.dt, rt.arena
+    B, Fin, U = x.shape[0], blk.feature_sz, blk.units
+    l1, bn, _, l2 = blk.feature_nonlinear
+    z = _alloc(rt, B, U)
+    stats = torch.zeros(3, U, device=rt.device, dtype=torch.float32) if training else None
+    hip.gemm_nt(dt, x, A.w(l1.weight), B, U, Fin, hip.epilogue(z, U, colsum=stats))
+    if training and rt.precise_bn:
+        hip.bn_centered_var(dt, z, stats, B, U)
+    a = _alloc(rt, B, U)
+    desc = hip.bn_desc(B, U, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, training, bn.momentum, bn.eps, True, centered=rt.precise_bn)
+    hip.bn_apply(dt, desc, z, None, a)
+    for _ in range(updates - 1 if training else 0):      # the reference's second pass updates the running stats again
+        desc2 = hip.bn_desc(B, U, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, True, bn.momentum, bn.eps, True, centered=rt.precise_bn)
+        hip.bn_apply(dt, desc2, z, None, a)
+    f = _alloc(rt, B, U)
+    hip.gemm_nt(dt, a, A.w(l2.weight), B, U, U, hip.epilogue(f, U, bias=l2.bias))
+    t = _alloc(rt, B, U)
+    hip.gemm_nt(dt, x, A.w(blk.feature_shortcut.weight), B, U, Fin, hip.epilogue(t, U, bias=blk.feature_shortcut.bias, residual=f))
+    if not blk.bln:
+        return t, (x, z, stats, a, t, None)
+    out = _alloc(rt, B, U)
+    lst = torch.empty(B, 2, device=rt.device, dtype=torch.float32)
+    ln = blk.feature_block_ln
+    hip.layernorm_fwd(dt, t, ln.weight, ln.bias, ln.eps, out, lst, B, U)
+    return out, (x, z, stats, a, t, lst)
+
+
+def mi_block_backward(rt, blk, ctx, dout, dx_residual=None):
+    """Returns dx [B][F] (+ dx_residual if given). Parameter gradients accumulate into the arena."""
+    from .bert import _linear_grads
+    dt, A = rt.dt, rt.arena
+    x, z, stats, a, t, lst = ctx
+    B, Fin, U = x.shape[0], blk.feature_sz, blk.units
+    l1, bn, _, l2 = blk.feature_nonlinear
+    ln = blk.feature_block_ln
+    if blk.bln:
+        dtt = _alloc(rt, B, U)
+        hip.layernorm_bwd(dt, dout, t, lst, ln.weight, dtt, None, A.g(ln.weight), A.g(ln.bias), B, U)
+    else:
+        dtt = dout
+    sc = blk.feature_shortcut
+    _linear_grads(rt, sc, dtt, x, B)
+    dx = _alloc(rt, B, Fin)
+    hip.gemm_nn(dt, dtt, A.w(sc.weight), B, Fin, U, hip.epilogue(dx, Fin, residual=dx_residual))
+    hip.gemm_tn(dt, dtt, a, U, U, B, hip.epilogue(A.g(l2.weight), U, atomic=True, out_f32=True))
+    hip.colsum(dt, dtt, A.g(l2.bias), B, U)
+    da = _alloc(rt, B, U)
+    hip.gemm_nn(dt, dtt, A.w(l2.weight), B, U, U, hip.epilogue(da, U))
+    dstats = torch.zeros(2, U, device=rt.device, dtype=torch.float32)
+    hip.bn_bwd_reduce(dt, da, a, z, dstats, B, U)
+    dz = _alloc(rt, B, U)
+    desc = hip.bn_desc(B, U, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn)
+    hip.bn_bwd_apply(dt, desc, da, a, z, dstats, dz, None, A.g(bn.weight), A.g(bn.bias))
+    hip.gemm_tn(dt, dz, x, U, Fin, B, hip.epilogue(A.g(l1.weight), Fin, atomic=True, out_f32=True))
+    dx2 = _alloc(rt, B, Fin)
+    hip.gemm_nn(dt, dz, A.w(l1.weight), B, Fin, U, hip.epilogue(dx2, Fin, residual=dx))
+    return dx2
+
+
+def prior_forward(rt, pd, feat, noise, acc_slot, step, site):
+    """-(mean log D(u) + mean log(1 - D(feat))) accumulated into acc_slot (f32 scalar view)."""
+    dt, A = rt.dt, rt.arena
+    B, sz = feat.shape
+    x2 = _alloc(rt, 2 * B, sz)
+    if noise is not None:
+        x2[:B].copy_(noise)
+    else:
+        hip.uniform_fill(dt, x2, B * sz, step.seed, site)
+    x2[B:].copy_(feat)
+    h0 = _alloc(rt, 2 * B, 1000)
+    hip.gemm_nt(dt, x2, A.w(pd.l0.weight), 2 * B, 1000, sz, hip.epilogue(h0, 1000, bias=pd.l0.bias, act=hip.ACT_RELU))
+    h1 = _alloc(rt, 2 * B, 200)
+    hip.gemm_nt(dt, h0, A.w(pd.l1.weight), 2 * B, 200, 1000, hip.epilogue(h1, 200, bias=pd.l1.bias, act=hip.ACT_RELU))
+    logit = torch.empty(2 * B, device=rt.device, dtype=torch.float32)
+    hip.prior_tail_fwd(dt, h1, pd.l2.weight, pd.l2.bias, B, 200, logit, acc_slot)
+    return (x2, h0, h1, logit)
+
+
+def prior_backward(rt, pd, ctx, gout, scale, dfeat_residual):
+    """Returns d(feat) [B][sz] + dfeat_residual."""
+    from .bert import _linear_grads
+    dt, A = rt.dt, rt.arena
+    x2, h0, h1, logit = ctx
+    B2, sz = x2.shape
+    B = B2 // 2
+    dh1 = _alloc(rt, B2, 200)
+    hip.prior_tail_bwd(dt, h1, pd.l2.weight, logit, gout, scale, B, 200, dh1, A.g(pd.l2.weight), A.g(pd.l2.bias))
+    _linear_grads(rt, pd.l1, dh1, h0, B2)
+    dh0 = _alloc(rt, B2, 1000)
+    hip.gemm_nn(dt, dh1, A.w(pd.l1.weight), B2, 1000, 200, hip.epilogue(dh0, 1000, dact_aux=h0, dact=hip.DACT_RELU))
+    _linear_grads(rt, pd.l0, dh0, x2, B2)
+    dfeat = _alloc(rt, B, sz)
+    # only the feature rows (B..2B) need an input gradient; the noise rows have none
+    hip.gemm_nn(dt, dh0[B:], A.w(pd.l0.weight), B, sz, 1000, hip.epilogue(dfeat, sz, residual=dfeat_residual))
+    return dfeat
+
+
+class _JSDLossFn(torch.autograd.Function):
+    """image/text features -> (total, [total, cross, prior, 0]); backward drives the head kernels and returns feature grads."""
+
+    @staticmethod
+    def forward(ctx, img, txt, mod, rt, step):
+        dt = rt.dt
+        training = step.training
+        in_dtypes = (img.dtype, txt.dtype)
+        img = img.to(rt.tdtype).contiguous()
+        txt = txt.to(rt.tdtype).contiguous()
+        B = img.shape[0]
+        acc = torch.zeros(4, device=rt.device, dtype=torch.float32)
+        noise = mod._noise or (None, None)
+        pctx_i = pctx_t = None
+        if mod.image_prior:
+            pctx_i = prior_forward(rt, mod.prior_d, img, noise[0], acc[2:3], step, step.site())
+        if mod.text_prior:
+            pctx_t = prior_forward(rt, mod.text_prior_d, txt, noise[1], acc[3:4], step, step.site())
+        gd = mod.global_d
+        f1, c1 = mi_block_forward(rt, gd.img_block, img, training)
+        f2, c2 = mi_block_forward(rt, gd.text_block, txt, training)
+        if training:
+            rt.bump_counters("loss", 2)
+        work = torch.empty(B, 8, device=rt.device, dtype=torch.float32)
+        hip.critic_jsd_fwd(dt, f1, f2, gd.temperature, B, gd.img_block.units, work, acc)
+        out = torch.empty(4, device=rt.device, dtype=torch.float32)
+        hip.loss_finalize(acc, mod.prior_weight, out)
+        ctx.mod, ctx.rt, ctx.saved = mod, rt, (f1, f2, c1, c2, work, pctx_i, pctx_t, B)
+        ctx.in_dtypes = (in_dtypes[0], in_dtypes[1])
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, gtotal, _gcomps):
+        mod, rt = ctx.mod, ctx.rt
+        dt, A = rt.dt, rt.arena
+        f1, f2, c1, c2, work, pctx_i, pctx_t, B = ctx.saved
+        gd = mod.global_d
+        U = gd.img_block.units
+        gout = gtotal.to(torch.float32).contiguous().view(1)
+        df1, df2 = _alloc(rt, B, U), _alloc(rt, B, U)
+        hip.critic_jsd_bwd(dt, f1, f2, gd.temperature, work, gout, 1.0 - mod.prior_weight, B, U, df1, df2, A.g(gd.temperature).view(1))
+        dimg = prior_backward(rt, mod.prior_d, pctx_i, gout, mod.prior_weight, None) if pctx_i is not None else None
+        dtxt = prior_backward(rt, mod.text_prior_d, pctx_t, gout, mod.prior_weight, None) if pctx_t is not None else None
+        dimg = mi_block_backward(rt, gd.img_block, c1, df1, dimg)
+        dtxt = mi_block_backward(rt, gd.text_block, c2, df2, dtxt)
+        return dimg.to(ctx.in_dtypes[0]), dtxt.to(ctx.in_dtypes[1]), None, None, None

@@ -1,0 +1,80 @@
+"""VLInfoModel — the reference's model wrapper (reference model.py:15-113) over the HIP encoders and loss.
+
+`is_amp=True` (the reference's autocast/fp16 mode) selects bf16 storage + bf16 MFMA kernels; `is_amp=False` (the reference's
+fp32 mode, also what its CPU path computes) selects the exact-f32 kernels (v_mfma_f32_32x32x2_f32), which is the parity mode.
+Moving the model to a GPU (`.to(device)`, as reference train.py:136 does) builds the flat parameter arena on that device.
+"""
+import torch
+from torch import nn
+
+from . import hip
+from .encoder import ImageEncoder, TextEncoder
+from .loss import JSDInfoMaxLoss
+from .runtime import DeviceRuntime
+
+
+def attach_runtime(model, device, lowp, seed=0):
+    groups = []
+    te = getattr(model, "text_encoder", None)
+    if te is not None and hasattr(te, "strans"):
+        groups = te.strans.contiguous_groups("text_encoder.strans.")
+    rt = DeviceRuntime(model, device, lowp, groups, seed)
+    # a leaf that requires grad: threads the custom autograd Functions into the graph even when their tensor inputs
+    # (images, token ids) do not require grad; parameter gradients are written straight into the arena by the kernels
+    rt.anchor = torch.zeros(1, device=rt.device, requires_grad=True)
+    return rt
+
+
+class VLInfoModel(nn.Module):
+    def __init__(self, text_encoder: TextEncoder, image_encoder: ImageEncoder, loss: JSDInfoMaxLoss, mode: str = "sbert", is_amp: bool = True):
+        super().__init__()
+        self.text_encoder = text_encoder
+        self.image_encoder = image_encoder
+        self.loss = loss
+        self.mode = mode
+        self.is_amp = is_amp
+        self._rt = None
+
+    # -- device placement builds the arena ---------------------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        p = next(self.parameters(), None)
+        dev = p.device if p is not None else None
+        if dev is not None and (dev.type == "cuda" or hip._allow_host_tensors):
+            if self._rt is None or self._rt.device != dev:
+                self._rt = attach_runtime(self, dev, self.is_amp, seed=torch.initial_seed() % (2 ** 31))
+        return out
+
+    @property
+    def runtime(self):
+        if self._rt is None:
+            raise RuntimeError("clip_lite_amd: move the model to a GPU first (model.to(device)); there is no CPU path")
+        return self._rt
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._rt is not None:
+            self._rt.arena.refresh_lowp()
+        return out
+
+    def forward(self, batch):
+        rt = self.runtime
+        image_features = self.image_encoder(batch["image"])
+        if self.mode == "sbert":
+            text_features = self.text_encoder(batch["caption_encodings"])
+        elif self.mode == "train_sbert":
+            if any(k in batch for k in ("neg_input_ids", "aug_image", "aug_input_ids")):
+                raise NotImplementedError("negative / augmented branches (reference model.py:61-92) are outside the accelerated hot path")
+            text_features = self.text_encoder({"input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"]})
+        else:
+            raise NotImplementedError(f"mode {self.mode!r}")
+        loss_dict = self.loss(image_features=image_features, text_features=text_features)
+        return {
+            "loss": loss_dict["total_loss"],
+            "loss_components": {
+                "total_loss": loss_dict["total_loss"].clone().detach(),
+                "cross_modal_loss": loss_dict["cross_modal_loss"].clone().detach(),
+                "visual_loss": loss_dict["visual_loss"].clone().detach(),
+                "textual_loss": loss_dict["textual_loss"].clone().detach(),
+            },
+        }

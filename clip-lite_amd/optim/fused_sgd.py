@@ -1,0 +1,175 @@
+"""Update path on the HIP kernels: global-norm clipping + SGD(momentum, weight decay, one group per tensor) + Lookahead
+in one pass over the flat parameter arena (csrc/optim_ops.hip).
+
+Mirrors the reference objects: torch.optim.SGD built with one param group per parameter (reference factories.py:464-482)
+wrapped in optim/lookahead.py:35-101's Lookahead(k, alpha). `state_dict()` keeps torch.optim.SGD's layout
+(`momentum_buffer` per parameter), and — like the reference (lookahead.py:68-78) — the slow weights are not serialized but
+re-seeded from the fast weights on load.
+"""
+import ctypes as C
+from typing import Any, Callable, Dict
+
+import torch
+
+from .. import hip
+
+CHUNK = 8192     # elements per workgroup of the update kernel
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=0, nesterov=False))
+        plist = [p for g in self.param_groups for p in g["params"]]
+        arenas = {id(p._clite[0]) for p in plist if hasattr(p, "_clite")}
+        if len(arenas) != 1 or any(not hasattr(p, "_clite") for p in plist):
+            raise RuntimeError("FusedSGD: parameters must live in one device arena — move the model to the GPU (model.to(device)) "
+                               "before building the optimizer, as reference train.py:136-138 does")
+        self.arena = plist[0]._clite[0]
+        dev = self.arena.device
+        self.flat_v = torch.zeros(self.arena.total, device=dev, dtype=torch.float32)
+        self.flat_slow = self.arena.flat_p.clone()
+        self.hp = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.max_norm = 0.0
+        self.grad_prescale = 1.0
+        self._items = None
+        self._items_key = None
+        self.before_step: Callable = None     # hook: e.g. wait for the gradient all-reduce stream
+
+    # -- work-item table (one entry per <= CHUNK slice of one tensor) ------------------------------------------------
+    def _base_lrs(self):
+        return tuple((g.get("initial_lr", g["lr"]), g["weight_decay"], bool(g["params"][0].requires_grad)) for g in self.param_groups)
+
+    def _build_items(self):
+        key = self._base_lrs()
+        if key == self._items_key:
+            return
+        rows = []
+        for g, (lr, wd, on) in zip(self.param_groups, key):
+            if not on:
+                continue
+            for p in g["params"]:
+                o, n = self.arena.index[p._clite[1]]
+                n4 = (n + 3) // 4 * 4
+                for s in range(0, n4, CHUNK):
+                    rows.append((o + s, min(CHUNK, n4 - s), lr, wd))
+        arr = (hip.OptimItem * len(rows))()
+        for i, (s, c, lr, wd) in enumerate(rows):
+            arr[i].start, arr[i].count, arr[i].lr, arr[i].wd = s, c, lr, wd
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self._items = host.to(self.arena.device)
+        self._n_items = len(rows)
+        self._items_key = key
+
+    def _lr_mult(self):
+        for g in self.param_groups:
+            base = g.get("initial_lr", None)
+            if base:
+                return g["lr"] / base
+        return 1.0
+
+    # -- reference train.py:222-223 ---------------------------------------------------------------------------------
+    def clip_grad_norm(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ over every parameter: the squared norm is reduced now, the scaling is applied
+        inside the update kernel. Returns the (device) total norm of the pre-scaled gradients."""
+        self.max_norm = float(max_norm)
+        self.sumsq.zero_()
+        hip.sumsq(self.arena.flat_g, self.arena.total, self.sumsq)
+        return self.sumsq.sqrt() * self.grad_prescale
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients are zeroed by the update kernel itself; this only clears a backward that was not followed by step()."""
+        if getattr(self, "_dirty", True):
+            self.arena.flat_g.zero_()
+        self._dirty = True
+
+    @torch.no_grad()
+    def step(self, closure=None, lookahead_sync=False, alpha=1.0):
+        if self.before_step is not None:
+            self.before_step()
+        self._build_items()
+        mom = self.param_groups[0]["momentum"]
+        self.hp.copy_(torch.tensor([self._lr_mult(), mom, self.max_norm, 1.0 if lookahead_sync else 0.0, alpha, self.grad_prescale, 0, 0]))
+        hip.sgd_step(self.arena.flat_p, self.arena.flat_g, self.flat_v, self.flat_slow, self.arena.flat_lp,
+                     C.c_void_p(self._items.data_ptr()), self._n_items, self.hp, self.sumsq)
+        self.max_norm = 0.0
+        self._dirty = False
+        return None
+
+    # -- torch.optim.SGD-compatible checkpoint layout -----------------------------------------------------------------
+    def state_dict(self):
+        state, groups = {}, []
+        for i, g in enumerate(self.param_groups):
+            p = g["params"][0]
+            o, n = self.arena.index[p._clite[1]]
+            state[i] = {"momentum_buffer": self.arena._torch_view(self.flat_v, o, n, p).clone()}
+            groups.append({k: v for k, v in g.items() if k != "params"} | {"params": [i]})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        for i, g in enumerate(self.param_groups):
+            saved = sd["param_groups"][i]
+            for k, v in saved.items():
+                if k != "params":
+                    g[k] = v
+            p = g["params"][0]
+            o, n = self.arena.index[p._clite[1]]
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is not None and st.get("momentum_buffer") is not None:
+                self.arena._torch_view(self.flat_v, o, n, p).copy_(st["momentum_buffer"])
+        self._items_key = None
+
+
+class Lookahead(object):
+    r"""Reference optim/lookahead.py:8-127 on top of FusedSGD: every ``k``-th step ``p = alpha*p + (1-alpha)*slow; slow = p`` —
+    executed inside the same update kernel."""
+
+    def __init__(self, optimizer: FusedSGD, k: int = 5, alpha: float = 0.8):
+        self.optimizer = optimizer
+        self.k = k
+        self.alpha = alpha
+        self._k_counter = 0
+        self.optimizer.flat_slow.copy_(self.optimizer.arena.flat_p)     # slow weights start as a copy of the parameters
+
+    def __getstate__(self):
+        return {"optimizer": self.optimizer, "alpha": self.alpha, "k": self.k, "_k_counter": self._k_counter}
+
+    @property
+    def param_groups(self):
+        return self.optimizer.param_groups
+
+    @property
+    def state(self):
+        return self.optimizer.state
+
+    def clip_grad_norm(self, max_norm):
+        return self.optimizer.clip_grad_norm(max_norm)
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    def state_dict(self):
+        return self.optimizer.state_dict()
+
+    def load_state_dict(self, state_dict: Dict[str, Any]):
+        self.optimizer.load_state_dict(state_dict)
+        self.optimizer.flat_slow.copy_(self.optimizer.arena.flat_p)      # reference lookahead.py:73-78
+
+    def step(self, closure: Callable = None):
+        self._k_counter += 1
+        sync = self._k_counter >= self.k
+        if sync:
+            self._k_counter = 0
+        return self.optimizer.step(closure, lookahead_sync=sync, alpha=self.alpha)
+
+    def load_slow_weights(self):
+        a = self.optimizer.arena
+        self._backup = a.flat_p.clone()
+        a.flat_p.copy_(self.optimizer.flat_slow)
+        a.refresh_lowp()
+
+    def restore_fast_weights(self):
+        a = self.optimizer.arena
+        a.flat_p.copy_(self._backup)
+        del self._backup
+        a.refresh_lowp()

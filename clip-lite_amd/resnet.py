@@ -1,0 +1,263 @@
+"""ResNet image encoder on the HIP kernels: torchvision-topology module tree (parameter/buffer names identical to
+torchvision.models.resnet*, which is what reference encoder.py:36-41 instantiates and encoder.py:84-94 renames) plus the
+hand-scheduled forward/backward executor that drives the implicit-GEMM conv, BatchNorm and pooling kernels.
+
+Data layout: activations NHWC, flattened to [N*H*W][C]; every conv output y (pre-BN) and every block output a (post
+BN/ReLU) is kept for backward. Train-mode BN statistics come out of the conv epilogue (per-channel sum / sum of squares
+through float atomics), so BN costs one apply pass forward and a reduce + apply pass backward.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+
+class Conv2dParams(nn.Module):
+    """Parameter holder with nn.Conv2d's state_dict surface (weight [K][C][R][S], bias=False)."""
+
+    def __init__(self, cin, cout, k, stride, pad):
+        super().__init__()
+        self.in_channels, self.out_channels, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")   # torchvision ResNet.__init__
+
+
+class BatchNormParams(nn.Module):
+    """Parameter/buffer holder with nn.BatchNorm{1,2}d's state_dict surface."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2dParams(inplanes, planes, 3, stride, 1)
+        self.bn1 = BatchNormParams(planes)
+        self.conv2 = Conv2dParams(planes, planes, 3, 1, 1)
+        self.bn2 = BatchNormParams(planes)
+        self.downsample = downsample
+
+    def units(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = Conv2dParams(inplanes, planes, 1, 1, 0)
+        self.bn1 = BatchNormParams(planes)
+        self.conv2 = Conv2dParams(planes, planes, 3, stride, 1)     # stride on the 3x3 (torchvision >= 0.4 "v1.5")
+        self.bn2 = BatchNormParams(planes)
+        self.conv3 = Conv2dParams(planes, planes * 4, 1, 1, 0)
+        self.bn3 = BatchNormParams(planes * 4)
+        self.downsample = downsample
+
+    def units(self):
+        return [(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)]
+
+
+SPECS = {"resnet18": (BasicBlock, (2, 2, 2, 2)), "resnet34": (BasicBlock, (3, 4, 6, 3)), "resnet50": (Bottleneck, (3, 4, 6, 3)),
+         "resnet101": (Bottleneck, (3, 4, 23, 3)), "resnet152": (Bottleneck, (3, 8, 36, 3))}
+
+
+class ResNet(nn.Module):
+    def __init__(self, name="resnet50"):
+        super().__init__()
+        if name not in SPECS:
+            raise ValueError(f"unsupported visual backbone {name!r}; supported: {sorted(SPECS)}")
+        block, layers = SPECS[name]
+        self.inplanes = 64
+        self.conv1 = Conv2dParams(3, 64, 7, 2, 3)
+        self.bn1 = BatchNormParams(64)
+        self.layer1 = self._make_layer(block, 64, layers[0], 1)
+        self.layer2 = self._make_layer(block, 128, layers[1], 2)
+        self.layer3 = self._make_layer(block, 256, layers[2], 2)
+        self.layer4 = self._make_layer(block, 512, layers[3], 2)
+        self.fc = nn.Identity()                                        # reference encoder.py:41
+        self.out_dim = 512 * block.expansion
+
+    def _make_layer(self, block, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(Conv2dParams(self.inplanes, planes * block.expansion, 1, stride, 0),
+                                       BatchNormParams(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def blocks(self):
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for b in layer:
+                yield b
+
+
+# ---------------------------------------------------------------------------------------------------- executor
+class _Unit:
+    """Saved tensors of one conv->BN unit."""
+    __slots__ = ("conv", "bn", "cv", "x", "y", "stats", "out")
+
+
+def _alloc(rt, *shape):
+    return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
+
+
+def _bn_desc(rt, bn, M, stats, relu, training, res=None):
+    res_bn = None
+    if res is not None:
+        rbn, rstats = res
+        res_bn = (rstats, rbn.weight, rbn.bias, rbn.running_mean, rbn.running_var)
+    return hip.bn_desc(M, bn.num_features, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                       training, training, bn.momentum, bn.eps, relu, res_bn, centered=rt.precise_bn)
+
+
+def _conv(rt, x, N, H, W, conv, training):
+    cv = hip.conv_desc(rt.dt, N, H, W, conv.in_channels, conv.out_channels, conv.k, conv.k, conv.stride, conv.pad)
+    M = N * cv.Ho * cv.Wo
+    y = _alloc(rt, M, conv.out_channels)
+    stats = torch.zeros(3, conv.out_channels, device=rt.device, dtype=torch.float32) if training else None
+    hip.conv_fwd(x, rt.arena.w(conv.weight), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
+    if training and rt.precise_bn:
+        hip.bn_centered_var(rt.dt, y, stats, M, conv.out_channels)
+    u = _Unit()
+    u.conv, u.cv, u.x, u.y, u.stats = conv, cv, x, y, stats
+    return u
+
+
+def resnet_forward(rt, net, image, training):
+    """image: f32 NCHW [N][3][H][W] on the device. Returns (features [N][C] in compute dtype, ctx for backward)."""
+    N, _, H, W = image.shape
+    dt = rt.dt
+    ctx = {"N": N}
+    # stem: 7x7/2 pad 3 on the pre-padded NHWC4 image
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = H + 6, W + 6 + 2
+    Wp += Wp % 2
+    xpad = _alloc(rt, N, Hp, Wp, 4)
+    hip.image_to_nhwc4(dt, image, xpad, N, H, W, 3, Hp, Wp)
+    wv = _alloc(rt, 64, 7, 8, 4)
+    hip.stem_pack(dt, rt.arena.w32(net.conv1.weight), wv)
+    y0 = _alloc(rt, N * Ho * Wo, 64)
+    st0 = torch.zeros(3, 64, device=rt.device, dtype=torch.float32) if training else None
+    hip.stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, hip.epilogue(y0, 64, colsum=st0))
+    if training and rt.precise_bn:
+        hip.bn_centered_var(dt, y0, st0, N * Ho * Wo, 64)
+    a0 = _alloc(rt, N * Ho * Wo, 64)
+    hip.bn_apply(dt, _bn_desc(rt, net.bn1, N * Ho * Wo, st0, True, training), y0, None, a0)
+    Hq, Wq = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+    p0 = _alloc(rt, N * Hq * Wq, 64)
+    idx = torch.empty(N * Hq * Wq, 64, device=rt.device, dtype=torch.uint8)
+    hip.maxpool_fwd(dt, a0, p0, idx, N, Ho, Wo, 64)
+    ctx["stem"] = (xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq)
+
+    x, Hc, Wc = p0, Hq, Wq
+    recs = []
+    for blk in net.blocks():
+        units = []
+        xin, Hin, Win = x, Hc, Wc
+        h, Hh, Wh = xin, Hin, Win
+        specs = blk.units()
+        for i, (conv, bn) in enumerate(specs):
+            u = _conv(rt, h, N, Hh, Wh, conv, training)
+            u.bn = bn
+            Hh, Wh = u.cv.Ho, u.cv.Wo
+            M = N * Hh * Wh
+            last = i == len(specs) - 1
+            u.out = _alloc(rt, M, conv.out_channels)
+            if not last:
+                hip.bn_apply(dt, _bn_desc(rt, bn, M, u.stats, True, training), u.y, None, u.out)
+            units.append(u)
+            h = u.out
+        ud = None
+        last = units[-1]
+        M = N * Hh * Wh
+        if blk.downsample is not None:
+            ud = _conv(rt, xin, N, Hin, Win, blk.downsample[0], training)
+            ud.bn = blk.downsample[1]
+            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, res=(ud.bn, ud.stats)), last.y, ud.y, last.out)
+        else:
+            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training), last.y, xin, last.out)
+        recs.append((units, ud, Hin, Win))
+        x, Hc, Wc = last.out, Hh, Wh
+    Cout = net.out_dim
+    feat = _alloc(rt, N, Cout)
+    hip.avgpool_fwd(dt, x, feat, N, Hc * Wc, Cout)
+    ctx["recs"], ctx["final"] = recs, (Hc, Wc, Cout)
+    return feat, ctx
+
+
+def _bn_backward(rt, u, dout, mask, N, want_dz=False, train_params=True):
+    """BN backward of unit u given dout (gradient w.r.t. the post-BN tensor) and the ReLU mask tensor (or None)."""
+    M, Cc = u.y.shape
+    dstats = torch.zeros(2, Cc, device=rt.device, dtype=torch.float32)
+    hip.bn_bwd_reduce(rt.dt, dout, mask, u.y, dstats, M, Cc)
+    dy = _alloc(rt, M, Cc)
+    dz = _alloc(rt, M, Cc) if want_dz else None
+    bn = u.bn
+    desc = hip.bn_desc(M, Cc, u.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn)
+    dg = rt.arena.g(bn.weight) if bn.weight.requires_grad else None
+    db = rt.arena.g(bn.bias) if bn.bias.requires_grad else None
+    hip.bn_bwd_apply(rt.dt, desc, dout, mask, u.y, dstats, dy, dz, dg, db)
+    return dy, dz
+
+
+def resnet_backward(rt, net, ctx, dfeat):
+    """dfeat: [N][C] gradient of the pooled features (compute dtype). Accumulates parameter gradients into the arena."""
+    N = ctx["N"]
+    dt = rt.dt
+    Hc, Wc, Cout = ctx["final"]
+    dout = _alloc(rt, N * Hc * Wc, Cout)
+    hip.avgpool_bwd(dt, dfeat, dout, N, Hc * Wc, Cout)
+    for units, ud, Hin, Win in reversed(ctx["recs"]):
+        last = units[-1]
+        xin = units[0].x
+        identity = ud is None
+        # block output = relu(bn_last(y_last) + shortcut): the mask is the block output itself
+        dy, dz = _bn_backward(rt, last, dout, last.out, N, want_dz=identity)
+        dyd = None
+        if ud is not None:
+            dyd, _ = _bn_backward(rt, ud, dout, last.out, N)
+        for i in range(len(units) - 1, -1, -1):
+            u = units[i]
+            if u.conv.weight.requires_grad:
+                hip.conv_wgrad(dy, u.x, u.cv, rt.arena.g(u.conv.weight))
+            Cin = u.conv.in_channels
+            dx = _alloc(rt, u.x.shape[0], Cin)
+            if i > 0:
+                hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin))
+                prev = units[i - 1]
+                dy, _ = _bn_backward(rt, prev, dx, prev.out, N)
+            else:
+                # gradient w.r.t. the block input: main path + shortcut
+                hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None))
+                if ud is not None:
+                    if ud.conv.weight.requires_grad:
+                        hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight))
+                    dx2 = _alloc(rt, u.x.shape[0], Cin)
+                    hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx2, Cin, residual=dx))
+                    dx = dx2
+                dout = dx
+    xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq = ctx["stem"]
+    da0 = _alloc(rt, N * Ho * Wo, 64)
+    hip.maxpool_bwd(dt, dout, idx, da0, N, Ho, Wo, 64)
+    u0 = _Unit()
+    u0.y, u0.stats, u0.bn = y0, st0, net.bn1
+    dy0, _ = _bn_backward(rt, u0, da0, a0, N)
+    if net.conv1.weight.requires_grad:
+        dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)
+        hip.stem_wgrad(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, dwv)
+        hip.stem_unpack_grad(dwv, rt.arena.g(net.conv1.weight))

@@ -1,0 +1,158 @@
+"""Device-side runtime of the train step: flat parameter/gradient arenas and per-step kernel state.
+
+Layout in HBM (MI355X, 288 GB): every trainable tensor of the model lives in ONE flat f32 buffer `flat_p` (master
+weights), with same-offset twins `flat_g` (gradients, written in place by the wgrad kernels' float atomics — no per-tensor
+.grad allocation, no autograd accumulation pass) and, in bf16 mode, `flat_lp` (the bf16 copy the forward/backward kernels
+read; refreshed by the fused update kernel). Conv weights are stored [K][R][S][C] (what the implicit-GEMM loaders gather)
+and exposed to PyTorch as channels_last [K][C][R][S] views, so `state_dict()` keeps the reference's torchvision shapes
+(reference encoder.py:84-94 key map). The gradient all-reduce (reference train.py:174-178, DDP) runs on slices of `flat_g`.
+"""
+import torch
+
+from . import hip
+
+ALIGN = 64  # elements; keeps every tensor 256-byte aligned and QKV groups exactly contiguous
+
+
+def _kernel_shape(p):
+    """Shape of the tensor as the kernels see it (conv weights KCRS -> KRSC)."""
+    if p.dim() == 4:
+        K, Cc, R, S = p.shape
+        return (K, R, S, Cc)
+    return tuple(p.shape)
+
+
+class Arena:
+    def __init__(self, named_params, device, lowp, contiguous_groups=()):
+        named = list(named_params)
+        by_name = dict(named)
+        order, placed = [], set()
+        group_of = {}
+        for g in contiguous_groups:
+            g = [n for n in g if n in by_name]
+            for n in g:
+                group_of[n] = g
+        for n, _ in named:
+            if n in placed:
+                continue
+            for m in group_of.get(n, [n]):
+                if m not in placed:
+                    order.append(m)
+                    placed.add(m)
+        self.device, self.lowp = device, lowp
+        self.index = {}
+        off = 0
+        for n in order:
+            numel = by_name[n].numel()
+            self.index[n] = (off, numel)
+            off += (numel + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.flat_p = torch.zeros(off, device=device, dtype=torch.float32)
+        self.flat_g = torch.zeros(off, device=device, dtype=torch.float32)
+        self.flat_lp = torch.zeros(off, device=device, dtype=torch.bfloat16) if lowp else None
+        self.params = {}
+        self.names = order
+        for n in order:
+            p = by_name[n]
+            o, numel = self.index[n]
+            ks = _kernel_shape(p)
+            src = p.detach().to(device=device, dtype=torch.float32)
+            if p.dim() == 4:
+                src = src.permute(0, 2, 3, 1)
+            self.flat_p[o:o + numel].view(ks).copy_(src)
+            p.data = self._torch_view(self.flat_p, o, numel, p)
+            p.grad = self._torch_view(self.flat_g, o, numel, p)
+            p._clite = (self, n)
+            self.params[n] = p
+        self.refresh_lowp()
+
+    @staticmethod
+    def _torch_view(flat, o, numel, p):
+        if p.dim() == 4:
+            K, Cc, R, S = p.shape
+            return flat[o:o + numel].view(K, R, S, Cc).permute(0, 3, 1, 2)
+        return flat[o:o + numel].view(p.shape)
+
+    # kernel-side views -------------------------------------------------------------------------------------------
+    def w(self, p):
+        """Weight as the kernels read it: compute-dtype copy, kernel layout, contiguous."""
+        _, n = p._clite
+        o, numel = self.index[n]
+        src = self.flat_lp if self.lowp else self.flat_p
+        return src[o:o + numel].view(_kernel_shape(p))
+
+    def w32(self, p):
+        _, n = p._clite
+        o, numel = self.index[n]
+        return self.flat_p[o:o + numel].view(_kernel_shape(p))
+
+    def g(self, p):
+        """f32 gradient buffer in kernel layout (wgrad kernels accumulate here)."""
+        _, n = p._clite
+        o, numel = self.index[n]
+        return self.flat_g[o:o + numel].view(_kernel_shape(p))
+
+    def span(self, params, grad=False, lowp=True):
+        """One contiguous kernel-side view over adjacent tensors (e.g. BERT q/k/v weights)."""
+        offs = [self.index[p._clite[1]] for p in params]
+        for (o, n), (o2, _) in zip(offs[:-1], offs[1:]):
+            assert o + n == o2, "tensors are not contiguous in the arena"
+        o, end = offs[0][0], offs[-1][0] + offs[-1][1]
+        src = self.flat_g if grad else (self.flat_lp if (self.lowp and lowp) else self.flat_p)
+        return src[o:end]
+
+    def refresh_lowp(self):
+        """Re-derive the bf16 copy from the f32 masters (after load_state_dict or any out-of-band weight edit)."""
+        if self.lowp:
+            hip.cast_bf16(self.flat_p, self.flat_lp, self.total)
+
+
+class StepState:
+    """Per-forward kernel state: dropout seed of this step and a bump allocator of dropout sites."""
+
+    def __init__(self, seed, training):
+        self.seed, self.training = seed, training
+        self._site = 0
+
+    def site(self):
+        self._site += 1
+        return self._site
+
+
+class DeviceRuntime:
+    """Everything a kernel-driving executor needs: device, compute dtype, the parameter arena, dropout seeding and the
+    BatchNorm `num_batches_tracked` counters (kept in one int64 tensor per owner so a step bumps them with one add)."""
+
+    def __init__(self, model, device, lowp, contiguous_groups=(), seed=0):
+        self.device = torch.device(device)
+        self.lowp = bool(lowp)
+        self.dt = hip.BF16 if lowp else hip.F32
+        self.tdtype = torch.bfloat16 if lowp else torch.float32
+        # exact-f32 parity mode: BatchNorm variance by a second, centered pass (PyTorch-grade accuracy); the bf16 production mode
+        # keeps the single-pass statistics that come for free out of the conv epilogue
+        self.precise_bn = not lowp
+        self.arena = Arena(model.named_parameters(), self.device, lowp, contiguous_groups)
+        self.base_seed = int(seed)
+        self.steps = 0
+        # flatten num_batches_tracked buffers per top-level owner
+        self.counters = {}
+        owners = {}
+        for name, mod in model.named_modules():
+            if "num_batches_tracked" in getattr(mod, "_buffers", {}):
+                owners.setdefault(name.split(".")[0], []).append(mod)
+        for owner, mods in owners.items():
+            flat = torch.zeros(len(mods), dtype=torch.long, device=self.device)
+            for i, m in enumerate(mods):
+                flat[i] = m._buffers["num_batches_tracked"].to(self.device)
+                m._buffers["num_batches_tracked"] = flat[i]
+            self.counters[owner] = flat
+        for mod in model.modules():
+            mod._clite_rt = self
+
+    def bump_counters(self, owner, n=1):
+        if owner in self.counters:
+            self.counters[owner] += n
+
+    def next_step(self, training):
+        self.steps += 1
+        return StepState(self.base_seed * 1000003 + self.steps, training)

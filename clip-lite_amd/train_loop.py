@@ -1,0 +1,150 @@
+"""The pretraining loop of the reference (train.py:120-296) around the HIP train step: same flags, same per-iteration order
+(zero_grad -> batch -> forward -> backward -> clip_grad_norm -> optimizer step -> scaler update -> scheduler step), same
+logging / checkpoint / validation cadence. Differences, all forced by the target: the gradient mean over ranks is an explicit
+RCCL exchange of the flat gradient arena overlapped with backward (utils/distributed.py) instead of DistributedDataParallel;
+clipping + SGD + Lookahead run in one fused kernel; wandb/loguru (absent from the image) are replaced by the stdlib logger."""
+import argparse
+from collections import Counter
+from typing import Any
+
+import torch
+from torch.utils.data import DataLoader, DistributedSampler
+
+from .config import Config
+from .factories import LRSchedulerFactory, OptimizerFactory, PretrainingDatasetFactory, PretrainingModelFactory
+from .utils import distributed as dist
+from .utils.base import Timer, make_directory
+from .utils.checkpointing import CheckpointManager
+from .utils.common import GradScaler, common_parser, common_setup, cycle, logger
+
+
+def build_parser():
+    parser = common_parser(description="Train the VLInfo (CLIP-Lite) model on image-caption pairs.")
+    group = parser.add_argument_group("Checkpointing and Logging")
+    group.add_argument("--resume-from", default=None, help="Path to a checkpoint to resume training from (if provided).")
+    group.add_argument("--checkpoint-every", type=int, default=10000, help="Serialize model to a checkpoint after every these many iterations.")
+    group.add_argument("--log-every", type=int, default=500, help="Log training curves after every these many iterations.")
+    group.add_argument("--climax-freq", type=int, default=1000, help="Frequency to checkpoint at during climax (last 20%% training)")
+    return parser
+
+
+def init_dataloaders(_C, _A, type="normal"):
+    if type != "normal":
+        raise NotImplementedError("clustered negative sampling (reference train.py:70-76) needs the faiss/LMDB assets and is out of scope")
+    train_dataset = PretrainingDatasetFactory.from_config(_C, split="train")
+    val_dataset = PretrainingDatasetFactory.from_config(_C, split="val")
+    batch_size = _C.OPTIM.BATCH_SIZE // dist.get_world_size()
+    distributed = dist.get_world_size() > 1
+    train_sampler = DistributedSampler(train_dataset, shuffle=True) if distributed else None
+    val_sampler = DistributedSampler(val_dataset, shuffle=False) if distributed else None
+    train_dataloader = DataLoader(train_dataset, batch_size=batch_size, sampler=train_sampler, shuffle=train_sampler is None,
+                                  num_workers=_A.cpu_workers, pin_memory=True, drop_last=True, collate_fn=train_dataset.collate_fn)
+    val_dataloader = DataLoader(val_dataset, batch_size=batch_size, sampler=val_sampler, shuffle=False, num_workers=_A.cpu_workers,
+                                pin_memory=True, drop_last=False, collate_fn=val_dataset.collate_fn)
+    return train_dataloader, val_dataloader
+
+
+class TrainStep:
+    """One optimisation step on one rank: reference train.py:211-226."""
+
+    def __init__(self, model, optimizer, scheduler, scaler, clip_grad_norm, exchange=None):
+        self.model, self.optimizer, self.scheduler, self.scaler = model, optimizer, scheduler, scaler
+        self.clip, self.exchange = clip_grad_norm, exchange
+        self.inner = optimizer.optimizer if hasattr(optimizer, "optimizer") else optimizer
+
+    def __call__(self, batch):
+        self.optimizer.zero_grad()
+        output_dict = self.model(batch)
+        loss = output_dict["loss"]
+        self.scaler.scale(loss).backward()
+        if self.exchange is not None:
+            self.inner.grad_prescale = self.exchange.finish()       # wait for the gradient mean (SUM here, 1/world in the update)
+        self.scaler.unscale_(self.optimizer)
+        if self.clip and self.clip > 0:
+            self.optimizer.clip_grad_norm(self.clip)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        self.scheduler.step()
+        return output_dict
+
+
+def main(_A: argparse.Namespace):
+    if _A.num_gpus_per_machine == 0 or not torch.cuda.is_available():
+        raise RuntimeError("clip_lite_amd trains on MI355X GPUs only: the device math is HIP kernels and there is no CPU path "
+                           "(the reference's own --num-gpus-per-machine 0 mode also fails: loss.py:186 calls .cuda())")
+    device: Any = torch.device("cuda", torch.cuda.current_device())
+    _C = Config(_A.config, _A.config_override)
+    common_setup(_C, _A)
+    if dist.is_master_process():
+        make_directory(_A.checkpoints_dir + _C.RUN_ID)
+
+    model = PretrainingModelFactory.from_config(_C).to(device)
+    dist.broadcast_parameters(model)
+    optimizer = OptimizerFactory.from_config(_C, model.named_parameters())
+    scheduler = LRSchedulerFactory.from_config(_C, optimizer)
+    scaler = GradScaler(enabled=_C.AMP)
+
+    if _A.resume_from is not None:
+        start_iteration = CheckpointManager(model=model, optimizer=optimizer, scheduler=scheduler, scaler=scaler).load(_A.resume_from)
+    else:
+        start_iteration = 0
+
+    train_dataloader, val_dataloader = init_dataloaders(_C, _A, type="normal")
+    train_dataloader_iter = cycle(train_dataloader, device, start_iteration, type="normal")
+
+    exchange = None
+    if dist.get_world_size() > 1:
+        dist.synchronize()
+        exchange = dist.GradientExchange(model.runtime.arena)
+        model.runtime.exchange = exchange
+
+    timer = Timer(start_from=start_iteration + 1, total_iterations=_C.OPTIM.NUM_ITERATIONS)
+    if dist.is_master_process():
+        checkpoint_manager = CheckpointManager(_A.checkpoints_dir + _C.RUN_ID, model=model, optimizer=optimizer, scheduler=scheduler, scaler=scaler)
+
+    step = TrainStep(model, optimizer, scheduler, scaler, _C.OPTIM.CLIP_GRAD_NORM, exchange)
+    for iteration in range(start_iteration + 1, _C.OPTIM.NUM_ITERATIONS + 1):
+        timer.tic()
+        batch = next(train_dataloader_iter)
+        output_dict = step(batch)
+        timer.toc()
+
+        if iteration % _A.log_every == 0:
+            loss = output_dict["loss"].item()          # host sync: off the timed path except on logging iterations
+            logger.info(f"{timer.stats} [Loss {loss:.3f}] [GPU {dist.gpu_mem_usage()} MB]")
+            if dist.is_master_process():
+                comps = {k: float(v) for k, v in output_dict["loss_components"].items()}
+                logger.info("train " + " ".join(f"{k}={v:.5f}" for k, v in comps.items()))
+
+        if iteration % _A.checkpoint_every == 0:
+            if dist.is_master_process():
+                checkpoint_manager.step(iteration)
+            dist.synchronize()
+            torch.set_grad_enabled(False)
+            model.eval()
+            val_loss_counter: Counter = Counter()
+            val_iteration = 0
+            for val_iteration, val_batch in enumerate(val_dataloader, start=1):
+                for key in val_batch:
+                    val_batch[key] = val_batch[key].to(device)
+                val_loss_counter.update(model(val_batch)["loss_components"])
+            val_loss_dict = {k: v / max(val_iteration, 1) for k, v in dict(val_loss_counter).items()}
+            dist.average_across_processes(val_loss_dict)
+            torch.set_grad_enabled(True)
+            model.train()
+            if dist.is_master_process():
+                logger.info("val " + " ".join(f"{k}={float(v):.5f}" for k, v in val_loss_dict.items()))
+
+        if (iteration / _C.OPTIM.NUM_ITERATIONS) > 0.8 and iteration % _A.climax_freq == 0:
+            if dist.is_master_process():
+                checkpoint_manager.climax_step(iteration)
+            dist.synchronize()
+
+
+def cli():
+    _A = build_parser().parse_args()
+    if _A.num_gpus_per_machine == 0:
+        main(_A)
+    else:
+        dist.launch(main, num_machines=_A.num_machines, num_gpus_per_machine=_A.num_gpus_per_machine, machine_rank=_A.machine_rank,
+                    dist_url=_A.dist_url, args=(_A,))

@@ -61,13 +61,14 @@ typedef struct clite_conv {
   int32_t Ho, Wo;
 } clite_conv;
 
-/* C[M,N] = A[M,K] * B[N,K]^T  — nn.Linear forward (reference loss.py:16-22,46-48; HF BertModel linears
+/* lda / ldb: row strides in elements (multiples of 8), so a strided row subset (BERT's h[:, 0] for the pooler) needs no copy.
+ * C[M,N] = A[M,K] * B[N,K]^T  — nn.Linear forward (reference loss.py:16-22,46-48; HF BertModel linears
  * behind encoder.py:193). K % 8 == 0, N % 8 == 0. */
-int clite_gemm_nt(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
+int clite_gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
 /* C[M,N] = A[M,K] * B[K,N]       — nn.Linear input gradient (autograd of the same call sites). */
-int clite_gemm_nn(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
+int clite_gemm_nn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
 /* C[M,N] (+)= A[K,M]^T * B[K,N]  — nn.Linear weight gradient; ep->atomic selects f32 accumulation. */
-int clite_gemm_tn(const void* A, const void* B, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
+int clite_gemm_tn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream);
 
 /* y = conv(x, w): torchvision ResNet nn.Conv2d forward (reference encoder.py:36-38,63; block arithmetic as
  * restated in model_zoo/resnet.py:60-100). Epilogue applies to y viewed as [N*Ho*Wo][K]. */
@@ -91,7 +92,7 @@ int clite_stem_unpack_grad(const float* dwv, float* dw, void* stream);
  * (clite_epilogue.colsum). Biased variance normalises; unbiased variance goes into running_var. */
 typedef struct clite_bn {
   int32_t M, C;
-  const float* stats;        /* [2][C] */
+  const float* stats;        /* [2][C], or [3][C] when centered = 1 */
   const float* gamma;        /* [C] */
   const float* beta;         /* [C] */
   float* running_mean;       /* [C] */
@@ -100,6 +101,7 @@ typedef struct clite_bn {
   int32_t update_running;    /* 1: workgroup 0 updates running_* with `momentum` */
   float momentum, eps;
   int32_t relu;              /* apply ReLU at the end */
+  int32_t centered;          /* 1: variance = stats[2][c] / M (two-pass, from clite_bn_centered_var) instead of E[x^2]-E[x]^2 */
   /* optional second BN applied to the residual operand (the 1x1/stride downsample branch of a block) */
   const float* res_stats;
   const float* res_gamma;
@@ -108,6 +110,9 @@ typedef struct clite_bn {
   float* res_running_var;
 } clite_bn;
 
+/* Second pass of a two-pass variance (used by the exact-f32 parity mode): stats[2][c] += sum_m (y[m][c] - stats[0][c]/M)^2;
+ * stats[2][*] must be zero on entry. */
+int clite_bn_centered_var(int dtype, const void* y, float* stats, int M, int C, void* stream);
 /* out = relu?( bn(y) + [res | bn_res(res)] ) */
 int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const void* res, void* out, void* stream);
 /* dstats[0][c] += sum dz, dstats[1][c] += sum dz*y, dz = dout * (mask > 0) (mask NULL: dz = dout). dstats pre-zeroed. */
@@ -147,6 +152,9 @@ int clite_attention_fwd(int dtype, const void* qkv, const int64_t* mask, void* c
                         float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream);
 int clite_attention_bwd(int dtype, const void* qkv, const int64_t* mask, const void* dctx, void* dqkv, int B, int L, int H,
                         float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream);
+
+/* BertPooler tanh backward: out = dy * (1 - y^2), n % 8 == 0 */
+int clite_tanh_bwd(int dtype, const void* dy, const void* y, void* out, uint64_t n, void* stream);
 
 /* ---- JSD mutual-information loss (reference loss.py). f1 = img_block(image_features), f2 = text_block(text_features),
  * both [B][D], D % 8 == 0, D <= 2048. Negatives are roll-by-one inside the batch: pair (n, n+1 mod B) (loss.py:214-216).

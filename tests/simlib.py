@@ -76,7 +76,7 @@ class Bn(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("C", C.c_int32), ("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("training", C.c_int32),
-        ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32),
+        ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32), ("centered", C.c_int32),
         ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
         ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p),
     ]

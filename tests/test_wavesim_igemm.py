@@ -34,7 +34,7 @@ def test_gemm_nt_epilogue(dtype, M, N, K):
     out = np.zeros((M, N), np.float32)
     pre = np.zeros((M, N), np.uint16 if dtype == BF16 else np.float32)
     ep = make_ep(out, N, out_f32=True, bias=bias, act=2, preact=pre, residual=Rb)
-    assert lib().clite_gemm_nt(ptr(Ab), ptr(Bb), M, N, K, dtype, C.byref(ep), None) == 0
+    assert lib().clite_gemm_nt(ptr(Ab), K, ptr(Bb), K, M, N, K, dtype, C.byref(ep), None) == 0
     z = A @ B.T + bias
     from scipy.special import erf
     ref = 0.5 * z * (1 + erf(z / np.sqrt(2))) + R
@@ -51,7 +51,7 @@ def test_gemm_nn_dact(dtype, M, N, K):
     aux, auxb = _prep(rng.standard_normal((M, N), dtype=np.float32), dtype)
     out = np.zeros((M, N), np.float32)
     ep = make_ep(out, N, out_f32=True, dact_aux=auxb, dact=1)
-    assert lib().clite_gemm_nn(ptr(Ab), ptr(Bb), M, N, K, dtype, C.byref(ep), None) == 0
+    assert lib().clite_gemm_nn(ptr(Ab), K, ptr(Bb), N, M, N, K, dtype, C.byref(ep), None) == 0
     _close(out, (A @ B) * (aux > 0))
 
 
@@ -63,7 +63,7 @@ def test_gemm_tn_atomic(dtype, M, N, K):
     B, Bb = _prep(rng.standard_normal((K, N), dtype=np.float32), dtype)
     out = np.ones((M, N), np.float32)
     ep = make_ep(out, N, out_f32=True, atomic=True)
-    assert lib().clite_gemm_tn(ptr(Ab), ptr(Bb), M, N, K, dtype, C.byref(ep), None) == 0
+    assert lib().clite_gemm_tn(ptr(Ab), M, ptr(Bb), N, M, N, K, dtype, C.byref(ep), None) == 0
     _close(out, 1 + A.T @ B)
 
 

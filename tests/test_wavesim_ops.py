@@ -31,7 +31,7 @@ def test_bn_apply_and_backward(dtype, M, Cc, dual):
     rstats = np.stack([r.sum(0), (r * r).sum(0)]).astype(np.float32)
     rm = np.zeros(Cc, np.float32); rv = np.ones(Cc, np.float32)
     rm2 = np.zeros(Cc, np.float32); rv2 = np.ones(Cc, np.float32)
-    p = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 1, 0.1, 1e-5, 1,
+    p = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 1, 0.1, 1e-5, 1, 0,
            ptr(rstats) if dual else None, ptr(g2) if dual else None, ptr(b2) if dual else None,
            ptr(rm2) if dual else None, ptr(rv2) if dual else None)
     out = outbuf((M, Cc), dtype)
