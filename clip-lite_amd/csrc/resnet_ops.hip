@@ -84,14 +84,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, c
   }
 }
 
-// dstats[0][c] += sum dz, dstats[1][c] += sum dz*y, with dz = dout * (mask > 0)
+// dstats[0][c] += sum dz, dstats[1][c] += sum dz*(y - mean_c), with dz = dout * (mask > 0) and mean_c = stats[0][c]/M.
+// Centering y here (instead of forming sum dz*y - mean*sum dz afterwards) avoids cancellation on channels with |mean| >> std.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const T* mask, const T* y, float* dstats, int M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const T* mask, const T* y, const float* stats, float* dstats, int M, int C, int rows_per_block) {
   __shared__ float red[256 * 16];
   const int CPR = C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
-  float s1[8], s2[8];
+  float s1[8], s2[8], mean[8];
   zero8(s1); zero8(s2);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) mean[e] = stats[c0 + e] / (float)M;
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > M) row_end = M;
   for (int r = row_begin + r0; r < row_end; r += RPS) {
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const
       for (int e = 0; e < 8; ++e) d[e] = m[e] > 0.f ? d[e] : 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] += d[e]; s2[e] += d[e] * yv[e]; }
+    for (int e = 0; e < 8; ++e) { s1[e] += d[e]; s2[e] += d[e] * (yv[e] - mean[e]); }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* y, float*
   }
 }
 
-// dy = gamma*rstd*(dz - S1/M - xhat*G/M), G = sum dz*xhat = rstd*(S2 - mean*S1); dgamma += G, dbeta += S1
+// dy = gamma*rstd*(dz - S1/M - xhat*G/M), G = sum dz*xhat = rstd*S2 (S2 = sum dz*(y-mean) from the reduce kernel); dgamma += G, dbeta += S1
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* dout, const T* mask, const T* y, const float* dstats,
                                                            T* dy, T* dz_out, float* dgamma, float* dbeta, int rows_per_block) {
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
     float var = p.centered ? p.stats[2 * p.C + c] * inv_count : fmaxf(p.stats[p.C + c] * inv_count - mean[e] * mean[e], 0.f);
     rstd[e] = rsqrtf(var + p.eps);
     float S1 = dstats[c], S2 = dstats[p.C + c];
-    float G = rstd[e] * (S2 - mean[e] * S1);
+    float G = rstd[e] * S2;
     float a = p.gamma[c] * rstd[e];
     // dy = a*(dz - S1/M - (y-mean)*rstd*G/M)
     ka[e] = a;
@@ -390,14 +393,14 @@ extern "C" int clite_bn_centered_var(int dtype, const void* y, float* stats, int
   return (int)hipGetLastError();
 }
 
-extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, float* dstats, int M, int C, void* stream) {
-  if (!bn_ok(M, C) || !dout || !y || !dstats) return -1;
+extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, const float* stats, float* dstats, int M, int C, void* stream) {
+  if (!bn_ok(M, C) || !dout || !y || !stats || !dstats) return -1;
   int rpb;
   int grid = bn_grid(M, C, &rpb);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, dstats, M, C, rpb),
-           hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, dstats, M, C, rpb));
+           hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, stats, dstats, M, C, rpb),
+           hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, stats, dstats, M, C, rpb));
   return (int)hipGetLastError();
 }
 

@@ -61,7 +61,7 @@ _SIGNATURES = {
     "clite_stem_unpack_grad": [_V, _V, _V],
     "clite_bn_apply": [_V, _I, _V, _V, _V, _V],
     "clite_bn_centered_var": [_I, _V, _V, _I, _I, _V],
-    "clite_bn_bwd_reduce": [_I, _V, _V, _V, _V, _I, _I, _V],
+    "clite_bn_bwd_reduce": [_I, _V, _V, _V, _V, _V, _I, _I, _V],
     "clite_bn_bwd_apply": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V],
     "clite_maxpool3x3s2_fwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_maxpool3x3s2_bwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
@@ -226,8 +226,8 @@ def bn_apply(dt, bn, y, res, out):
     check(lib().clite_bn_apply(C.byref(bn), dt, p(y), p(res), p(out), stream_ptr(y)), "bn_apply")
 
 
-def bn_bwd_reduce(dt, dout, mask, y, dstats, M, Cc):
-    check(lib().clite_bn_bwd_reduce(dt, p(dout), p(mask), p(y), p(dstats), M, Cc, stream_ptr(y)), "bn_bwd_reduce")
+def bn_bwd_reduce(dt, dout, mask, y, stats, dstats, M, Cc):
+    check(lib().clite_bn_bwd_reduce(dt, p(dout), p(mask), p(y), p(stats), p(dstats), M, Cc, stream_ptr(y)), "bn_bwd_reduce")
 
 
 def bn_bwd_apply(dt, bn, dout, mask, y, dstats, dy, dz, dgamma, dbeta):

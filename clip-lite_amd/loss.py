@@ -153,7 +153,7 @@ def mi_block_backward(rt, blk, ctx, dout, dx_residual=None):
     da = _alloc(rt, B, U)
     hip.gemm_nn(dt, dtt, A.w(l2.weight), B, U, U, hip.epilogue(da, U))
     dstats = torch.zeros(2, U, device=rt.device, dtype=torch.float32)
-    hip.bn_bwd_reduce(dt, da, a, z, dstats, B, U)
+    hip.bn_bwd_reduce(dt, da, a, z, stats, dstats, B, U)
     dz = _alloc(rt, B, U)
     desc = hip.bn_desc(B, U, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn)
     hip.bn_bwd_apply(dt, desc, da, a, z, dstats, dz, None, A.g(bn.weight), A.g(bn.bias))

@@ -204,7 +204,7 @@ def _bn_backward(rt, u, dout, mask, N, want_dz=False, train_params=True):
     """BN backward of unit u given dout (gradient w.r.t. the post-BN tensor) and the ReLU mask tensor (or None)."""
     M, Cc = u.y.shape
     dstats = torch.zeros(2, Cc, device=rt.device, dtype=torch.float32)
-    hip.bn_bwd_reduce(rt.dt, dout, mask, u.y, dstats, M, Cc)
+    hip.bn_bwd_reduce(rt.dt, dout, mask, u.y, u.stats, dstats, M, Cc)
     dy = _alloc(rt, M, Cc)
     dz = _alloc(rt, M, Cc) if want_dz else None
     bn = u.bn

@@ -112,7 +112,7 @@ class GradientExchange:
         self.stream = torch.cuda.Stream() if self.on_gpu else None
         self._pending = []      # [lo, hi) regions not yet sent
         self._works = []
-        self._sent = 0
+        self._covered = []     # [lo, hi) regions already handed to RCCL this step
 
     def _send(self, lo, hi):
         buf = self.arena.flat_g[lo:hi]
@@ -122,10 +122,10 @@ class GradientExchange:
                 self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        self._sent += hi - lo
+        self._covered.append((lo, hi))
 
     def region_ready(self, lo, hi):
-        if self.world == 1:
+        if self.world == 1 or hi <= lo:
             return
         # merge with an adjacent pending region when possible
         if self._pending and self._pending[-1][0] == hi:
@@ -139,17 +139,23 @@ class GradientExchange:
             self._send(lo0, hi0)
 
     def finish(self):
-        """Flush what is left (including anything never reported: the whole arena is exchanged exactly once per step)."""
+        """Flush pending regions, then exchange every part of the arena that was never reported, so each element is reduced
+        exactly once per step whatever the executors announced. Returns the factor that turns the SUM into the mean."""
         if self.world == 1:
             return 1.0
         for lo, hi in self._pending:
             self._send(lo, hi)
         self._pending = []
-        if self._sent == 0:
-            self._send(0, self.arena.total)
+        pos = 0
+        for lo, hi in sorted(self._covered):
+            if lo > pos:
+                self._send(pos, lo)
+            pos = max(pos, hi)
+        if pos < self.arena.total:
+            self._send(pos, self.arena.total)
         for w in self._works:
             w.wait()
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.stream)
-        self._works, self._sent = [], 0
+        self._works, self._covered = [], []
         return 1.0 / self.world

@@ -115,8 +115,9 @@ typedef struct clite_bn {
 int clite_bn_centered_var(int dtype, const void* y, float* stats, int M, int C, void* stream);
 /* out = relu?( bn(y) + [res | bn_res(res)] ) */
 int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const void* res, void* out, void* stream);
-/* dstats[0][c] += sum dz, dstats[1][c] += sum dz*y, dz = dout * (mask > 0) (mask NULL: dz = dout). dstats pre-zeroed. */
-int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, float* dstats, int M, int C, void* stream);
+/* dstats[0][c] += sum dz, dstats[1][c] += sum dz*(y - mean_c), dz = dout * (mask > 0) (mask NULL: dz = dout), mean_c = stats[0][c]/M.
+ * dstats pre-zeroed. */
+int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, const float* stats, float* dstats, int M, int C, void* stream);
 /* dy = BN backward of dz through batch statistics; dz (optional) <- masked dout; dgamma/dbeta (optional) += . */
 int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const void* y, const float* dstats,
                        void* dy, void* dz, float* dgamma, float* dbeta, void* stream);

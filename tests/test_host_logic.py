@@ -1,0 +1,137 @@
+"""CPU-side tests of the host layer: the C-ABI library loads and exports every symbol include/clite.h declares (no compute),
+config semantics, schedulers against the reference-generated fixture, checkpoint layout, data contract, and the product's
+refusal to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_c_abi_library_exports_header_symbols():
+    from clip_lite_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "clite.h")).read()
+    declared = sorted(set(re.findall(r"\bint (clite_\w+)\(", hdr)))
+    assert declared == hip.exported_symbols()
+    lib = hip.lib()                     # dlopen + bind every symbol + ABI version check
+    assert lib.clite_abi_version() == 1
+    raw = C.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+
+
+def test_ctypes_structs_match_header_layout():
+    from clip_lite_amd import hip
+    assert C.sizeof(hip.OptimItem) == 24
+    assert C.sizeof(hip.Conv) == 12 * 4
+    assert hip.Epilogue.colsum.offset == C.sizeof(hip.Epilogue) - 8
+    assert hip.Bn.res_stats.offset % 8 == 0 and hip.Bn.centered.offset == hip.Bn.relu.offset + 4
+
+
+def test_no_cpu_path():
+    """The product must fail loudly without a GPU instead of silently computing somewhere else."""
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    m = VLInfoModel(TextEncoder(mode="sbert"), ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "sbert", False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m({"image": torch.zeros(2, 3, 64, 64), "caption_encodings": torch.zeros(2, 768)})
+    assert not any("oracle" in (getattr(mod, "__file__", "") or "") for name, mod in list(__import__("sys").modules.items())
+                   if name.startswith("clip_lite_amd"))
+
+
+def test_state_dict_keys_match_reference_layout():
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    from oracle import ref_model as O
+    m = VLInfoModel(TextEncoder(mode="train_sbert", num_hidden_layers=2), ImageEncoder("resnet50"), JSDInfoMaxLoss(2048, 768, "dot", 0.1, True, True), "train_sbert")
+    o = O.build_oracle_model("resnet50", "train_sbert", 2)
+    sd, so = m.state_dict(), o.state_dict()
+    assert sorted(sd) == sorted(so)
+    assert all(tuple(sd[k].shape) == tuple(so[k].shape) for k in sd)
+    fx = np.load(os.path.join(G, "model_rn18_bert1_b4.npz"))
+    m1 = VLInfoModel(TextEncoder(mode="train_sbert", num_hidden_layers=1), ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert")
+    assert sorted(n for n, _ in m1.named_parameters()) == [str(x) for x in fx["gnames"]]     # names of the reference's own model
+    assert sum(p.numel() for p in m.image_encoder.parameters()) == 23508032
+    d2 = m.image_encoder.detectron2_backbone_state_dict()["model"]
+    assert "stem.conv1.weight" in d2 and "res2.0.conv1.norm.weight" in d2 and "res3.0.shortcut.weight" in d2
+
+
+def test_config_defaults_yaml_overrides_and_freeze(tmp_path):
+    from clip_lite_amd.config import Config
+    c = Config()
+    assert c.OPTIM.CNN_LR == 0.2 and c.MODEL.LOSS.PRIOR_WEIGHT == 0.1 and c.DATA.MAX_CAPTION_LENGTH == 30 and c.OPTIM.LOOKAHEAD.STEPS == 5
+    y = tmp_path / "c.yaml"
+    y.write_text("MODEL:\n  VISUAL:\n    NETWORK_NAME: resnet18\n    FEATURE_SIZE: 512\nOPTIM:\n  BATCH_SIZE: 64\n  LR: 0.01\nRUN_ID: abc\n")
+    c = Config(str(y), ["OPTIM.BATCH_SIZE", "1024", "OPTIM.WARMUP_STEPS", 5])
+    assert c.MODEL.VISUAL.NETWORK_NAME == "resnet18" and c.OPTIM.BATCH_SIZE == 1024 and c.OPTIM.LR == 0.01 and c.OPTIM.WARMUP_STEPS == 5
+    assert c.RUN_ID == "/V?resnet18_T?train_sbert_Ty?dot_Vs?False_Ts?False_N?normal_B?1024_O?sgd_B?1024_D?cosine_Ni?500000_ID?abc"
+    with pytest.raises(AttributeError):
+        c._C.OPTIM.LR = 1.0
+    with pytest.raises(KeyError):
+        Config(None, ["OPTIM.NOPE", 1])
+    with pytest.raises(ValueError):
+        Config(None, ["OPTIM.BATCH_SIZE", "abc"])
+    c.dump(str(tmp_path / "out.yaml"))
+    assert Config(str(tmp_path / "out.yaml")).OPTIM.BATCH_SIZE == 1024
+
+
+def test_schedulers_match_reference_fixture():
+    from clip_lite_amd.optim import lr_scheduler as S
+    fx = np.load(os.path.join(G, "optim.npz"))
+    ts = (0, 1, 9999, 10000, 255000, 499999, 500000)
+    mk = lambda: torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    for name, kw in (("LinearWarmupCosineAnnealingLR", {"min_mult": 0.0}), ("LinearWarmupLinearDecayLR", {}), ("LinearWarmupNoDecayLR", {})):
+        s = getattr(S, name)(mk(), total_steps=500000, warmup_steps=10000, **kw)
+        assert np.allclose([s._lr_multiplier(t) for t in ts], fx["mult_" + name], rtol=1e-12, atol=1e-15)
+    s = S.LinearWarmupMultiStepLR(mk(), total_steps=100, warmup_steps=10, milestones=[30, 60], gamma=0.1)
+    assert np.allclose([s._lr_multiplier(t) for t in (0, 5, 10, 29, 30, 59, 60, 99)], fx["mult_LinearWarmupMultiStepLR"], rtol=1e-12)
+    o = mk()
+    s = S.LinearWarmupCosineAnnealingLR(o, total_steps=20, warmup_steps=4)
+    assert o.param_groups[0]["lr"] == 0.0            # first optimizer step of the reference runs with lr 0
+
+
+def test_batch_contract_and_factories():
+    from clip_lite_amd.config import Config
+    from clip_lite_amd.data import RandomDataset, hash_tokenize
+    from clip_lite_amd.factories import PretrainingDatasetFactory, PretrainingModelFactory
+    ds = RandomDataset(mode="train_sbert", image_size=32, max_caption_length=30, length=10)
+    b = ds.collate_fn([ds[i] for i in range(4)])
+    assert b["image"].shape == (4, 3, 32, 32) and b["image"].dtype == torch.float32
+    assert b["input_ids"].dtype == torch.int64 and b["input_ids"].shape == b["attention_mask"].shape and b["input_ids"].shape[1] <= 30
+    assert (b["input_ids"][:, 0] == 101).all() and ((b["input_ids"] == 0) == (b["attention_mask"] == 0)).all()   # right-padded with pad id 0
+    assert len(hash_tokenize("word " * 100, 30)) == 30
+    c = Config(None, ["MODEL.NAME", "random", "MODEL.TEXTUAL.NAME", "sbert", "MODEL.VISUAL.NETWORK_NAME", "resnet18", "MODEL.VISUAL.FEATURE_SIZE", 512])
+    d = PretrainingDatasetFactory.from_config(c, "train")
+    assert len(d) == 118000 and "caption_encodings" in d.collate_fn([d[0], d[1]])
+    m = PretrainingModelFactory.from_config(c)
+    assert m.mode == "sbert" and sum(p.numel() for p in m.text_encoder.parameters()) == 0
+    assert sum(p.numel() for p in m.parameters()) == 26515379      # RN18 + frozen SBERT + heads
+    ref_json = "/root/reference/data/mock_data.json"
+    if os.path.exists(ref_json):                                    # the reference's own 41-record mock file (build container only)
+        from clip_lite_amd.data import JsonCaptionDataset
+        j = JsonCaptionDataset([ref_json], image_size=16)
+        assert len(j) == 41 and j.collate_fn([j[0], j[1]])["input_ids"].shape[0] == 2
+
+
+def test_checkpoint_manager_layout(tmp_path):
+    from clip_lite_amd.utils.checkpointing import CheckpointManager
+    model = torch.nn.Linear(4, 2)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    cm = CheckpointManager(str(tmp_path), keep_recent=2, model=model, optimizer=opt)
+    for it in (10, 20, 30):
+        cm.step(it)
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["checkpoint_20.pth", "checkpoint_30.pth"]
+    ck = torch.load(tmp_path / "checkpoint_30.pth", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "iteration"} and ck["iteration"] == 30
+    cm.climax_step(40)
+    assert set(torch.load(tmp_path / "checkpoint_40.pth", weights_only=False)) == {"model", "iteration"}
+    model2 = torch.nn.Linear(4, 2)
+    assert CheckpointManager(model=model2, scheduler=None and 0).load(str(tmp_path / "checkpoint_30.pth")) == 30
+    assert torch.equal(model2.weight, model.weight)

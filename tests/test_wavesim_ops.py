@@ -52,10 +52,10 @@ def test_bn_apply_and_backward(dtype, M, Cc, dual):
     outv = val(out, dtype)
     dout, doutb = prep(rng.standard_normal((M, Cc), dtype=np.float32), dtype)
     dstats = np.zeros((2, Cc), np.float32)
-    assert lib().clite_bn_bwd_reduce(dtype, ptr(doutb), ptr(out), ptr(yb), ptr(dstats), M, Cc, None) == 0
+    assert lib().clite_bn_bwd_reduce(dtype, ptr(doutb), ptr(out), ptr(yb), ptr(stats), ptr(dstats), M, Cc, None) == 0
     dz = dout * (outv > 0)
     _close(dstats[0], dz.sum(0), 1e-4)
-    _close(dstats[1], (dz * y).sum(0), 1e-4)
+    _close(dstats[1], (dz * (y - y.mean(0))).sum(0), 1e-4)
     dy = outbuf((M, Cc), dtype); dzb = outbuf((M, Cc), dtype)
     dg = np.ones(Cc, np.float32); db = np.ones(Cc, np.float32)
     assert lib().clite_bn_bwd_apply(C.byref(p), dtype, ptr(doutb), ptr(out), ptr(yb), ptr(dstats), ptr(dy), ptr(dzb), ptr(dg), ptr(db), None) == 0
