@@ -469,7 +469,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, i
   }
 
   if (ep.colsum) {
-    // threads sharing a column chunk are tid, tid+CPRE, ...: fold them through LDS, one atomic per column
+    // threads sharing a column chunk are tid, tid+CPRE, ...: fold them through LDS, one atomic per column. The accumulator
+    // is replicated (workgroup b adds into replica b % R) because thousands of tiles adding to the same few addresses
+    // serialise at the memory side; consumers fold the replicas when they read the statistics.
+    float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
     float* red = (float*)smem;                      // [RPSE][CPRE*16]
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, i
       for (int r = 0; r < RPSE; ++r) s += red[r * (CPRE * 16) + idx];
       int chunk = idx / 16, e = idx % 16;
       int col = n0 + chunk * 8 + (e & 7);
-      if (col < N) atomic_add_f32(ep.colsum + (e >= 8 ? N : 0) + col, s);
+      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
     }
   }
 }

@@ -12,17 +12,24 @@ namespace {
 
 struct BnCoef { float a[8], b[8]; };
 
+// sum of the R partial accumulators of one statistic
+DEV float rsum(const float* p, int replicas, int rstride) {
+  float s = p[0];
+  for (int r = 1; r < replicas; ++r) s += p[(size_t)r * rstride];
+  return s;
+}
+
 // scale/shift of 8 channels from batch statistics (training) or running statistics (eval)
-DEV void bn_coef(const float* stats, const float* gamma, const float* beta, const float* rmean, const float* rvar,
+DEV void bn_coef(const float* stats, int R, int RS, const float* gamma, const float* beta, const float* rmean, const float* rvar,
                  int training, int centered, float inv_count, float eps, int C, int c0, BnCoef& k, float (&mean)[8], float (&var)[8]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     int c = c0 + e;
     if (training) {
-      mean[e] = stats[c] * inv_count;
+      mean[e] = rsum(stats + c, R, RS) * inv_count;
       // single-pass E[x^2]-E[x]^2 (sums from the conv epilogue), or the two-pass sum of squared deviations when a
       // centered pass (clite_bn_centered_var) filled stats[2][C]
-      var[e] = centered ? stats[2 * C + c] * inv_count : fmaxf(stats[C + c] * inv_count - mean[e] * mean[e], 0.f);
+      var[e] = centered ? rsum(stats + 2 * C + c, R, RS) * inv_count : fmaxf(rsum(stats + C + c, R, RS) * inv_count - mean[e] * mean[e], 0.f);
     } else {
       mean[e] = rmean[c];
       var[e] = rvar[c];
@@ -41,10 +48,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, c
   const float inv_count = 1.0f / (float)p.M;
   BnCoef k, kr;
   float mean[8], var[8], mr[8], vr[8];
-  bn_coef(p.stats, p.gamma, p.beta, p.running_mean, p.running_var, p.training, p.centered, inv_count, p.eps, p.C, c0, k, mean, var);
+  bn_coef(p.stats, p.replicas, p.rstride, p.gamma, p.beta, p.running_mean, p.running_var, p.training, p.centered, inv_count, p.eps, p.C, c0, k, mean, var);
   const bool res_affine = res && p.res_gamma;
   if (res_affine)
-    bn_coef(p.res_stats, p.res_gamma, p.res_beta, p.res_running_mean, p.res_running_var, p.training, p.centered, inv_count, p.eps, p.C, c0, kr, mr, vr);
+    bn_coef(p.res_stats, p.replicas, p.rstride, p.res_gamma, p.res_beta, p.res_running_mean, p.res_running_var, p.training, p.centered, inv_count, p.eps, p.C, c0, kr, mr, vr);
   if (blockIdx.x == 0 && r0 == 0 && p.training && p.update_running) {
     float unb = p.M > 1 ? (float)p.M / (float)(p.M - 1) : 1.f;
 #pragma unroll
@@ -87,14 +94,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, c
 // dstats[0][c] += sum dz, dstats[1][c] += sum dz*(y - mean_c), with dz = dout * (mask > 0) and mean_c = stats[0][c]/M.
 // Centering y here (instead of forming sum dz*y - mean*sum dz afterwards) avoids cancellation on channels with |mean| >> std.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const T* mask, const T* y, const float* stats, float* dstats, int M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const T* mask, const T* y, const float* stats, float* dstats, int R, int RS, int M, int C, int rows_per_block) {
   __shared__ float red[256 * 16];
   const int CPR = C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
   float s1[8], s2[8], mean[8];
   zero8(s1); zero8(s2);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) mean[e] = stats[c0 + e] / (float)M;
+  for (int e = 0; e < 8; ++e) mean[e] = rsum(stats + c0 + e, R, RS) / (float)M;
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > M) row_end = M;
   for (int r = row_begin + r0; r < row_end; r += RPS) {
@@ -118,21 +125,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const
     for (int e = 0; e < 16; ++e) {
       float s = 0.f;
       for (int r = 0; r < RPS; ++r) s += red[(r * CPR + cc) * 16 + e];
-      atomic_add_f32(dstats + (e >= 8 ? C : 0) + c0 + (e & 7), s);
+      atomic_add_f32(dstats + (size_t)(blockIdx.x % R) * RS + (e >= 8 ? C : 0) + c0 + (e & 7), s);
     }
   }
 }
 
 // second pass of a two-pass variance: stats[2][c] += sum (y - mean_c)^2 with mean_c = stats[0][c] / M
 template <typename T>
-__global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* y, float* stats, int M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* y, float* stats, int R, int RS, int M, int C, int rows_per_block) {
   __shared__ float red[256 * 8];
   const int CPR = C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
   float mean[8], s[8];
   const float inv_count = 1.0f / (float)M;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { mean[e] = stats[c0 + e] * inv_count; s[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { mean[e] = rsum(stats + c0 + e, R, RS) * inv_count; s[e] = 0.f; }
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > M) row_end = M;
   for (int r = row_begin + r0; r < row_end; r += RPS) {
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* y, float*
     for (int e = 0; e < 8; ++e) {
       float t = 0.f;
       for (int r = 0; r < RPS; ++r) t += red[(r * CPR + cc) * 8 + e];
-      atomic_add_f32(stats + 2 * C + c0 + e, t);
+      atomic_add_f32(stats + (size_t)(blockIdx.x % R) * RS + 2 * C + c0 + e, t);
     }
   }
 }
@@ -164,10 +171,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     int c = c0 + e;
-    mean[e] = p.stats[c] * inv_count;
-    float var = p.centered ? p.stats[2 * p.C + c] * inv_count : fmaxf(p.stats[p.C + c] * inv_count - mean[e] * mean[e], 0.f);
+    mean[e] = rsum(p.stats + c, p.replicas, p.rstride) * inv_count;
+    float var = p.centered ? rsum(p.stats + 2 * p.C + c, p.replicas, p.rstride) * inv_count
+                           : fmaxf(rsum(p.stats + p.C + c, p.replicas, p.rstride) * inv_count - mean[e] * mean[e], 0.f);
     rstd[e] = rsqrtf(var + p.eps);
-    float S1 = dstats[c], S2 = dstats[p.C + c];
+    float S1 = rsum(dstats + c, p.replicas, p.rstride), S2 = rsum(dstats + p.C + c, p.replicas, p.rstride);
     float G = rstd[e] * S2;
     float a = p.gamma[c] * rstd[e];
     // dy = a*(dz - S1/M - (y-mean)*rstd*G/M)
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
 int bn_grid(int M, int C, int* rows_per_block) {
   int CPR = C / 8, RPS = 256 / CPR;
   int sweeps = (M + RPS - 1) / RPS;
-  int grid = sweeps < 2048 ? sweeps : 2048;
+  int grid = sweeps < 1024 ? sweeps : 1024;
   int spb = (sweeps + grid - 1) / grid;
   *rows_per_block = spb * RPS;
   return (M + *rows_per_block - 1) / *rows_per_block;
@@ -351,6 +359,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int
   if (row_end > M) row_end = M;
   float acc[8];
   zero8(acc);
+#pragma unroll 4
   for (int r = row_begin; r < row_end; ++r) {
     float v[8];
     load8(x + (size_t)r * N + chunk * 8, v);
@@ -372,7 +381,7 @@ int ew_grid(size_t total) {
   if ((dtype) == CLITE_BF16) { CALL_BF16; } else if ((dtype) == CLITE_F32) { CALL_F32; } else return -1;
 
 extern "C" int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const void* res, void* out, void* stream) {
-  if (!p || !bn_ok(p->M, p->C) || !y || !out) return -1;
+  if (!p || !bn_ok(p->M, p->C) || !y || !out || p->replicas < 1) return -1;
   int rpb;
   int grid = bn_grid(p->M, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
@@ -382,31 +391,32 @@ extern "C" int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const
   return (int)hipGetLastError();
 }
 
-extern "C" int clite_bn_centered_var(int dtype, const void* y, float* stats, int M, int C, void* stream) {
-  if (!bn_ok(M, C) || !y || !stats) return -1;
+extern "C" int clite_bn_centered_var(int dtype, const void* y, float* stats, int replicas, int rstride, int M, int C, void* stream) {
+  if (!bn_ok(M, C) || !y || !stats || replicas < 1) return -1;
   int rpb;
   int grid = bn_grid(M, C, &rpb);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(bn_centered_var_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, stats, M, C, rpb),
-           hipLaunchKernelGGL(bn_centered_var_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, stats, M, C, rpb));
+           hipLaunchKernelGGL(bn_centered_var_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, stats, replicas, rstride, M, C, rpb),
+           hipLaunchKernelGGL(bn_centered_var_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y, stats, replicas, rstride, M, C, rpb));
   return (int)hipGetLastError();
 }
 
-extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, const float* stats, float* dstats, int M, int C, void* stream) {
-  if (!bn_ok(M, C) || !dout || !y || !stats || !dstats) return -1;
+extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, const float* stats, float* dstats, int replicas, int rstride,
+                                   int M, int C, void* stream) {
+  if (!bn_ok(M, C) || !dout || !y || !stats || !dstats || replicas < 1) return -1;
   int rpb;
   int grid = bn_grid(M, C, &rpb);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, stats, dstats, M, C, rpb),
-           hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, stats, dstats, M, C, rpb));
+           hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, stats, dstats, replicas, rstride, M, C, rpb),
+           hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, stats, dstats, replicas, rstride, M, C, rpb));
   return (int)hipGetLastError();
 }
 
 extern "C" int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const void* y, const float* dstats,
                                   void* dy, void* dz, float* dgamma, float* dbeta, void* stream) {
-  if (!p || !bn_ok(p->M, p->C) || !dout || !y || !dstats || !dy) return -1;
+  if (!p || !bn_ok(p->M, p->C) || !dout || !y || !dstats || !dy || p->replicas < 1) return -1;
   int rpb;
   int grid = bn_grid(p->M, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
@@ -471,8 +481,8 @@ extern "C" int clite_image_to_nhwc4(int dtype, const float* img, void* out, int 
 extern "C" int clite_colsum(int dtype, const void* x, float* out, int M, int N, void* stream) {
   if (M <= 0 || N <= 0 || N % 8) return -1;
   int gx = (N / 8 + 255) / 256;
-  int slabs = 512 / gx;
-  if (slabs < 1) slabs = 1;
+  int slabs = 96 / gx;            // every slab ends in one float atomic per column: keep same-address adds to a few dozen
+  if (slabs < 16) slabs = 16;
   if (slabs > M) slabs = M;
   int rpb = (M + slabs - 1) / slabs;
   slabs = (M + rpb - 1) / rpb;

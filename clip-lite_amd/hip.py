@@ -25,6 +25,7 @@ class Epilogue(C.Structure):
         ("alpha", C.c_float), ("bias", C.c_void_p), ("act", C.c_int32), ("preact", C.c_void_p),
         ("dact_aux", C.c_void_p), ("dact", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
         ("drop_site", C.c_uint32), ("residual", C.c_void_p), ("colsum", C.c_void_p),
+        ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32),
     ]
 
 
@@ -36,7 +37,7 @@ class Bn(C.Structure):
     _fields_ = [
         ("M", C.c_int32), ("C", C.c_int32), ("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("training", C.c_int32),
-        ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32), ("centered", C.c_int32),
+        ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32), ("replicas", C.c_int32), ("rstride", C.c_int32), ("centered", C.c_int32),
         ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
         ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p),
     ]
@@ -60,8 +61,8 @@ _SIGNATURES = {
     "clite_stem_pack": [_V, _V, _I, _V],
     "clite_stem_unpack_grad": [_V, _V, _V],
     "clite_bn_apply": [_V, _I, _V, _V, _V, _V],
-    "clite_bn_centered_var": [_I, _V, _V, _I, _I, _V],
-    "clite_bn_bwd_reduce": [_I, _V, _V, _V, _V, _V, _I, _I, _V],
+    "clite_bn_centered_var": [_I, _V, _V, _I, _I, _I, _I, _V],
+    "clite_bn_bwd_reduce": [_I, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_bn_bwd_apply": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V],
     "clite_maxpool3x3s2_fwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_maxpool3x3s2_bwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
@@ -138,6 +139,18 @@ def check(rc, what):
         raise RuntimeError(f"clip_lite_amd: {what} failed with code {rc}")
 
 
+class Stats:
+    """Replicated per-channel accumulator [R][3][C] f32 (rows: sum, sum of squares, centered sum of squares), zero-initialised."""
+    __slots__ = ("t", "R", "C")
+
+    def __init__(self, t, R, Cc):
+        self.t, self.R, self.C = t, R, Cc
+
+    @property
+    def rstride(self):
+        return 3 * self.C
+
+
 def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
              drop=None, residual=None, colsum=None, out_f32=None):
     ep = Epilogue()
@@ -154,7 +167,10 @@ def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, pr
     if drop is not None and drop[0] > 0.0:
         ep.drop_p, ep.drop_seed, ep.drop_site = drop
     ep.residual = p(residual)
-    ep.colsum = p(colsum)
+    if isinstance(colsum, Stats):
+        ep.colsum, ep.colsum_replicas, ep.colsum_stride = p(colsum.t), colsum.R, colsum.rstride
+    else:
+        ep.colsum = p(colsum)
     return ep
 
 
@@ -207,19 +223,23 @@ def stem_unpack_grad(dwv, dw):
 
 # ------------------------------------------------------------------------------------------------ BN / pools
 def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, eps, relu, res_bn=None, centered=False):
+    """stats: hip.Stats (training) or None (eval: running statistics)."""
     b = Bn()
     b.M, b.C = M, Cc
     b.centered = int(centered)
-    b.stats, b.gamma, b.beta, b.running_mean, b.running_var = p(stats), p(gamma), p(beta), p(rmean), p(rvar)
+    b.replicas, b.rstride = (stats.R, stats.rstride) if stats is not None else (1, 0)
+    b.stats = p(stats.t) if stats is not None else None
+    b.gamma, b.beta, b.running_mean, b.running_var = p(gamma), p(beta), p(rmean), p(rvar)
     b.training, b.update_running, b.momentum, b.eps, b.relu = int(training), int(update), momentum, eps, int(relu)
     if res_bn is not None:
         rs, rg, rb, rrm, rrv = res_bn
-        b.res_stats, b.res_gamma, b.res_beta, b.res_running_mean, b.res_running_var = p(rs), p(rg), p(rb), p(rrm), p(rrv)
+        b.res_stats = p(rs.t) if rs is not None else None
+        b.res_gamma, b.res_beta, b.res_running_mean, b.res_running_var = p(rg), p(rb), p(rrm), p(rrv)
     return b
 
 
 def bn_centered_var(dt, y, stats, M, Cc):
-    check(lib().clite_bn_centered_var(dt, p(y), p(stats), M, Cc, stream_ptr(y)), "bn_centered_var")
+    check(lib().clite_bn_centered_var(dt, p(y), p(stats.t), stats.R, stats.rstride, M, Cc, stream_ptr(y)), "bn_centered_var")
 
 
 def bn_apply(dt, bn, y, res, out):
@@ -227,11 +247,12 @@ def bn_apply(dt, bn, y, res, out):
 
 
 def bn_bwd_reduce(dt, dout, mask, y, stats, dstats, M, Cc):
-    check(lib().clite_bn_bwd_reduce(dt, p(dout), p(mask), p(y), p(stats), p(dstats), M, Cc, stream_ptr(y)), "bn_bwd_reduce")
+    assert stats.R == dstats.R
+    check(lib().clite_bn_bwd_reduce(dt, p(dout), p(mask), p(y), p(stats.t), p(dstats.t), stats.R, stats.rstride, M, Cc, stream_ptr(y)), "bn_bwd_reduce")
 
 
 def bn_bwd_apply(dt, bn, dout, mask, y, dstats, dy, dz, dgamma, dbeta):
-    check(lib().clite_bn_bwd_apply(C.byref(bn), dt, p(dout), p(mask), p(y), p(dstats), p(dy), p(dz), p(dgamma), p(dbeta), stream_ptr(y)),
+    check(lib().clite_bn_bwd_apply(C.byref(bn), dt, p(dout), p(mask), p(y), p(dstats.t), p(dy), p(dz), p(dgamma), p(dbeta), stream_ptr(y)),
           "bn_bwd_apply")
 
 

@@ -129,7 +129,7 @@ def _conv(rt, x, N, H, W, conv, training):
     cv = hip.conv_desc(rt.dt, N, H, W, conv.in_channels, conv.out_channels, conv.k, conv.k, conv.stride, conv.pad)
     M = N * cv.Ho * cv.Wo
     y = _alloc(rt, M, conv.out_channels)
-    stats = torch.zeros(3, conv.out_channels, device=rt.device, dtype=torch.float32) if training else None
+    stats = rt.new_stats(conv.out_channels) if training else None
     hip.conv_fwd(x, rt.arena.w(conv.weight), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
     if training and rt.precise_bn:
         hip.bn_centered_var(rt.dt, y, stats, M, conv.out_channels)
@@ -152,7 +152,7 @@ def resnet_forward(rt, net, image, training):
     wv = _alloc(rt, 64, 7, 8, 4)
     hip.stem_pack(dt, rt.arena.w32(net.conv1.weight), wv)
     y0 = _alloc(rt, N * Ho * Wo, 64)
-    st0 = torch.zeros(3, 64, device=rt.device, dtype=torch.float32) if training else None
+    st0 = rt.new_stats(64) if training else None
     hip.stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, hip.epilogue(y0, 64, colsum=st0))
     if training and rt.precise_bn:
         hip.bn_centered_var(dt, y0, st0, N * Ho * Wo, 64)
@@ -203,7 +203,7 @@ def resnet_forward(rt, net, image, training):
 def _bn_backward(rt, u, dout, mask, N, want_dz=False, train_params=True):
     """BN backward of unit u given dout (gradient w.r.t. the post-BN tensor) and the ReLU mask tensor (or None)."""
     M, Cc = u.y.shape
-    dstats = torch.zeros(2, Cc, device=rt.device, dtype=torch.float32)
+    dstats = rt.new_stats(Cc)
     hip.bn_bwd_reduce(rt.dt, dout, mask, u.y, u.stats, dstats, M, Cc)
     dy = _alloc(rt, M, Cc)
     dz = _alloc(rt, M, Cc) if want_dz else None

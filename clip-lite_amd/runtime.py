@@ -119,6 +119,27 @@ class StepState:
         return self._site
 
 
+class ZeroPool:
+    """Bump allocator over pre-zeroed f32 chunks: the many small accumulators of a step (BatchNorm statistics, loss sums) come
+    out of a few large memsets instead of one tiny fill kernel each. A chunk is handed out once and never reused."""
+
+    def __init__(self, device, chunk=4 * 1024 * 1024):
+        self.device, self.chunk = device, chunk
+        self.buf, self.pos = None, 0
+
+    def take(self, n):
+        n = (n + 63) // 64 * 64
+        if self.buf is None or self.pos + n > self.buf.numel():
+            self.buf = torch.zeros(max(self.chunk, n), device=self.device, dtype=torch.float32)
+            self.pos = 0
+        out = self.buf[self.pos:self.pos + n]
+        self.pos += n
+        return out
+
+
+STAT_REPLICAS = 8
+
+
 class DeviceRuntime:
     """Everything a kernel-driving executor needs: device, compute dtype, the parameter arena, dropout seeding and the
     BatchNorm `num_batches_tracked` counters (kept in one int64 tensor per owner so a step bumps them with one add)."""
@@ -133,6 +154,7 @@ class DeviceRuntime:
         self.precise_bn = not lowp
         self.arena = Arena(model.named_parameters(), self.device, lowp, contiguous_groups)
         self.base_seed = int(seed)
+        self.zpool = ZeroPool(self.device)
         self.steps = 0
         # flatten num_batches_tracked buffers per top-level owner
         self.counters = {}
@@ -148,6 +170,10 @@ class DeviceRuntime:
             self.counters[owner] = flat
         for mod in model.modules():
             mod._clite_rt = self
+
+    def new_stats(self, Cc):
+        """Zeroed replicated accumulator for per-channel statistics of a [rows][Cc] tensor."""
+        return hip.Stats(self.zpool.take(STAT_REPLICAS * 3 * Cc), STAT_REPLICAS, Cc)
 
     def bump_counters(self, owner, n=1):
         if owner in self.counters:

@@ -50,6 +50,8 @@ typedef struct clite_epilogue {
   uint32_t drop_site;
   const void* residual; /* [M][ldc] in the call's dtype, or NULL */
   float* colsum;        /* f32 [2][N] or NULL */
+  int32_t colsum_replicas;  /* R > 1: workgroup b accumulates into colsum + (b % R) * colsum_stride (spreads same-address atomics) */
+  int32_t colsum_stride;    /* elements between replicas */
 } clite_epilogue;
 
 /* NHWC convolution problem. x: [N][H][W][C], w: [K][R][S][C], y: [N][Ho][Wo][K], all of `dtype`. */
@@ -101,6 +103,8 @@ typedef struct clite_bn {
   int32_t update_running;    /* 1: workgroup 0 updates running_* with `momentum` */
   float momentum, eps;
   int32_t relu;              /* apply ReLU at the end */
+  int32_t replicas;          /* R >= 1: `stats` (and res_stats) are R partial accumulators `rstride` elements apart; readers sum them */
+  int32_t rstride;
   int32_t centered;          /* 1: variance = stats[2][c] / M (two-pass, from clite_bn_centered_var) instead of E[x^2]-E[x]^2 */
   /* optional second BN applied to the residual operand (the 1x1/stride downsample branch of a block) */
   const float* res_stats;
@@ -112,12 +116,13 @@ typedef struct clite_bn {
 
 /* Second pass of a two-pass variance (used by the exact-f32 parity mode): stats[2][c] += sum_m (y[m][c] - stats[0][c]/M)^2;
  * stats[2][*] must be zero on entry. */
-int clite_bn_centered_var(int dtype, const void* y, float* stats, int M, int C, void* stream);
+int clite_bn_centered_var(int dtype, const void* y, float* stats, int replicas, int rstride, int M, int C, void* stream);
 /* out = relu?( bn(y) + [res | bn_res(res)] ) */
 int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const void* res, void* out, void* stream);
 /* dstats[0][c] += sum dz, dstats[1][c] += sum dz*(y - mean_c), dz = dout * (mask > 0) (mask NULL: dz = dout), mean_c = stats[0][c]/M.
  * dstats pre-zeroed. */
-int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, const float* stats, float* dstats, int M, int C, void* stream);
+int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, const float* stats, float* dstats, int replicas, int rstride,
+                        int M, int C, void* stream);   /* stats and dstats are both replicated (R, rstride) */
 /* dy = BN backward of dz through batch statistics; dz (optional) <- masked dout; dgamma/dbeta (optional) += . */
 int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const void* y, const float* dstats,
                        void* dy, void* dz, float* dgamma, float* dbeta, void* stream);

@@ -25,12 +25,26 @@ def test_c_abi_library_exports_header_symbols():
         assert hasattr(raw, name), name
 
 
-def test_ctypes_structs_match_header_layout():
+def test_ctypes_structs_match_header_layout(tmp_path):
+    """sizeof / offsetof of every struct in include/clite.h as gcc lays them out == the ctypes mirrors in clip_lite_amd/hip.py."""
+    import subprocess
     from clip_lite_amd import hip
-    assert C.sizeof(hip.OptimItem) == 24
-    assert C.sizeof(hip.Conv) == 12 * 4
-    assert hip.Epilogue.colsum.offset == C.sizeof(hip.Epilogue) - 8
-    assert hip.Bn.res_stats.offset % 8 == 0 and hip.Bn.centered.offset == hip.Bn.relu.offset + 4
+    structs = {"clite_epilogue": hip.Epilogue, "clite_conv": hip.Conv, "clite_bn": hip.Bn, "clite_optim_item": hip.OptimItem}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "clite.h"', "int main(void) {"]
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
 
 
 def test_no_cpu_path():

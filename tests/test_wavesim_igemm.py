@@ -23,8 +23,8 @@ def _close(got, ref, rel=2e-3):
     assert np.abs(got - ref).max() <= rel * max(np.abs(ref).max(), 1e-6)
 
 
-@pytest.mark.parametrize("dtype", [BF16, F32])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 104), (300, 64, 32), (70, 1000, 200)])
+@pytest.mark.parametrize("dtype,M,N,K", [(BF16, 128, 128, 64), (BF16, 200, 136, 104), (BF16, 300, 64, 32), (BF16, 70, 1000, 200),
+                                          (F32, 200, 136, 104), (F32, 300, 64, 32)])
 def test_gemm_nt_epilogue(dtype, M, N, K):
     rng = np.random.default_rng(M + N)
     A, Ab = _prep(rng.standard_normal((M, K), dtype=np.float32), dtype)
@@ -42,8 +42,7 @@ def test_gemm_nt_epilogue(dtype, M, N, K):
     _close(from_bf16(pre) if dtype == BF16 else pre, z, 6e-3)
 
 
-@pytest.mark.parametrize("dtype", [BF16, F32])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 104), (300, 64, 40)])
+@pytest.mark.parametrize("dtype,M,N,K", [(BF16, 128, 128, 64), (BF16, 200, 136, 104), (BF16, 300, 64, 40), (F32, 200, 136, 104), (F32, 300, 64, 40)])
 def test_gemm_nn_dact(dtype, M, N, K):
     rng = np.random.default_rng(M + K)
     A, Ab = _prep(rng.standard_normal((M, K), dtype=np.float32), dtype)
@@ -55,8 +54,7 @@ def test_gemm_nn_dact(dtype, M, N, K):
     _close(out, (A @ B) * (aux > 0))
 
 
-@pytest.mark.parametrize("dtype", [BF16, F32])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 136, 300), (256, 8, 1000)])
+@pytest.mark.parametrize("dtype,M,N,K", [(BF16, 128, 128, 64), (BF16, 72, 136, 300), (BF16, 256, 8, 1000), (F32, 72, 136, 300)])
 def test_gemm_tn_atomic(dtype, M, N, K):
     rng = np.random.default_rng(M + K)
     A, Ab = _prep(rng.standard_normal((K, M), dtype=np.float32), dtype)
@@ -110,8 +108,7 @@ CASES = [(2, 8, 8, 32, 64, 3, 3, 1, 1), (2, 9, 7, 64, 32, 3, 3, 2, 1), (3, 6, 6,
          (2, 8, 8, 32, 64, 1, 1, 2, 0), (1, 10, 10, 32, 160, 3, 3, 1, 1)]
 
 
-@pytest.mark.parametrize("dtype", [BF16, F32])
-@pytest.mark.parametrize("N,H,W,Cc,K,R,S,st,pad", CASES)
+@pytest.mark.parametrize("dtype,N,H,W,Cc,K,R,S,st,pad", [(BF16,) + c for c in CASES] + [(F32,) + CASES[1], (F32,) + CASES[3]])
 def test_conv_fwd_dgrad_wgrad(dtype, N, H, W, Cc, K, R, S, st, pad):
     rng = np.random.default_rng(H * W + K)
     Ho = (H + 2 * pad - R) // st + 1
@@ -121,9 +118,13 @@ def test_conv_fwd_dgrad_wgrad(dtype, N, H, W, Cc, K, R, S, st, pad):
     w, wb = _prep(rng.standard_normal((K, R, S, Cc), dtype=np.float32) * 0.2, dtype)
     dy, dyb = _prep(rng.standard_normal((N, Ho, Wo, K), dtype=np.float32), dtype)
     y = np.zeros((N, Ho, Wo, K), np.float32)
-    cs = np.zeros((2, K), np.float32)
-    assert lib().clite_conv_fwd(ptr(xb), ptr(wb), C.byref(cv), C.byref(make_ep(y, K, out_f32=True, colsum=cs)), None) == 0
+    csr = np.zeros((4, 3, K), np.float32)          # 4 replicated accumulators, stride 3*K
+    ep = make_ep(y, K, out_f32=True, colsum=csr)
+    ep.colsum_replicas, ep.colsum_stride = 4, 3 * K
+    assert lib().clite_conv_fwd(ptr(xb), ptr(wb), C.byref(cv), C.byref(ep), None) == 0
     ref = conv_ref(x, w, st, pad)
+    cs = csr.sum(0)
+    assert not csr[:, 2].any()
     _close(y, ref)
     _close(cs[0], ref.reshape(-1, K).sum(0))
     _close(cs[1], (ref.reshape(-1, K) ** 2).sum(0))

@@ -27,11 +27,16 @@ def test_bn_apply_and_backward(dtype, M, Cc, dual):
     beta = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
     g2 = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
     b2 = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
-    stats = np.stack([y.sum(0), (y * y).sum(0)]).astype(np.float32)
-    rstats = np.stack([r.sum(0), (r * r).sum(0)]).astype(np.float32)
+    R = 3                                   # replicated accumulators: split the true sums unevenly over R partials
+    def rep(v):
+        parts = np.zeros((R, 3, Cc), np.float32)
+        parts[0, :2] = 0.5 * v; parts[1, :2] = 0.3 * v; parts[2, :2] = v - parts[0, :2] - parts[1, :2]
+        return parts
+    stats = rep(np.stack([y.sum(0), (y * y).sum(0)]).astype(np.float32))
+    rstats = rep(np.stack([r.sum(0), (r * r).sum(0)]).astype(np.float32))
     rm = np.zeros(Cc, np.float32); rv = np.ones(Cc, np.float32)
     rm2 = np.zeros(Cc, np.float32); rv2 = np.ones(Cc, np.float32)
-    p = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 1, 0.1, 1e-5, 1, 0,
+    p = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 1, 0.1, 1e-5, 1, R, 3 * Cc, 0,
            ptr(rstats) if dual else None, ptr(g2) if dual else None, ptr(b2) if dual else None,
            ptr(rm2) if dual else None, ptr(rv2) if dual else None)
     out = outbuf((M, Cc), dtype)
@@ -51,11 +56,20 @@ def test_bn_apply_and_backward(dtype, M, Cc, dual):
     # backward of the main branch: dz = dout * (out > 0); dy = gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat))
     outv = val(out, dtype)
     dout, doutb = prep(rng.standard_normal((M, Cc), dtype=np.float32), dtype)
-    dstats = np.zeros((2, Cc), np.float32)
-    assert lib().clite_bn_bwd_reduce(dtype, ptr(doutb), ptr(out), ptr(yb), ptr(stats), ptr(dstats), M, Cc, None) == 0
+    dstats = np.zeros((R, 3, Cc), np.float32)
+    assert lib().clite_bn_bwd_reduce(dtype, ptr(doutb), ptr(out), ptr(yb), ptr(stats), ptr(dstats), R, 3 * Cc, M, Cc, None) == 0
     dz = dout * (outv > 0)
-    _close(dstats[0], dz.sum(0), 1e-4)
-    _close(dstats[1], (dz * (y - y.mean(0))).sum(0), 1e-4)
+    _close(dstats.sum(0)[0], dz.sum(0), 1e-4)
+    _close(dstats.sum(0)[1], (dz * (y - y.mean(0))).sum(0), 1e-4)
+    # two-pass variance: the centered pass fills row 2; a BN apply with centered=1 must give the same output
+    assert lib().clite_bn_centered_var(dtype, ptr(yb), ptr(stats), R, 3 * Cc, M, Cc, None) == 0
+    _close(stats.sum(0)[2], ((y - y.mean(0)) ** 2).sum(0), 1e-4)
+    pc = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 0, 0.1, 1e-5, 1, R, 3 * Cc, 1,
+            ptr(rstats) if dual else None, ptr(g2) if dual else None, ptr(b2) if dual else None, ptr(rm2) if dual else None, ptr(rv2) if dual else None)
+    if not dual:
+        outc = outbuf((M, Cc), dtype)
+        assert lib().clite_bn_apply(C.byref(pc), dtype, ptr(yb), ptr(rb), ptr(outc), None) == 0
+        _close(val(outc, dtype), ref, _tol(dtype))
     dy = outbuf((M, Cc), dtype); dzb = outbuf((M, Cc), dtype)
     dg = np.ones(Cc, np.float32); db = np.ones(Cc, np.float32)
     assert lib().clite_bn_bwd_apply(C.byref(p), dtype, ptr(doutb), ptr(out), ptr(yb), ptr(dstats), ptr(dy), ptr(dzb), ptr(dg), ptr(db), None) == 0
