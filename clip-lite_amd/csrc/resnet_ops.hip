@@ -36,7 +36,7 @@ DEV void bn_coef(const float* stats, int R, int RS, const float* gamma, const fl
     }
     float rstd = rsqrtf(var[e] + eps);
     k.a[e] = gamma[c] * rstd;
-    k.b[e] = beta[c] - mean[e] * k.a[e];
+    k.b[e] = beta[c];           // applied as (y - mean)*a + b: folding mean into the shift cancels badly when |mean| >> std
   }
 }
 
@@ -71,13 +71,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, c
     float v[8];
     load8(y + idx, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = v[e] * k.a[e] + k.b[e];
+    for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[e]) * k.a[e] + k.b[e];
     if (res) {
       float rv[8];
       load8(res + idx, rv);
       if (res_affine) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e] * kr.a[e] + kr.b[e];
+        for (int e = 0; e < 8; ++e) v[e] += (rv[e] - mr[e]) * kr.a[e] + kr.b[e];
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
   const int CPR = p.C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
   const float inv_count = 1.0f / (float)p.M;
-  float mean[8], rstd[8], ka[8], kb[8], kc[8];   // dy = ka*dz + kb + kc*y
+  float mean[8], rstd[8], ka[8], kb[8], kc[8];   // dy = ka*dz + kb + kc*(y - mean)
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     int c = c0 + e;
@@ -178,10 +178,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
     float S1 = rsum(dstats + c, p.replicas, p.rstride), S2 = rsum(dstats + p.C + c, p.replicas, p.rstride);
     float G = rstd[e] * S2;
     float a = p.gamma[c] * rstd[e];
-    // dy = a*(dz - S1/M - (y-mean)*rstd*G/M)
+    // dy = a*(dz - S1/M - (y-mean)*rstd*G/M); (y - mean) is formed explicitly: folding mean into kb cancels badly when |mean| >> std
     ka[e] = a;
     kc[e] = -a * rstd[e] * G * inv_count;
-    kb[e] = -a * S1 * inv_count - kc[e] * mean[e];
+    kb[e] = -a * S1 * inv_count;
     if (blockIdx.x == 0 && r0 == 0) {
       if (dgamma) dgamma[c] += G;
       if (dbeta) dbeta[c] += S1;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
     }
     if (dz_out) store8(dz_out + idx, d);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) d[e] = ka[e] * d[e] + kb[e] + kc[e] * yv[e];
+    for (int e = 0; e < 8; ++e) d[e] = ka[e] * d[e] + kb[e] + kc[e] * (yv[e] - mean[e]);
     store8(dy + idx, d);
   }
 }

@@ -1,14 +1,13 @@
-"""GPU parity of the implicit-GEMM engine (through the C ABI) against torch fp32 references on the same
-bf16-rounded inputs. Tolerance: the kernel accumulates in fp32 from exact bf16 products, so against an fp32
-reference computed from the same bf16 inputs the error is summation-order only: <= 2e-3 relative to max|ref| for
-fp32 outputs; bf16 outputs add one rounding (2^-8 relative)."""
-import ctypes as C
-
+"""GPU parity of the implicit-GEMM engine (through the C ABI) against torch fp32 references on the same inputs, for the bf16
+MFMA path and the exact-f32 MFMA path. Tolerance: accumulation is fp32 in both, so against an fp32 reference computed from the
+same (bf16-rounded) inputs the error is summation order only: <= 2e-3 of max|ref| for fp32 outputs; bf16 outputs add one
+rounding (2^-8 relative)."""
 import pytest
 import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+BF16, F32 = 0, 1
 
 
 def _hip():
@@ -20,43 +19,49 @@ def _rel(got, ref):
     return ((got.float() - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
 
 
+def _t(shape, g, dt, scale=1.0):
+    x = torch.randn(*shape, device="cuda", generator=g) * scale
+    return x.bfloat16() if dt == BF16 else x
+
+
+@pytest.mark.parametrize("dt", [BF16, F32])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 104), (300, 64, 32), (70, 1000, 200), (3840, 768, 768), (128, 2048, 2048)])
-def test_gemm_nt_bias_relu(M, N, K):
+def test_gemm_nt_bias_relu(dt, M, N, K):
     hip = _hip()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    B = torch.randn(N, K, device="cuda", generator=g).bfloat16()
+    A, B = _t((M, K), g, dt), _t((N, K), g, dt)
     bias = torch.randn(N, device="cuda", generator=g)
-    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    ep = hip.epilogue(out, N, bias=bias, act=hip.ACT_RELU, preact=pre)
-    hip.check(hip.lib().clite_gemm_nt(hip.p(A), hip.p(B), M, N, K, C.byref(ep), hip.stream_ptr()), "gemm_nt")
+    out, pre = torch.empty_like(A[:, :1].expand(M, N).contiguous()), torch.empty(M, N, device="cuda", dtype=A.dtype)
+    hip.gemm_nt(dt, A, B, M, N, K, hip.epilogue(out, N, bias=bias, act=hip.ACT_RELU, preact=pre))
     ref = A.float() @ B.float().t() + bias
-    assert _rel(pre, ref) < 6e-3
-    assert _rel(out, ref.relu()) < 6e-3
+    tol = 6e-3 if dt == BF16 else 1e-4
+    assert _rel(pre, ref) < tol and _rel(out, ref.relu()) < tol
 
 
+@pytest.mark.parametrize("dt", [BF16, F32])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 104), (300, 64, 40), (3840, 768, 3072)])
-def test_gemm_nn(M, N, K):
+def test_gemm_nn_and_strided_rows(dt, M, N, K):
     hip = _hip()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    B = torch.randn(K, N, device="cuda", generator=g).bfloat16()
+    A, B = _t((M, K), g, dt), _t((K, N), g, dt)
     out = torch.empty(M, N, device="cuda", dtype=torch.float32)
-    ep = hip.epilogue(out, N)
-    hip.check(hip.lib().clite_gemm_nn(hip.p(A), hip.p(B), M, N, K, C.byref(ep), hip.stream_ptr()), "gemm_nn")
+    hip.gemm_nn(dt, A, B, M, N, K, hip.epilogue(out, N))
     assert _rel(out, A.float() @ B.float()) < 2e-3
+    # every 3rd row of A through lda (BERT pooler reads h[:, 0] this way), output scattered through ldc
+    Ms = M // 3
+    out2 = torch.zeros(Ms, 2 * N, device="cuda", dtype=torch.float32)
+    hip.gemm_nn(dt, A, B, Ms, N, K, hip.epilogue(out2, 2 * N), lda=3 * K)
+    assert _rel(out2[:, :N], A[::3][:Ms].float() @ B.float()) < 2e-3 and not out2[:, N:].any()
 
 
+@pytest.mark.parametrize("dt", [BF16, F32])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (72, 136, 300), (256, 8, 1000), (768, 3072, 3840)])
-def test_gemm_tn_atomic(M, N, K):
+def test_gemm_tn_atomic(dt, M, N, K):
     hip = _hip()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    A = torch.randn(K, M, device="cuda", generator=g).bfloat16()
-    B = torch.randn(K, N, device="cuda", generator=g).bfloat16()
+    A, B = _t((K, M), g, dt), _t((K, N), g, dt)
     out = torch.ones(M, N, device="cuda", dtype=torch.float32)
-    ep = hip.epilogue(out, N, atomic=True)
-    hip.check(hip.lib().clite_gemm_tn(hip.p(A), hip.p(B), M, N, K, C.byref(ep), hip.stream_ptr()), "gemm_tn")
+    hip.gemm_tn(dt, A, B, M, N, K, hip.epilogue(out, N, atomic=True))
     assert _rel(out, 1 + A.float().t() @ B.float()) < 2e-3
 
 
@@ -68,16 +73,14 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dt", [BF16, F32])
 @pytest.mark.parametrize("N,H,W,Cc,K,R,S,st,pad", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(N, H, W, Cc, K, R, S, st, pad):
+def test_conv_fwd_dgrad_wgrad(dt, N, H, W, Cc, K, R, S, st, pad):
     hip = _hip()
-    Ho = (H + 2 * pad - R) // st + 1
-    Wo = (W + 2 * pad - S) // st + 1
-    cv = hip.Conv(N, H, W, Cc, K, R, S, st, pad, Ho, Wo)
+    cv = hip.conv_desc(dt, N, H, W, Cc, K, R, S, st, pad)
+    Ho, Wo = cv.Ho, cv.Wo
     g = torch.Generator(device="cuda").manual_seed(N * H + Cc + K)
-    x = torch.randn(N, H, W, Cc, device="cuda", generator=g).bfloat16()
-    w = (torch.randn(K, R, S, Cc, device="cuda", generator=g) * 0.1).bfloat16()
-    dy = torch.randn(N, Ho, Wo, K, device="cuda", generator=g).bfloat16()
+    x, w, dy = _t((N, H, W, Cc), g, dt), _t((K, R, S, Cc), g, dt, 0.1), _t((N, Ho, Wo, K), g, dt)
     x32 = x.float().permute(0, 3, 1, 2).requires_grad_(True)
     w32 = w.float().permute(0, 3, 1, 2).requires_grad_(True)
     with torch.backends.cudnn.flags(enabled=False):
@@ -86,18 +89,44 @@ def test_conv_fwd_dgrad_wgrad(N, H, W, Cc, K, R, S, st, pad):
     yref = yref.detach().permute(0, 2, 3, 1)
 
     y = torch.empty(N, Ho, Wo, K, device="cuda", dtype=torch.float32)
-    cs = torch.zeros(2, K, device="cuda")
-    ep = hip.epilogue(y, K, colsum=cs)
-    hip.check(hip.lib().clite_conv_fwd(hip.p(x), hip.p(w), C.byref(cv), C.byref(ep), hip.stream_ptr()), "conv_fwd")
+    stats = hip.Stats(torch.zeros(8 * 3 * K, device="cuda"), 8, K)
+    hip.conv_fwd(x, w, cv, hip.epilogue(y, K, colsum=stats))
+    cs = stats.t.view(8, 3, K).sum(0)
     assert _rel(y, yref) < 2e-3
-    assert _rel(cs[0], yref.reshape(-1, K).sum(0)) < 2e-3
-    assert _rel(cs[1], (yref.reshape(-1, K) ** 2).sum(0)) < 2e-3
-
+    assert _rel(cs[0], yref.reshape(-1, K).sum(0)) < 2e-3 and _rel(cs[1], (yref.reshape(-1, K) ** 2).sum(0)) < 2e-3
     dx = torch.empty(N, H, W, Cc, device="cuda", dtype=torch.float32)
-    ep = hip.epilogue(dx, Cc)
-    hip.check(hip.lib().clite_conv_dgrad(hip.p(dy), hip.p(w), C.byref(cv), C.byref(ep), hip.stream_ptr()), "conv_dgrad")
+    hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc))
     assert _rel(dx, x32.grad.permute(0, 2, 3, 1)) < 2e-3
-
     dw = torch.zeros(K, R, S, Cc, device="cuda", dtype=torch.float32)
-    hip.check(hip.lib().clite_conv_wgrad(hip.p(dy), hip.p(x), C.byref(cv), hip.p(dw), hip.stream_ptr()), "conv_wgrad")
+    hip.conv_wgrad(dy, x, cv, dw)
     assert _rel(dw, w32.grad.permute(0, 2, 3, 1)) < 2e-3
+
+
+@pytest.mark.parametrize("dt", [BF16, F32])
+def test_stem_7x7(dt):
+    hip = _hip()
+    N, H, W = 4, 64, 48
+    g = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.randn(N, 3, H, W, device="cuda", generator=g)
+    w = torch.randn(64, 7, 7, 3, device="cuda", generator=g) * 0.1
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = H + 6, W + 8
+    td = torch.bfloat16 if dt == BF16 else torch.float32
+    xpad = torch.empty(N, Hp, Wp, 4, device="cuda", dtype=td)
+    hip.image_to_nhwc4(dt, img, xpad, N, H, W, 3, Hp, Wp)
+    wv = torch.empty(64, 7, 8, 4, device="cuda", dtype=td)
+    hip.stem_pack(dt, w, wv)
+    y = torch.empty(N * Ho * Wo, 64, device="cuda", dtype=torch.float32)
+    hip.stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, hip.epilogue(y, 64))
+    imgr = img.to(td).float().requires_grad_(True)
+    wr = w.to(td).float().permute(0, 3, 1, 2).requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):
+        ref = F.conv2d(imgr, wr, stride=2, padding=3)
+    assert _rel(y.view(N, Ho, Wo, 64), ref.detach().permute(0, 2, 3, 1)) < 2e-3
+    dy = torch.randn(N, Ho, Wo, 64, device="cuda", generator=g).to(td)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    dwv = torch.zeros(64, 7, 8, 4, device="cuda")
+    hip.stem_wgrad(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dwv)
+    dw = torch.zeros(64, 7, 7, 3, device="cuda")
+    hip.stem_unpack_grad(dwv, dw)
+    assert _rel(dw, wr.grad.permute(0, 2, 3, 1)) < 2e-3
