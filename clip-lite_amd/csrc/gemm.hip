@@ -1,5 +1,6 @@
 // Host launchers (C ABI, include/clite.h) for the implicit-GEMM engine in igemm.h.
-#include "igemm.h"
+#include "igemm_dma.h"
+#include <stdlib.h>
 
 using namespace clite;
 
@@ -35,6 +36,26 @@ template <typename T> struct Cfg {
   typedef TileCfg<256, 64, BK, 64, 64> C256x64;
 };
 
+// The LDS-DMA pipelined kernel is the default; CLITE_IGEMM_LEGACY=1 selects the register-staged kernel (A/B timing, debugging).
+bool use_dma() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CLITE_IGEMM_LEGACY"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v == 1;
+}
+template <class L> struct ToDma;
+template <typename T, int ROWS, int BK, bool D> struct ToDma<GatherKC<T, ROWS, BK, D>> {
+  typedef DmaKC<T, ROWS, BK, D> type;
+  static type make(const GatherKC<T, ROWS, BK, D>& l) { return type{l.ptr, l.bytes, l.g}; }
+};
+template <typename T, int COLS, int BK> struct ToDma<StridedXC<T, COLS, BK>> {
+  typedef DmaXCStrided<T, COLS, BK> type;
+  static type make(const StridedXC<T, COLS, BK>& l) { return type{l.ptr, l.bytes, l.ld, l.Cx, l.Ck, l.RS}; }
+};
+template <typename T, int COLS, int BK> struct ToDma<GatherXC<T, COLS, BK>> {
+  typedef DmaXCGather<T, COLS, BK> type;
+  static type make(const GatherXC<T, COLS, BK>& l) { return type{l.ptr, l.bytes, l.g}; }
+};
+
 template <typename T, class CFG, class LA, class LB>
 int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, int Ktot, int splits, hipStream_t st) {
   int ktiles = (Ktot + CFG::BK - 1) / CFG::BK;
@@ -43,7 +64,14 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
   int per = (ktiles + splits - 1) / splits;
   splits = (ktiles + per - 1) / per;
   int tiles = ((M + CFG::BM - 1) / CFG::BM) * ((N + CFG::BN - 1) / CFG::BN);
-  hipLaunchKernelGGL((igemm_kernel<T, CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, M, N, ktiles, per);
+  if (use_dma()) {
+    typedef typename ToDma<LA>::type DA;
+    typedef typename ToDma<LB>::type DB;
+    hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, M, N,
+                       ktiles, per);
+  } else {
+    hipLaunchKernelGGL((igemm_kernel<T, CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, M, N, ktiles, per);
+  }
   return (int)hipGetLastError();
 }
 

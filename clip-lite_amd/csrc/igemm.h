@@ -276,99 +276,13 @@ struct TileCfg {
   static constexpr int EPI_BYTES = WM * EPI_PITCH;
 };
 
-template <typename T, class CFG, class LA, class LB>
-__global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, int M, int N, int ktiles, int ktiles_per_split) {
-  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
+// Fused epilogue shared by the register-staged and the LDS-DMA kernels. `smem` must be free (all waves past their last
+// fragment read) and at least max(CFG::EPI_BYTES, 16 KB) large.
+template <typename T, class CFG>
+DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, char* smem, int M, int N, int m0, int n0,
+                        int tid, int lane, int wave, int wm0, int wn0) {
+  constexpr int BN = CFG::BN;
   constexpr int RM = CFG::RM, RN = CFG::RN;
-  constexpr int STAGE = LA::BYTES + LB::BYTES;
-  constexpr int SMEM = (2 * STAGE > CFG::EPI_BYTES) ? 2 * STAGE : CFG::EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
-  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
-
-  // XCD-aware tile order: workgroups b and b+8 share an XCD (and its 4 MiB L2) under round-robin dispatch, so give
-  // each XCD a contiguous run of logical tiles (bijective for any grid size); placement affects speed only.
-  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
-  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
-  const int tiles_n = (N + BN - 1) / BN;
-  const int tm = wg / tiles_n;
-  const int tn = wg - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int t_begin = blockIdx.z * ktiles_per_split;
-  int t_end = t_begin + ktiles_per_split;
-  if (t_end > ktiles) t_end = ktiles;
-
-  typename LA::State sa;
-  typename LB::State sb;
-  la.init(sa, m0, tid, t_begin);
-  lb.init(sb, n0, tid, t_begin);
-
-  f32x16 acc[RM][RN];
-#pragma unroll
-  for (int i = 0; i < RM; ++i)
-#pragma unroll
-    for (int j = 0; j < RN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  u32x4 ra[LA::NCH], rb[LB::NCH];
-  if (t_begin < t_end) {
-    la.load(sa, ra);
-    lb.load(sb, rb);
-    LA::store(smem, tid, ra);
-    LB::store(smem + LA::BYTES, tid, rb);
-  }
-  __syncthreads();
-
-  for (int t = t_begin; t < t_end; ++t) {
-    const int cur = (t - t_begin) & 1;
-    const bool more = t + 1 < t_end;
-    if (more) {
-      la.load(sa, ra);
-      lb.load(sb, rb);
-    }
-    const char* abuf = smem + cur * STAGE;
-    const char* bbuf = abuf + LA::BYTES;
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8 af[RM], bfr[RN];
-#pragma unroll
-        for (int i = 0; i < RM; ++i) af[i] = LA::frag(abuf, wm0 + i * 32, ks, lane);
-#pragma unroll
-        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag(bbuf, wn0 + j * 32, ks, lane);
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
-      }
-    } else {   // exact-f32 parity mode: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain per output
-#pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        float af[RM], bfr[RN];
-#pragma unroll
-        for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
-#pragma unroll
-        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
-      }
-    }
-    if (more) {
-      char* nbuf = smem + (cur ^ 1) * STAGE;
-      LA::store(nbuf, tid, ra);
-      LB::store(nbuf + LA::BYTES, tid, rb);
-    }
-    __syncthreads();
-  }
-
-  // ---------------------------------------------------------------- epilogue
   if (ep.atomic) {
     float* out = (float*)ep.out;
 #pragma unroll
@@ -488,6 +402,101 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, i
       if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
     }
   }
+}
+
+template <typename T, class CFG, class LA, class LB>
+__global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, int M, int N, int ktiles, int ktiles_per_split) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int SMEM = (2 * STAGE > CFG::EPI_BYTES) ? 2 * STAGE : CFG::EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+
+  // XCD-aware tile order: workgroups b and b+8 share an XCD (and its 4 MiB L2) under round-robin dispatch, so give
+  // each XCD a contiguous run of logical tiles (bijective for any grid size); placement affects speed only.
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tm = wg / tiles_n;
+  const int tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t_begin = blockIdx.z * ktiles_per_split;
+  int t_end = t_begin + ktiles_per_split;
+  if (t_end > ktiles) t_end = ktiles;
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, tid, t_begin);
+  lb.init(sb, n0, tid, t_begin);
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[LA::NCH], rb[LB::NCH];
+  if (t_begin < t_end) {
+    la.load(sa, ra);
+    lb.load(sb, rb);
+    LA::store(smem, tid, ra);
+    LB::store(smem + LA::BYTES, tid, rb);
+  }
+  __syncthreads();
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int cur = (t - t_begin) & 1;
+    const bool more = t + 1 < t_end;
+    if (more) {
+      la.load(sa, ra);
+      lb.load(sb, rb);
+    }
+    const char* abuf = smem + cur * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 af[RM], bfr[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) af[i] = LA::frag(abuf, wm0 + i * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag(bbuf, wn0 + j * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+      }
+    } else {   // exact-f32 parity mode: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain per output
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float af[RM], bfr[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+      }
+    }
+    if (more) {
+      char* nbuf = smem + (cur ^ 1) * STAGE;
+      LA::store(nbuf, tid, ra);
+      LB::store(nbuf + LA::BYTES, tid, rb);
+    }
+    __syncthreads();
+  }
+
+  igemm_epilogue<T, CFG>(acc, ep, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
 }
 
 }  // namespace clite

@@ -1,0 +1,323 @@
+// LDS-DMA pipelined variant of the implicit-GEMM engine (same math, operands, epilogue and C ABI as igemm.h).
+//
+// Operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write), three LDS stages, one raw
+// s_barrier per K tile and a counted `s_waitcnt vmcnt(N)` that leaves the next tile's loads in flight across the barrier:
+//
+//   prologue: issue(t0 -> buf0), issue(t0+1 -> buf1)
+//   for t:    vmcnt(loads of one tile)   // tile t landed (this wave's part) ...
+//             s_barrier                  // ... and everyone's part; also: everyone finished computing tile t-1
+//             issue(t+2 -> buf (t+2)%3)  // overwrites the buffer of tile t-1
+//             compute(buf t%3)
+//
+// The DMA destination is lane-linear (wave-uniform base + lane*16 B), so rows cannot be padded; bank conflicts are removed by
+// an XOR swizzle applied to the SOURCE chunk each lane fetches and to the fragment read address (the same involution on both
+// sides):
+//   KC image [rows][64 B]:   16-B chunk c of row r sits in slot c ^ ((r>>2)&3)          -> conflict-free ds_read_b128
+//   XC image [BK][cols*sizeof(T)]: 64-B segment s of k-row k sits in segment s ^ f(k)   -> conflict-free ds_read_b64_tr_b16
+#ifndef CLITE_IGEMM_DMA_H
+#define CLITE_IGEMM_DMA_H
+#include "igemm.h"
+
+namespace clite {
+
+// ---- KC gather (activations forward, dY in dgrad, weights forward). One wave instruction = 16 rows x 64 B.
+template <typename T, int ROWS, int BK, bool DGRAD>
+struct DmaKC {
+  static_assert(BK * sizeof(T) == 64, "a K tile row is one 64-byte line");
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  static constexpr int NI = ROWS / 64;               // DMA instructions per wave per tile (4 waves x 16 rows each)
+  static constexpr int BYTES = ROWS * 64;
+  const void* ptr;
+  uint32_t bytes;
+  ConvGeom g;
+
+  struct State {
+    rsrc_t rs;
+    int base[NI], h0[NI], w0[NI];
+    int kc;                     // element offset inside the K tile of the chunk this lane fetches (swizzled)
+    int r, s, c0;
+  };
+  DEV void init(State& st, int row0, int wave, int lane, int t_begin) const {
+    st.rs = make_rsrc(ptr, bytes);
+    st.kc = ((lane & 3) ^ ((lane >> 4) & 3)) * EPC;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int row = row0 + (wave * NI + j) * 16 + (lane >> 2);
+      if (row < g.rows) {
+        uint32_t n = fd_div(row, g.div_hw);
+        uint32_t rem = row - n * g.div_hw.d;
+        uint32_t rh = fd_div(rem, g.div_w);
+        uint32_t rw = rem - rh * g.div_w.d;
+        st.base[j] = n * g.sN;
+        if (DGRAD) { st.h0[j] = rh + g.pad; st.w0[j] = rw + g.pad; }
+        else { st.h0[j] = rh * g.stride - g.pad; st.w0[j] = rw * g.stride - g.pad; }
+      } else {
+        st.base[j] = -1; st.h0[j] = 0; st.w0[j] = 0;
+      }
+    }
+    int k0 = t_begin * BK;
+    int rs = k0 / g.C;
+    st.c0 = k0 - rs * g.C;
+    st.r = rs / g.S;
+    st.s = rs - st.r * g.S;
+  }
+  DEV void issue(State& st, char* lds, int wave) const {
+    int c = st.c0 + st.kc;
+    bool kvalid = c < g.C && st.r < g.R;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int hi, wi;
+      bool v = kvalid && st.base[j] >= 0;
+      if (DGRAD) {
+        int hh = st.h0[j] - st.r, ww = st.w0[j] - st.s;
+        if (g.stride == 1) { hi = hh; wi = ww; }
+        else if (g.stride == 2) { v = v && ((hh | ww) & 1) == 0; hi = hh >> 1; wi = ww >> 1; }
+        else { v = v && hh % g.stride == 0 && ww % g.stride == 0; hi = hh / g.stride; wi = ww / g.stride; }
+        v = v && hh >= 0 && ww >= 0;
+      } else {
+        hi = st.h0[j] + st.r; wi = st.w0[j] + st.s;
+      }
+      v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+      uint32_t off = v ? (uint32_t)(st.base[j] + hi * g.sH + wi * g.sW + c) * (uint32_t)sizeof(T) : OOB_OFF;
+      buf_load16_lds(st.rs, off, lds + (wave * NI + j) * 1024);
+    }
+    st.c0 += BK;
+    if (st.c0 >= g.C) { st.c0 = 0; if (++st.s == g.S) { st.s = 0; ++st.r; } }
+  }
+  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
+    int r = x0 + (lane & 31), c = ks * 2 + (lane >> 5);
+    Chunk16 ch;
+    ch.u = *(const u32x4*)(lds + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+    return ch.h;
+  }
+  DEV static float frag32(const char* lds, int x0, int kk, int lane) {
+    int r = x0 + (lane & 31), k = kk * 2 + (lane >> 5);           // k in [0,16)
+    return *(const float*)(lds + r * 64 + (((k >> 2) ^ ((r >> 2) & 3)) << 4) + (k & 3) * 4);
+  }
+};
+
+// 64-byte-segment swizzle of an XC image row k (row = COLS*sizeof(T) bytes)
+template <int ROWBYTES> DEV int xc_seg_xor(int k) {
+  return ROWBYTES == 128 ? ((k >> 1) & 1) : (k & 3);      // 128 B rows: 2 k-rows per 256-B bank row; >= 256 B rows: one or less
+}
+
+// ---- XC strided (weights in dgrad, dY in wgrad, linear weights in input-grad): element (k, x) at ptr[(k0+krow)*ld + rs*Cx + x]
+template <typename T, int COLS, int BK>
+struct DmaXCStrided {
+  static constexpr int EPC = 16 / (int)sizeof(T);
+  static constexpr int ROWB = COLS * (int)sizeof(T);         // bytes per k-row of the image
+  static constexpr int CPR = ROWB / 16;                      // 16-B chunks per k-row
+  static constexpr int RPI = 64 / CPR;                       // k-rows per wave instruction
+  static constexpr int NI = BK / (4 * RPI);                  // instructions per wave per tile
+  static constexpr int BYTES = BK * ROWB;
+  static_assert(CPR <= 64 && 64 % CPR == 0 && BK % (4 * RPI) == 0, "tile shape");
+  const void* ptr;
+  uint32_t bytes;
+  int ld, Cx, Ck, RS;
+
+  struct State {
+    rsrc_t rs_;
+    int x[NI];        // first element of the (swizzled) source chunk this lane fetches in instruction j, or -1 if out of range
+    int krow[NI];     // k-row inside the tile
+    int rs, k0;
+  };
+  DEV void init(State& st, int x0, int wave, int lane, int t_begin) const {
+    st.rs_ = make_rsrc(ptr, bytes);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int krow = (wave * NI + j) * RPI + lane / CPR;
+      int c = (lane % CPR) ^ (xc_seg_xor<ROWB>(krow) << 2);   // source chunk that lands in this lane's slot
+      int x = x0 + c * EPC;
+      st.krow[j] = krow;
+      st.x[j] = x < Cx ? x : -1;
+    }
+    int kk = t_begin * BK;
+    st.rs = (RS == 1) ? 0 : kk / Ck;
+    st.k0 = kk - st.rs * Ck;
+  }
+  DEV void issue(State& st, char* lds, int wave, int, int) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int k = st.k0 + st.krow[j];
+      bool v = st.x[j] >= 0 && k < Ck && st.rs < RS;
+      uint32_t off = v ? (uint32_t)(k * ld + st.rs * Cx + st.x[j]) * (uint32_t)sizeof(T) : OOB_OFF;
+      buf_load16_lds(st.rs_, off, lds + (wave * NI + j) * 1024);
+    }
+    st.k0 += BK;
+    if (st.k0 >= Ck && RS > 1) { st.k0 = 0; ++st.rs; }
+  }
+  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
+    int x = x0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);     // 4 consecutive x of one 16-B chunk half
+    int k = ks * 16 + 8 * (lane >> 5) + ((lane >> 2) & 3);
+    int c = (x * 2) >> 4, within = (x * 2) & 15;
+    const char* p0 = lds + k * ROWB + ((c ^ (xc_seg_xor<ROWB>(k) << 2)) << 4) + within;
+    int k2 = k + 4;
+    const char* p1 = lds + k2 * ROWB + ((c ^ (xc_seg_xor<ROWB>(k2) << 2)) << 4) + within;
+    s16x4 lo = lds_read_tr16(p0);
+    s16x4 hi = lds_read_tr16(p1);
+    union { s16x4 v[2]; bf16x8 h; } u;
+    u.v[0] = lo; u.v[1] = hi;
+    return u.h;
+  }
+  DEV static float frag32(const char* lds, int x0, int kk, int lane) {
+    int k = kk * 2 + (lane >> 5), x = x0 + (lane & 31);
+    int c = (x * 4) >> 4, within = (x * 4) & 15;
+    return *(const float*)(lds + k * ROWB + ((c ^ (xc_seg_xor<ROWB>(k) << 2)) << 4) + within);
+  }
+};
+
+// ---- XC gather (wgrad's activation operand): k = output pixel p, x = (r, s, ci)
+template <typename T, int COLS, int BK>
+struct DmaXCGather {
+  typedef DmaXCStrided<T, COLS, BK> L;
+  static constexpr int EPC = L::EPC, ROWB = L::ROWB, CPR = L::CPR, RPI = L::RPI, NI = L::NI, BYTES = L::BYTES;
+  const void* ptr;
+  uint32_t bytes;
+  ConvGeom g;
+
+  struct State {
+    rsrc_t rs_;
+    int xoff[NI];     // r*sH + s*sW + ci of this lane's source chunk in instruction j, or -1 if the column is out of range
+    int r[NI], s[NI], krow[NI];
+    int p0;
+  };
+  DEV void init(State& st, int x0, int wave, int lane, int t_begin) const {
+    st.rs_ = make_rsrc(ptr, bytes);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int krow = (wave * NI + j) * RPI + lane / CPR;
+      int c = (lane % CPR) ^ (xc_seg_xor<ROWB>(krow) << 2);
+      int x = x0 + c * EPC;
+      int rs = x / g.C;
+      int ci = x - rs * g.C;
+      st.r[j] = rs / g.S;
+      st.s[j] = rs - st.r[j] * g.S;
+      st.krow[j] = krow;
+      st.xoff[j] = x < g.R * g.S * g.C ? ci : -1;
+    }
+    st.p0 = t_begin * BK;
+  }
+  DEV void issue(State& st, char* lds, int wave, int, int) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int p = st.p0 + st.krow[j];
+      bool v = st.xoff[j] >= 0 && p < g.rows;
+      uint32_t n = fd_div(p, g.div_hw);
+      uint32_t rem = p - n * g.div_hw.d;
+      uint32_t ho = fd_div(rem, g.div_w);
+      uint32_t wo = rem - ho * g.div_w.d;
+      int hi = (int)ho * g.stride - g.pad + st.r[j];
+      int wi = (int)wo * g.stride - g.pad + st.s[j];
+      v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+      uint32_t off = v ? (uint32_t)((int)n * g.sN + hi * g.sH + wi * g.sW + st.xoff[j]) * (uint32_t)sizeof(T) : OOB_OFF;
+      buf_load16_lds(st.rs_, off, lds + (wave * NI + j) * 1024);
+    }
+    st.p0 += BK;
+  }
+  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) { return L::frag(lds, x0, ks, lane); }
+  DEV static float frag32(const char* lds, int x0, int kk, int lane) { return L::frag32(lds, x0, kk, lane); }
+};
+
+// uniform issue() signature over the three loaders
+template <class L> struct DmaIssue {
+  DEV static void go(const L& l, typename L::State& st, char* lds, int wave, int lane, int x0) { l.issue(st, lds, wave, lane, x0); }
+};
+template <typename T, int ROWS, int BK, bool D> struct DmaIssue<DmaKC<T, ROWS, BK, D>> {
+  typedef DmaKC<T, ROWS, BK, D> L;
+  DEV static void go(const L& l, typename L::State& st, char* lds, int wave, int, int) { l.issue(st, lds, wave); }
+};
+
+template <typename T, class CFG, class LA, class LB>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, int M, int N, int ktiles, int ktiles_per_split) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int NSTAGE = 3;
+  constexpr int SMEM = (NSTAGE * STAGE > CFG::EPI_BYTES) ? NSTAGE * STAGE : CFG::EPI_BYTES;
+  constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tm = wg / tiles_n;
+  const int tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t_begin = blockIdx.z * ktiles_per_split;
+  int t_end = t_begin + ktiles_per_split;
+  if (t_end > ktiles) t_end = ktiles;
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, wave, lane, t_begin);
+  lb.init(sb, n0, wave, lane, t_begin);
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: two tiles in flight
+  if (t_begin < t_end) {
+    DmaIssue<LA>::go(la, sa, smem, wave, lane, m0);
+    DmaIssue<LB>::go(lb, sb, smem + LA::BYTES, wave, lane, n0);
+  }
+  if (t_begin + 1 < t_end) {
+    DmaIssue<LA>::go(la, sa, smem + STAGE, wave, lane, m0);
+    DmaIssue<LB>::go(lb, sb, smem + STAGE + LA::BYTES, wave, lane, n0);
+  }
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    if (t + 1 < t_end) wait_vmcnt<LOADS_PER_TILE>(); else wait_vmcnt<0>();
+    barrier_raw();
+    if (t + 2 < t_end) {
+      int nb = buf + 2; if (nb >= NSTAGE) nb -= NSTAGE;
+      DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+      DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+    }
+    const char* abuf = smem + buf * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 af[RM], bfr[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) af[i] = LA::frag(abuf, wm0 + i * 32, ks, lane);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag(bbuf, wn0 + j * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        float af[RM], bfr[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+      }
+    }
+    if (++buf == NSTAGE) buf = 0;
+  }
+  barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
+  igemm_epilogue<T, CFG>(acc, ep, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+}
+
+}  // namespace clite
+#endif  // CLITE_IGEMM_DMA_H

@@ -42,6 +42,15 @@ DEV void buf_store16(rsrc_t r, uint32_t off, u32x4 v) { __builtin_amdgcn_raw_buf
 DEV void buf_store8(rsrc_t r, uint32_t off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0); }
 DEV void buf_store4(rsrc_t r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 0); }
 
+// LDS-DMA: buffer_load_dwordx4 ... lds — 16 bytes per lane from its own global offset straight into LDS at
+// lds_wave_base + lane*16 (the LDS destination is wave-uniform base + lane slot; out-of-range sources write zeros).
+// Counts on vmcnt like any other load; data is visible to ds_read only after the issuing wave's vmcnt wait + a barrier.
+DEV void buf_load16_lds(rsrc_t r, uint32_t off, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, off, 0, 0, 0);
+}
+template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+DEV void barrier_raw() { __builtin_amdgcn_s_barrier(); }   // no implied vmcnt(0): LDS-DMA may stay in flight across it
+
 // v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k 8*(l>>5)+j], B[k 8*(l>>5)+j][col l&31];
 // D reg i of lane l = D[row (i&3)+8*(i>>2)+4*(l>>5)][col l&31].
 DEV f32x16 mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c) {

@@ -12,28 +12,38 @@ namespace {
 
 struct BnCoef { float a[8], b[8]; };
 
-// sum of the R partial accumulators of one statistic
-DEV float rsum(const float* p, int replicas, int rstride) {
-  float s = p[0];
-  for (int r = 1; r < replicas; ++r) s += p[(size_t)r * rstride];
-  return s;
+// sum of the R partial accumulators of 8 consecutive channels of one statistic (32-byte vector loads)
+DEV void rsum8(const float* p, int replicas, int rstride, float (&s)[8]) {
+  load8(p, s);
+  for (int r = 1; r < replicas; ++r) {
+    float t[8];
+    load8(p + (size_t)r * rstride, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += t[e];
+  }
 }
 
 // scale/shift of 8 channels from batch statistics (training) or running statistics (eval)
 DEV void bn_coef(const float* stats, int R, int RS, const float* gamma, const float* beta, const float* rmean, const float* rvar,
                  int training, int centered, float inv_count, float eps, int C, int c0, BnCoef& k, float (&mean)[8], float (&var)[8]) {
+  if (training) {
+    // single-pass E[x^2]-E[x]^2 (sums from the conv epilogue), or the two-pass sum of squared deviations when a
+    // centered pass (clite_bn_centered_var) filled stats[2][C]
+    float s1[8], s2[8];
+    rsum8(stats + c0, R, RS, s1);
+    rsum8(stats + (centered ? 2 : 1) * C + c0, R, RS, s2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mean[e] = s1[e] * inv_count;
+      var[e] = centered ? s2[e] * inv_count : fmaxf(s2[e] * inv_count - mean[e] * mean[e], 0.f);
+    }
+  } else {
+    load8(rmean + c0, mean);
+    load8(rvar + c0, var);
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     int c = c0 + e;
-    if (training) {
-      mean[e] = rsum(stats + c, R, RS) * inv_count;
-      // single-pass E[x^2]-E[x]^2 (sums from the conv epilogue), or the two-pass sum of squared deviations when a
-      // centered pass (clite_bn_centered_var) filled stats[2][C]
-      var[e] = centered ? rsum(stats + 2 * C + c, R, RS) * inv_count : fmaxf(rsum(stats + C + c, R, RS) * inv_count - mean[e] * mean[e], 0.f);
-    } else {
-      mean[e] = rmean[c];
-      var[e] = rvar[c];
-    }
     float rstd = rsqrtf(var[e] + eps);
     k.a[e] = gamma[c] * rstd;
     k.b[e] = beta[c];           // applied as (y - mean)*a + b: folding mean into the shift cancels badly when |mean| >> std
@@ -100,8 +110,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
   float s1[8], s2[8], mean[8];
   zero8(s1); zero8(s2);
+  rsum8(stats + c0, R, RS, mean);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) mean[e] = rsum(stats + c0 + e, R, RS) / (float)M;
+  for (int e = 0; e < 8; ++e) mean[e] /= (float)M;
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > M) row_end = M;
   for (int r = row_begin + r0; r < row_end; r += RPS) {
@@ -138,8 +149,9 @@ __global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* y, float*
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
   float mean[8], s[8];
   const float inv_count = 1.0f / (float)M;
+  rsum8(stats + c0, R, RS, mean);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { mean[e] = rsum(stats + c0 + e, R, RS) * inv_count; s[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { mean[e] *= inv_count; s[e] = 0.f; }
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > M) row_end = M;
   for (int r = row_begin + r0; r < row_end; r += RPS) {
@@ -168,23 +180,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
   const float inv_count = 1.0f / (float)p.M;
   float mean[8], rstd[8], ka[8], kb[8], kc[8];   // dy = ka*dz + kb + kc*(y - mean)
+  float v1[8], v2[8], S1[8], S2[8];
+  rsum8(p.stats + c0, p.replicas, p.rstride, v1);
+  rsum8(p.stats + (p.centered ? 2 : 1) * p.C + c0, p.replicas, p.rstride, v2);
+  rsum8(dstats + c0, p.replicas, p.rstride, S1);
+  rsum8(dstats + p.C + c0, p.replicas, p.rstride, S2);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     int c = c0 + e;
-    mean[e] = rsum(p.stats + c, p.replicas, p.rstride) * inv_count;
-    float var = p.centered ? rsum(p.stats + 2 * p.C + c, p.replicas, p.rstride) * inv_count
-                           : fmaxf(rsum(p.stats + p.C + c, p.replicas, p.rstride) * inv_count - mean[e] * mean[e], 0.f);
+    mean[e] = v1[e] * inv_count;
+    float var = p.centered ? v2[e] * inv_count : fmaxf(v2[e] * inv_count - mean[e] * mean[e], 0.f);
     rstd[e] = rsqrtf(var + p.eps);
-    float S1 = rsum(dstats + c, p.replicas, p.rstride), S2 = rsum(dstats + p.C + c, p.replicas, p.rstride);
-    float G = rstd[e] * S2;
+    float G = rstd[e] * S2[e];
     float a = p.gamma[c] * rstd[e];
     // dy = a*(dz - S1/M - (y-mean)*rstd*G/M); (y - mean) is formed explicitly: folding mean into kb cancels badly when |mean| >> std
     ka[e] = a;
     kc[e] = -a * rstd[e] * G * inv_count;
-    kb[e] = -a * S1 * inv_count;
+    kb[e] = -a * S1[e] * inv_count;
     if (blockIdx.x == 0 && r0 == 0) {
       if (dgamma) dgamma[c] += G;
-      if (dbeta) dbeta[c] += S1;
+      if (dbeta) dbeta[c] += S1[e];
     }
   }
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
@@ -210,7 +225,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
 int bn_grid(int M, int C, int* rows_per_block) {
   int CPR = C / 8, RPS = 256 / CPR;
   int sweeps = (M + RPS - 1) / RPS;
-  int grid = sweeps < 1024 ? sweeps : 1024;
+  int want = (sweeps + 15) / 16;            // >= 16 row sweeps per workgroup amortise the per-channel coefficient prologue
+  int grid = want < 1 ? 1 : (want > 1024 ? 1024 : want);
   int spb = (sweeps + grid - 1) / grid;
   *rows_per_block = spb * RPS;
   return (M + *rows_per_block - 1) / *rows_per_block;

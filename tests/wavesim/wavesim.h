@@ -158,6 +158,15 @@ inline void buf_store16(rsrc_t r, uint32_t off, u32x4 v) { assert(off % 4 == 0);
 inline void buf_store8(rsrc_t r, uint32_t off, u32x2 v) { assert(off % 4 == 0); wavesim_buf_store(r, off, v); }
 inline void buf_store4(rsrc_t r, uint32_t off, uint32_t v) { assert(off % 4 == 0); wavesim_buf_store(r, off, v); }
 
+// LDS-DMA is emulated synchronously (data lands immediately), so the simulator checks addressing and swizzles, not the
+// vmcnt/barrier protocol.
+inline void buf_load16_lds(rsrc_t r, uint32_t off, void* lds_wave_base) {
+  u32x4 v = buf_load16(r, off);
+  memcpy((char*)lds_wave_base + wavesim::g_lane * 16, &v, 16);
+}
+template <int N> inline void wait_vmcnt() {}
+inline void barrier_raw() { __syncthreads(); }
+
 // ---------------------------------------------------------------- conversions
 inline float bf2f(bf16 x) {
   uint16_t b;

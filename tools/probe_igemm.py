@@ -21,23 +21,23 @@ def gemm(kind, M, N, K):
     B = torch.randn(N, K, device="cuda").bfloat16() if kind == "nt" else torch.randn(K, N, device="cuda").bfloat16()
     out = torch.zeros(M, N, device="cuda", dtype=torch.float32 if kind == "tn" else torch.bfloat16)
     ep = hip.epilogue(out, N, atomic=(kind == "tn"))
-    f = getattr(L, "clite_gemm_" + kind)
-    ms = timeit(lambda: f(hip.p(A), hip.p(B), M, N, K, C.byref(ep), hip.stream_ptr()))
+    f = getattr(hip, "gemm_" + kind)
+    ms = timeit(lambda: f(hip.BF16, A, B, M, N, K, ep))
     print(f"gemm_{kind} M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:8.1f} TFLOP/s")
 
 def conv(N, H, W, Cc, K, R, S, st, pad):
     Ho = (H + 2 * pad - R) // st + 1; Wo = (W + 2 * pad - S) // st + 1
-    cv = hip.Conv(N, H, W, Cc, K, R, S, st, pad, Ho, Wo)
+    cv = hip.conv_desc(hip.BF16, N, H, W, Cc, K, R, S, st, pad)
     x = torch.randn(N, H, W, Cc, device="cuda").bfloat16(); w = torch.randn(K, R, S, Cc, device="cuda").bfloat16()
     dy = torch.randn(N, Ho, Wo, K, device="cuda").bfloat16()
     y = torch.empty(N, Ho, Wo, K, device="cuda", dtype=torch.bfloat16); dx = torch.empty_like(x)
     dw = torch.zeros(K, R, S, Cc, device="cuda")
-    cs = torch.zeros(2, K, device="cuda")
+    cs = hip.Stats(torch.zeros(8 * 3 * K, device="cuda"), 8, K)
     epy = hip.epilogue(y, K, colsum=cs); epx = hip.epilogue(dx, Cc)
     fl = 2.0 * N * Ho * Wo * K * R * S * Cc
-    t1 = timeit(lambda: L.clite_conv_fwd(hip.p(x), hip.p(w), C.byref(cv), C.byref(epy), hip.stream_ptr()))
-    t2 = timeit(lambda: L.clite_conv_dgrad(hip.p(dy), hip.p(w), C.byref(cv), C.byref(epx), hip.stream_ptr()))
-    t3 = timeit(lambda: L.clite_conv_wgrad(hip.p(dy), hip.p(x), C.byref(cv), hip.p(dw), hip.stream_ptr()))
+    t1 = timeit(lambda: hip.conv_fwd(x, w, cv, epy))
+    t2 = timeit(lambda: hip.conv_dgrad(dy, w, cv, epx))
+    t3 = timeit(lambda: hip.conv_wgrad(dy, x, cv, dw))
     print(f"conv N={N} {H}x{W} C={Cc} K={K} {R}x{S}/{st}: fwd {t1*1e3:7.1f} us {fl/t1/1e9:6.1f} TF | dgrad {t2*1e3:7.1f} us {fl/t2/1e9:6.1f} TF | wgrad {t3*1e3:7.1f} us {fl/t3/1e9:6.1f} TF")
 
 if __name__ == "__main__":
