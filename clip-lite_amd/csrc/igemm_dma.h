@@ -34,9 +34,31 @@ struct DmaKC {
   struct State {
     rsrc_t rs;
     int base[NI], h0[NI], w0[NI];
+    uint32_t off[NI];           // byte offset of this lane's chunk for the current K tile (valid when ok[j])
+    bool ok[NI];                // window position (r, s) lands inside the tensor for row j
     int kc;                     // element offset inside the K tile of the chunk this lane fetches (swizzled)
     int r, s, c0;
   };
+  // offsets of all rows for the current (r, s, c0): done once per window position, then advanced by 64 B per K tile
+  DEV void locate(State& st) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int hi, wi;
+      bool v = st.base[j] >= 0 && st.r < g.R;
+      if (DGRAD) {
+        int hh = st.h0[j] - st.r, ww = st.w0[j] - st.s;
+        if (g.stride == 1) { hi = hh; wi = ww; }
+        else if (g.stride == 2) { v = v && ((hh | ww) & 1) == 0; hi = hh >> 1; wi = ww >> 1; }
+        else { v = v && hh % g.stride == 0 && ww % g.stride == 0; hi = hh / g.stride; wi = ww / g.stride; }
+        v = v && hh >= 0 && ww >= 0;
+      } else {
+        hi = st.h0[j] + st.r; wi = st.w0[j] + st.s;
+      }
+      v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+      st.ok[j] = v;
+      st.off[j] = (uint32_t)(st.base[j] + hi * g.sH + wi * g.sW + st.c0 + st.kc) * (uint32_t)sizeof(T);
+    }
+  }
   DEV void init(State& st, int row0, int wave, int lane, int t_begin) const {
     st.rs = make_rsrc(ptr, bytes);
     st.kc = ((lane & 3) ^ ((lane >> 4) & 3)) * EPC;
@@ -60,34 +82,31 @@ struct DmaKC {
     st.c0 = k0 - rs * g.C;
     st.r = rs / g.S;
     st.s = rs - st.r * g.S;
+    locate(st);
   }
   DEV void issue(State& st, char* lds, int wave) const {
-    int c = st.c0 + st.kc;
-    bool kvalid = c < g.C && st.r < g.R;
+    bool kvalid = st.c0 + st.kc < g.C;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      int hi, wi;
-      bool v = kvalid && st.base[j] >= 0;
-      if (DGRAD) {
-        int hh = st.h0[j] - st.r, ww = st.w0[j] - st.s;
-        if (g.stride == 1) { hi = hh; wi = ww; }
-        else if (g.stride == 2) { v = v && ((hh | ww) & 1) == 0; hi = hh >> 1; wi = ww >> 1; }
-        else { v = v && hh % g.stride == 0 && ww % g.stride == 0; hi = hh / g.stride; wi = ww / g.stride; }
-        v = v && hh >= 0 && ww >= 0;
-      } else {
-        hi = st.h0[j] + st.r; wi = st.w0[j] + st.s;
-      }
-      v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-      uint32_t off = v ? (uint32_t)(st.base[j] + hi * g.sH + wi * g.sW + c) * (uint32_t)sizeof(T) : OOB_OFF;
+      uint32_t off = (kvalid && st.ok[j]) ? st.off[j] : OOB_OFF;
       buf_load16_lds(st.rs, off, lds + (wave * NI + j) * 1024);
+      st.off[j] += 64;
     }
     st.c0 += BK;
-    if (st.c0 >= g.C) { st.c0 = 0; if (++st.s == g.S) { st.s = 0; ++st.r; } }
+    if (st.c0 >= g.C) {          // next window position (block-uniform branch)
+      st.c0 = 0;
+      if (++st.s == g.S) { st.s = 0; ++st.r; }
+      locate(st);
+    }
   }
-  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
+  // byte offset (inside the operand image) of the fragment of the 32-row block at x0, k-step ks: loop-invariant per lane
+  DEV static int frag_off(int x0, int ks, int lane) {
     int r = x0 + (lane & 31), c = ks * 2 + (lane >> 5);
+    return r * 64 + ((c ^ ((r >> 2) & 3)) << 4);
+  }
+  DEV static bf16x8 frag_at(const char* p) {
     Chunk16 ch;
-    ch.u = *(const u32x4*)(lds + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+    ch.u = *(const u32x4*)p;
     return ch.h;
   }
   DEV static float frag32(const char* lds, int x0, int kk, int lane) {
@@ -119,8 +138,14 @@ struct DmaXCStrided {
     rsrc_t rs_;
     int x[NI];        // first element of the (swizzled) source chunk this lane fetches in instruction j, or -1 if out of range
     int krow[NI];     // k-row inside the tile
+    uint32_t off[NI]; // byte offset for the current K tile
     int rs, k0;
   };
+  DEV void locate(State& st) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      st.off[j] = (uint32_t)((st.k0 + st.krow[j]) * ld + st.rs * Cx + (st.x[j] < 0 ? 0 : st.x[j])) * (uint32_t)sizeof(T);
+  }
   DEV void init(State& st, int x0, int wave, int lane, int t_begin) const {
     st.rs_ = make_rsrc(ptr, bytes);
 #pragma unroll
@@ -134,27 +159,29 @@ struct DmaXCStrided {
     int kk = t_begin * BK;
     st.rs = (RS == 1) ? 0 : kk / Ck;
     st.k0 = kk - st.rs * Ck;
+    locate(st);
   }
   DEV void issue(State& st, char* lds, int wave, int, int) const {
+    const uint32_t step = (uint32_t)(BK * ld) * (uint32_t)sizeof(T);
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      int k = st.k0 + st.krow[j];
-      bool v = st.x[j] >= 0 && k < Ck && st.rs < RS;
-      uint32_t off = v ? (uint32_t)(k * ld + st.rs * Cx + st.x[j]) * (uint32_t)sizeof(T) : OOB_OFF;
-      buf_load16_lds(st.rs_, off, lds + (wave * NI + j) * 1024);
+      bool v = st.x[j] >= 0 && st.k0 + st.krow[j] < Ck && st.rs < RS;
+      buf_load16_lds(st.rs_, v ? st.off[j] : OOB_OFF, lds + (wave * NI + j) * 1024);
+      st.off[j] += step;
     }
     st.k0 += BK;
-    if (st.k0 >= Ck && RS > 1) { st.k0 = 0; ++st.rs; }
+    if (st.k0 >= Ck && RS > 1) { st.k0 = 0; ++st.rs; locate(st); }
   }
-  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) {
+  // k and k+4 get the same segment swizzle for every supported row size, so the second transposed read is +4 rows
+  DEV static int frag_off(int x0, int ks, int lane) {
     int x = x0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);     // 4 consecutive x of one 16-B chunk half
     int k = ks * 16 + 8 * (lane >> 5) + ((lane >> 2) & 3);
     int c = (x * 2) >> 4, within = (x * 2) & 15;
-    const char* p0 = lds + k * ROWB + ((c ^ (xc_seg_xor<ROWB>(k) << 2)) << 4) + within;
-    int k2 = k + 4;
-    const char* p1 = lds + k2 * ROWB + ((c ^ (xc_seg_xor<ROWB>(k2) << 2)) << 4) + within;
-    s16x4 lo = lds_read_tr16(p0);
-    s16x4 hi = lds_read_tr16(p1);
+    return k * ROWB + ((c ^ (xc_seg_xor<ROWB>(k) << 2)) << 4) + within;
+  }
+  DEV static bf16x8 frag_at(const char* p) {
+    s16x4 lo = lds_read_tr16(p);
+    s16x4 hi = lds_read_tr16(p + 4 * ROWB);
     union { s16x4 v[2]; bf16x8 h; } u;
     u.v[0] = lo; u.v[1] = hi;
     return u.h;
@@ -214,7 +241,8 @@ struct DmaXCGather {
     }
     st.p0 += BK;
   }
-  DEV static bf16x8 frag(const char* lds, int x0, int ks, int lane) { return L::frag(lds, x0, ks, lane); }
+  DEV static int frag_off(int x0, int ks, int lane) { return L::frag_off(x0, ks, lane); }
+  DEV static bf16x8 frag_at(const char* p) { return L::frag_at(p); }
   DEV static float frag32(const char* lds, int x0, int kk, int lane) { return L::frag32(lds, x0, kk, lane); }
 };
 
@@ -266,6 +294,18 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // loop-invariant LDS offsets of this lane's MFMA fragments (bf16 path)
+  int aoff[RM][BK / 16 > 0 ? BK / 16 : 1], boff[RN][BK / 16 > 0 ? BK / 16 : 1];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i) aoff[i][ks] = LA::frag_off(wm0 + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) boff[j][ks] = LB::frag_off(wn0 + j * 32, ks, lane);
+    }
+  }
+
   // prologue: two tiles in flight
   if (t_begin < t_end) {
     DmaIssue<LA>::go(la, sa, smem, wave, lane, m0);
@@ -291,9 +331,9 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
       for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 af[RM], bfr[RN];
 #pragma unroll
-        for (int i = 0; i < RM; ++i) af[i] = LA::frag(abuf, wm0 + i * 32, ks, lane);
+        for (int i = 0; i < RM; ++i) af[i] = LA::frag_at(abuf + aoff[i][ks]);
 #pragma unroll
-        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag(bbuf, wn0 + j * 32, ks, lane);
+        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag_at(bbuf + boff[j][ks]);
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
