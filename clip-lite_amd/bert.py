@@ -205,6 +205,7 @@ def bert_backward(rt, net, ctx, dpooled):
     if pw.weight.requires_grad:
         hip.gemm_tn(dt, dpre, ctx["h_last"], Hd, Hd, B, hip.epilogue(A.g(pw.weight), Hd, atomic=True, out_f32=True), ldb=L * Hd)
         hip.colsum(dt, dpre, A.g(pw.bias), B, Hd)
+    rt.grads_ready(net.pooler)
     dh = torch.zeros(M, Hd, device=rt.device, dtype=rt.tdtype)
     hip.gemm_nn(dt, dpre, A.w(pw.weight), B, Hd, Hd, hip.epilogue(dh, L * Hd))
     for (layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2) in reversed(ctx["layers"]):
@@ -236,9 +237,11 @@ def bert_backward(rt, net, ctx, dpooled):
         dhp = _alloc(rt, M, Hd)
         hip.gemm_nn(dt, dqkv, wqkv, M, Hd, 3 * Hd, hip.epilogue(dhp, Hd, residual=ds1))
         dh = dhp
+        rt.grads_ready(layer)
     emb = net.embeddings
     ds0 = _alloc(rt, M, Hd)
     hip.layernorm_bwd(dt, dh, ctx["s0"], ctx["st0"], emb.LayerNorm.weight, ds0, None, A.g(emb.LayerNorm.weight), A.g(emb.LayerNorm.bias), M, Hd,
                       drop_in=ctx["d0"])
     hip.embed_bwd(dt, ctx["ids"], ds0, A.g(emb.word_embeddings.weight), A.g(emb.position_embeddings.weight), M, L, Hd, net.vocab)
     hip.colsum(dt, ds0, A.g(emb.token_type_embeddings.weight)[0], M, Hd)
+    rt.grads_ready(emb)

@@ -75,11 +75,16 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
   return (int)hipGetLastError();
 }
 
+// Split-K factor for float-atomic accumulation (weight gradients). Every split adds a full output tile of atomic traffic
+// (chip-wide ~1.3 TB/s) plus a prologue/epilogue, so split only as far as needed to give every CU about two workgroups, and
+// never below 8 K tiles per split.
 int pick_splits(int M, int N, int ktiles) {
   long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
-  long want = 1024 / tiles;      // ~4 workgroups per CU
+  long want = (512 + tiles - 1) / tiles;
+  long cap = ktiles / 8;
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
   if (want < 1) want = 1;
-  if (want > ktiles) want = ktiles;
   return (int)want;
 }
 

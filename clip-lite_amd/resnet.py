@@ -222,7 +222,8 @@ def resnet_backward(rt, net, ctx, dfeat):
     Hc, Wc, Cout = ctx["final"]
     dout = _alloc(rt, N * Hc * Wc, Cout)
     hip.avgpool_bwd(dt, dfeat, dout, N, Hc * Wc, Cout)
-    for units, ud, Hin, Win in reversed(ctx["recs"]):
+    blocks = list(net.blocks())
+    for bi, (units, ud, Hin, Win) in reversed(list(enumerate(ctx["recs"]))):
         last = units[-1]
         xin = units[0].x
         identity = ud is None
@@ -251,6 +252,7 @@ def resnet_backward(rt, net, ctx, dfeat):
                     hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx2, Cin, residual=dx))
                     dx = dx2
                 dout = dx
+        rt.grads_ready(blocks[bi])
     xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq = ctx["stem"]
     da0 = _alloc(rt, N * Ho * Wo, 64)
     hip.maxpool_bwd(dt, dout, idx, da0, N, Ho, Wo, 64)
@@ -261,3 +263,5 @@ def resnet_backward(rt, net, ctx, dfeat):
         dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)
         hip.stem_wgrad(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, dwv)
         hip.stem_unpack_grad(dwv, rt.arena.g(net.conv1.weight))
+    rt.grads_ready(net.conv1)
+    rt.grads_ready(net.bn1)

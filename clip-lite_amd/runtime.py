@@ -155,6 +155,8 @@ class DeviceRuntime:
         self.arena = Arena(model.named_parameters(), self.device, lowp, contiguous_groups)
         self.base_seed = int(seed)
         self.zpool = ZeroPool(self.device)
+        self.exchange = None
+        self._spans = {}
         self.steps = 0
         # flatten num_batches_tracked buffers per top-level owner
         self.counters = {}
@@ -174,6 +176,19 @@ class DeviceRuntime:
     def new_stats(self, Cc):
         """Zeroed replicated accumulator for per-channel statistics of a [rows][Cc] tensor."""
         return hip.Stats(self.zpool.take(STAT_REPLICAS * 3 * Cc), STAT_REPLICAS, Cc)
+
+    def grads_ready(self, module):
+        """Tell the gradient exchange (data parallel) that every parameter gradient under `module` is final for this step,
+        so its region of the flat gradient arena can be all-reduced while the rest of backward still runs."""
+        ex = getattr(self, "exchange", None)
+        if ex is None:
+            return
+        span = self._spans.get(id(module))
+        if span is None:
+            offs = [self.arena.index[p._clite[1]] for p in module.parameters() if hasattr(p, "_clite")]
+            span = (min(o for o, _ in offs), max((o + n + ALIGN - 1) // ALIGN * ALIGN for o, n in offs)) if offs else (0, 0)
+            self._spans[id(module)] = span
+        ex.region_ready(*span)
 
     def bump_counters(self, owner, n=1):
         if owner in self.counters:

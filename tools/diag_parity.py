@@ -30,3 +30,16 @@ for k, p in M.named_parameters():
     e_o32 = (g32[k].double() - r).abs().max().item() / max(sc, 1e-12)
     flag = " <<<" if e_hip > 10 * max(e_o32, 1e-5) else ""
     print(f"{k:75s} scale {sc:9.3e}  hip {e_hip:9.2e}  oracle32 {e_o32:9.2e}{flag}")
+
+# summary: cosine similarity of gradients against fp64 truth
+import math
+num = den1 = den2 = 0.0
+worst = []
+for k, p in M.named_parameters():
+    a = p.grad.detach().double().cpu().flatten(); b = gd[k].flatten()
+    c = float(a @ b) / (float(a.norm()) * float(b.norm()) + 1e-30)
+    worst.append((c, k, float(b.norm())))
+    num += float(a @ b); den1 += float(a @ a); den2 += float(b @ b)
+print("global grad cosine", num / math.sqrt(den1 * den2))
+for c, k, n in sorted(worst)[:12]:
+    print(f"  cos {c:.4f}  |g| {n:.3e}  {k}")
