@@ -42,6 +42,11 @@ bool use_dma() {
   if (v < 0) { const char* e = getenv("CLITE_IGEMM_LEGACY"); v = (e && e[0] == '1') ? 0 : 1; }
   return v == 1;
 }
+int stages_pref() {      // CLITE_IGEMM_STAGES=3|4 forces a ring depth (timing experiments); default: chosen per launch
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CLITE_IGEMM_STAGES"); v = e ? atoi(e) : 0; }
+  return v;
+}
 template <class L> struct ToDma;
 template <typename T, int ROWS, int BK, bool D> struct ToDma<GatherKC<T, ROWS, BK, D>> {
   typedef DmaKC<T, ROWS, BK, D> type;
@@ -67,8 +72,15 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
   if (use_dma()) {
     typedef typename ToDma<LA>::type DA;
     typedef typename ToDma<LB>::type DB;
-    hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, M, N,
-                       ktiles, per);
+    // a grid that gives each CU at most ~2 workgroups hides DMA latency with a deeper ring instead (4 stages x 16 KB = 64 KB)
+    constexpr int STAGE = DA::BYTES + DB::BYTES;
+    bool deep = 4 * STAGE <= 65536 && (long)tiles * splits <= 2 * 256 && per >= 4 && stages_pref() != 3;
+    if (deep || (stages_pref() == 4 && 4 * STAGE <= 65536))
+      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 4>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep,
+                         M, N, ktiles, per);
+    else
+      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep,
+                         M, N, ktiles, per);
   } else {
     hipLaunchKernelGGL((igemm_kernel<T, CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, M, N, ktiles, per);
   }

@@ -3,7 +3,7 @@
 // Operand tiles go global -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write), three LDS stages, one raw
 // s_barrier per K tile and a counted `s_waitcnt vmcnt(N)` that leaves the next tile's loads in flight across the barrier:
 //
-//   prologue: issue(t0 -> buf0), issue(t0+1 -> buf1)
+//   prologue: issue(t0 -> buf0), issue(t0+1 -> buf1)        (NSTAGE = 3; NSTAGE = 4 keeps one more tile in flight for small grids)
 //   for t:    vmcnt(loads of one tile)   // tile t landed (this wave's part) ...
 //             s_barrier                  // ... and everyone's part; also: everyone finished computing tile t-1
 //             issue(t+2 -> buf (t+2)%3)  // overwrites the buffer of tile t-1
@@ -255,12 +255,11 @@ template <typename T, int ROWS, int BK, bool D> struct DmaIssue<DmaKC<T, ROWS, B
   DEV static void go(const L& l, typename L::State& st, char* lds, int wave, int, int) { l.issue(st, lds, wave); }
 };
 
-template <typename T, class CFG, class LA, class LB>
+template <typename T, class CFG, class LA, class LB, int NSTAGE>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, int M, int N, int ktiles, int ktiles_per_split) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
-  constexpr int NSTAGE = 3;
   constexpr int SMEM = (NSTAGE * STAGE > CFG::EPI_BYTES) ? NSTAGE * STAGE : CFG::EPI_BYTES;
   constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
@@ -306,21 +305,24 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
     }
   }
 
-  // prologue: two tiles in flight
-  if (t_begin < t_end) {
-    DmaIssue<LA>::go(la, sa, smem, wave, lane, m0);
-    DmaIssue<LB>::go(lb, sb, smem + LA::BYTES, wave, lane, n0);
-  }
-  if (t_begin + 1 < t_end) {
-    DmaIssue<LA>::go(la, sa, smem + STAGE, wave, lane, m0);
-    DmaIssue<LB>::go(lb, sb, smem + STAGE + LA::BYTES, wave, lane, n0);
+  // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+  for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+    if (t_begin + pz < t_end) {
+      DmaIssue<LA>::go(la, sa, smem + pz * STAGE, wave, lane, m0);
+      DmaIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
+    }
   }
   int buf = 0;
   for (int t = t_begin; t < t_end; ++t) {
-    if (t + 1 < t_end) wait_vmcnt<LOADS_PER_TILE>(); else wait_vmcnt<0>();
+    // tile t has landed once at most min(NSTAGE-2, tiles after t) younger tiles are still outstanding
+    const int after = t_end - 1 - t;
+    if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LOADS_PER_TILE>();
+    else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
+    else wait_vmcnt<0>();
     barrier_raw();
-    if (t + 2 < t_end) {
-      int nb = buf + 2; if (nb >= NSTAGE) nb -= NSTAGE;
+    if (t + NSTAGE - 1 < t_end) {
+      int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
       DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
       DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
     }

@@ -36,8 +36,10 @@ def emulate(model):
 
 
 visual, mode, layers, B, S, Ls, idim = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
-M, Mo, Md, out, ref = run_case(visual, mode, layers, True, B, S, Ls, idim)
-Me = det_fill(O.build_oracle_model(visual, mode, max(layers, 1), dropout=0.0)).train()
+init = sys.argv[8] if len(sys.argv) > 8 else "det"
+M, Mo, Md, out, ref = run_case(visual, mode, layers, True, B, S, Ls, idim, init)
+Me = O.build_oracle_model(visual, mode, max(layers, 1), dropout=0.0).train()
+Me.load_state_dict(Mo.state_dict())
 for m in Me.modules():
     if isinstance(m, nn.ReLU):
         m.inplace = False
