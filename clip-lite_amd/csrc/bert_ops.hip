@@ -331,6 +331,212 @@ __global__ __launch_bounds__(64) void attention_bwd_kernel(const T* qkv, const i
   }
 }
 
+// ------------------------------------------------------------------------------------------------ attention on MFMA (bf16)
+// Same math as the VALU kernels above, on v_mfma_f32_32x32x16_bf16: one wave per (batch, head), the whole 32x32 score tile in
+// one accumulator. Forward keeps the KEY index in registers (S^T = K Q^T), so the softmax row reduction is over registers plus
+// one cross-half shuffle and the probabilities are directly the B operand of O^T = V^T P^T (accumulator-as-operand with its
+// permuted k order; V^T fragments come from ds_read_b64_tr_b16 with the same permutation). Backward keeps the key on the LANE
+// (S = Q K^T, dP = dO V^T), so P and dS are directly the B operands of dV^T = dO^T P and dK^T = Q^T dS; only dS crosses LDS once
+// (transposed) for dQ^T = K^T dS^T. Dropout masks use the same (seed, site, index) convention as the VALU kernels.
+constexpr int AM_PI = 192;   // [32][64] bf16 image pitch (128 B row + 64 B pad)
+constexpr int AM_PT = 80;    // [32][32] bf16 image pitch
+
+struct AmFwdSmem { char v[32 * AM_PI]; float madd[32]; };
+struct AmBwdSmem { char q[32 * AM_PI], k[32 * AM_PI], d[32 * AM_PI], t[32 * AM_PT]; float m[32 * 33]; float madd[32]; };
+
+DEV void am_load_image(const bf16* base, size_t ld, int L, char* img, int lane) {
+  for (int c = lane; c < 256; c += 64) {
+    int r = c >> 3, ch = c & 7;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < L) v = *(const u32x4*)(base + (size_t)r * ld + ch * 8);
+    *(u32x4*)(img + r * AM_PI + ch * 16) = v;
+  }
+}
+// row-major fragment straight from global memory: rows x = lane&31 (zero beyond L), k = 16*ks + 8*(lane>>5) + e
+DEV bf16x8 am_frag_rows(const bf16* base, size_t ld, int L, int ks, int lane) {
+  Chunk16 c;
+  c.u = u32x4{0u, 0u, 0u, 0u};
+  int r = lane & 31;
+  if (r < L) c.u = *(const u32x4*)(base + (size_t)r * ld + ks * 16 + 8 * (lane >> 5));
+  return c.h;
+}
+// transposed fragment from a [k][x] image, natural k order: k = 16*s + 8*(lane>>5) + e
+template <int PITCH> DEV bf16x8 am_frag_tr(const char* img, int x0, int s, int lane) {
+  int x = x0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  int k = 16 * s + 8 * (lane >> 5) + ((lane >> 2) & 3);
+  const char* p = img + k * PITCH + x * 2;
+  union { s16x4 v[2]; bf16x8 h; } u;
+  u.v[0] = lds_read_tr16(p);
+  u.v[1] = lds_read_tr16(p + 4 * PITCH);
+  return u.h;
+}
+// transposed fragment in the k order of an accumulator used as the other operand: element e of lane-half h <-> k = 16s + 8(e>>2) + 4h + (e&3)
+template <int PITCH> DEV bf16x8 am_frag_tr_acc(const char* img, int x0, int s, int lane) {
+  int x = x0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  int k = 16 * s + 4 * (lane >> 5) + ((lane >> 2) & 3);
+  const char* p = img + k * PITCH + x * 2;
+  union { s16x4 v[2]; bf16x8 h; } u;
+  u.v[0] = lds_read_tr16(p);
+  u.v[1] = lds_read_tr16(p + 8 * PITCH);
+  return u.h;
+}
+DEV bf16x8 am_acc_frag(const f32x16& a, int s) {
+  bf16x8 f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = f2bf(a[8 * s + e]);
+  return f;
+}
+DEV int am_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+// store an accumulator whose rows are d (32 per block) and whose column is a token (lane&31): 4 consecutive d per register group
+DEV void am_store_T(bf16* base, size_t ld, int L, int d0, const f32x16& a, float scale, int lane) {
+  int tok = lane & 31;
+  if (tok >= L) return;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    union { bf16 e[4]; u32x2 u; } pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk.e[e] = f2bf(a[4 * g + e] * scale);
+    *(u32x2*)(base + (size_t)tok * ld + d0 + 8 * g + 4 * (lane >> 5)) = pk.u;
+  }
+}
+
+__global__ __launch_bounds__(256) void attention_mfma_fwd_kernel(const bf16* qkv, const int64_t* mask, bf16* ctx, int B, int L, int H, Drop drop) {
+  __shared__ __attribute__((aligned(16))) AmFwdSmem sm[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bh = blockIdx.x * 4 + wave;
+  const bool live = bh < B * H;
+  if (!live) bh = B * H - 1;
+  const int b = bh / H, h = bh % H;
+  const size_t ld = (size_t)3 * H * 64;
+  const bf16* qb = qkv + (size_t)b * L * ld + h * 64;
+  AmFwdSmem& S = sm[wave];
+  am_load_image(qb + 2 * H * 64, ld, L, S.v, lane);
+  if (lane < 32) S.madd[lane] = (lane < L) ? ((mask && mask[(size_t)b * L + lane] == 0) ? AT_NEG : 0.f) : -INFINITY;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)      // S^T[j][i] = sum_d K[j][d] Q[i][d]
+    acc = mfma32_bf16(am_frag_rows(qb + H * 64, ld, L, ks, lane), am_frag_rows(qb, ld, L, ks, lane), acc);
+  __syncthreads();
+  // softmax over j (registers x the two lane halves) for the query i = lane&31
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = acc[r] * 0.125f + S.madd[am_row(r, lane)]; mx = fmaxf(mx, acc[r]); }
+  mx = fmaxf(mx, wave_shfl_xor(mx, 32));
+  float den = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = __expf(acc[r] - mx); den += acc[r]; }
+  den += wave_shfl_xor(den, 32);
+  const float inv = 1.0f / den;
+  const int i = lane & 31;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float u[4] = {1.f, 1.f, 1.f, 1.f};
+    if (drop.p > 0.f) rng_uniform4(drop.seed, drop.site, ((size_t)bh * AT_L + i) * AT_L + 8 * g + 4 * (lane >> 5), u);
+    const float ks = drop.p > 0.f ? 1.0f / (1.0f - drop.p) : 1.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[4 * g + e] *= inv * (u[e] >= drop.p ? ks : 0.f);
+  }
+  // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) o = mfma32_bf16(am_frag_tr_acc<AM_PI>(S.v, db * 32, s, lane), am_acc_frag(acc, s), o);
+    if (live) am_store_T(ctx + (size_t)b * L * ((size_t)H * 64) + h * 64, (size_t)H * 64, L, db * 32, o, 1.f, lane);
+  }
+}
+
+__global__ __launch_bounds__(128) void attention_mfma_bwd_kernel(const bf16* qkv, const int64_t* mask, const bf16* dctx, bf16* dqkv, int B, int L, int H, Drop drop) {
+  __shared__ __attribute__((aligned(16))) AmBwdSmem sm[2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bh = blockIdx.x * 2 + wave;
+  const bool live = bh < B * H;
+  if (!live) bh = B * H - 1;
+  const int b = bh / H, h = bh % H;
+  const size_t ld = (size_t)3 * H * 64, ldc = (size_t)H * 64;
+  const bf16* qb = qkv + (size_t)b * L * ld + h * 64;
+  const bf16* dob = dctx + (size_t)b * L * ldc + h * 64;
+  AmBwdSmem& S = sm[wave];
+  am_load_image(qb, ld, L, S.q, lane);
+  am_load_image(qb + H * 64, ld, L, S.k, lane);
+  am_load_image(dob, ldc, L, S.d, lane);
+  if (lane < 32) S.madd[lane] = (lane < L) ? ((mask && mask[(size_t)b * L + lane] == 0) ? AT_NEG : 0.f) : -INFINITY;
+  {   // dropout multipliers m[i][j]
+    const float ks = drop.p > 0.f ? 1.0f / (1.0f - drop.p) : 1.f;
+    for (int q4 = lane; q4 < 256; q4 += 64) {
+      int i = q4 >> 3, j0 = (q4 & 7) * 4;
+      float u[4] = {1.f, 1.f, 1.f, 1.f};
+      if (drop.p > 0.f) rng_uniform4(drop.seed, drop.site, ((size_t)bh * AT_L + i) * AT_L + j0, u);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) S.m[i * 33 + j0 + e] = u[e] >= drop.p ? ks : 0.f;
+    }
+  }
+  f32x16 p, dp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { p[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    p = mfma32_bf16(am_frag_rows(qb, ld, L, ks, lane), am_frag_rows(qb + H * 64, ld, L, ks, lane), p);            // S[i][j]
+    dp = mfma32_bf16(am_frag_rows(dob, ldc, L, ks, lane), am_frag_rows(qb + 2 * H * 64, ld, L, ks, lane), dp);    // dP[i][j] = dO V^T
+  }
+  __syncthreads();
+  const int j = lane & 31;
+  const float madd = S.madd[j];
+  f32x16 pd, ds;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {      // softmax over j = across the 32 lanes of a half, per register row i
+    float s = p[r] * 0.125f + madd;
+    float mx = s;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) mx = fmaxf(mx, wave_shfl_xor(mx, m));
+    float e = __expf(s - mx);
+    float den = e;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) den += wave_shfl_xor(den, m);
+    int i = am_row(r, lane);
+    float pr = (i < L) ? e / den : 0.f;
+    float mul = S.m[i * 33 + j];
+    float dpd = dp[r] * mul;
+    float t = dpd * pr;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) t += wave_shfl_xor(t, m);
+    p[r] = pr;
+    pd[r] = pr * mul;
+    ds[r] = pr * (dpd - t);
+  }
+  // dS^T image for dQ: T[j][i] = dS[i][j]
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    union { bf16 e[4]; u32x2 u; } pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk.e[e] = f2bf(ds[4 * g + e]);
+    *(u32x2*)(S.t + j * AM_PT + (8 * g + 4 * (lane >> 5)) * 2) = pk.u;
+  }
+  __syncthreads();
+  bf16* ob = dqkv + (size_t)b * L * ld + h * 64;
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    f32x16 dv, dk, dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; dq[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      dv = mfma32_bf16(am_frag_tr_acc<AM_PI>(S.d, db * 32, s, lane), am_acc_frag(pd, s), dv);      // dV^T[d][j] = sum_i dO^T[d][i] Pd[i][j]
+      dk = mfma32_bf16(am_frag_tr_acc<AM_PI>(S.q, db * 32, s, lane), am_acc_frag(ds, s), dk);      // dK^T[d][j] = sum_i Q^T[d][i] dS[i][j]
+      dq = mfma32_bf16(am_frag_tr<AM_PI>(S.k, db * 32, s, lane), am_frag_tr<AM_PT>(S.t, 0, s, lane), dq);   // dQ^T[d][i] = sum_j K^T[d][j] dS^T[j][i]
+    }
+    if (live) {
+      am_store_T(ob + 2 * H * 64, ld, L, db * 32, dv, 1.f, lane);
+      am_store_T(ob + H * 64, ld, L, db * 32, dk, 0.125f, lane);
+      am_store_T(ob, ld, L, db * 32, dq, 0.125f, lane);
+    }
+  }
+}
+
 // BertPooler backward through tanh: out = dy * (1 - y^2)
 template <typename T>
 __global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* dy, const T* y, T* out, size_t n8) {
@@ -416,7 +622,7 @@ extern "C" int clite_attention_fwd(int dtype, const void* qkv, const int64_t* ma
   Drop d{drop_p, drop_seed, drop_site};
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(attention_fwd_kernel<bf16>, dim3(B * H), dim3(64), 0, st, (const bf16*)qkv, mask, (bf16*)ctx, B, L, H, d),
+           hipLaunchKernelGGL(attention_mfma_fwd_kernel, dim3((B * H + 3) / 4), dim3(256), 0, st, (const bf16*)qkv, mask, (bf16*)ctx, B, L, H, d),
            hipLaunchKernelGGL(attention_fwd_kernel<float>, dim3(B * H), dim3(64), 0, st, (const float*)qkv, mask, (float*)ctx, B, L, H, d));
   return (int)hipGetLastError();
 }
@@ -427,7 +633,7 @@ extern "C" int clite_attention_bwd(int dtype, const void* qkv, const int64_t* ma
   Drop d{drop_p, drop_seed, drop_site};
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(attention_bwd_kernel<bf16>, dim3(B * H), dim3(64), 0, st, (const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, H, d),
+           hipLaunchKernelGGL(attention_mfma_bwd_kernel, dim3((B * H + 1) / 2), dim3(128), 0, st, (const bf16*)qkv, mask, (const bf16*)dctx, (bf16*)dqkv, B, L, H, d),
            hipLaunchKernelGGL(attention_bwd_kernel<float>, dim3(B * H), dim3(64), 0, st, (const float*)qkv, mask, (const float*)dctx, (float*)dqkv, B, L, H, d));
   return (int)hipGetLastError();
 }

@@ -366,24 +366,38 @@ __global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* img, T
   }
 }
 
-// out[c] += sum_m x[m][c]  (bias gradients). grid = (ceil(N/8/256), row slabs)
+// out[c] += sum_m x[m][c]  (bias gradients). Workgroup = 32 column chunks (256 columns) x 8 row lanes; grid = (column
+// groups, row slabs); the 8 row lanes fold through LDS and every slab ends in one float atomic per column.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int M, int N, int rows_per_block) {
-  int chunk = blockIdx.x * 256 + threadIdx.x;
-  if (chunk >= N / 8) return;
+  __shared__ float red[8][32 * 8];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int chunk = blockIdx.x * 32 + cx;
+  const bool cvalid = chunk < N / 8;
   int row_begin = blockIdx.y * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > M) row_end = M;
   float acc[8];
   zero8(acc);
+  if (cvalid) {
 #pragma unroll 4
-  for (int r = row_begin; r < row_end; ++r) {
-    float v[8];
-    load8(x + (size_t)r * N + chunk * 8, v);
+    for (int r = row_begin + ry; r < row_end; r += 8) {
+      float v[8];
+      load8(x + (size_t)r * N + chunk * 8, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) atomic_add_f32(out + chunk * 8 + e, acc[e]);
+  for (int e = 0; e < 8; ++e) red[ry][cx * 8 + e] = acc[e];
+  __syncthreads();
+  int col = threadIdx.x;                       // 256 columns of this group
+  int gcol = blockIdx.x * 256 + col;
+  if (gcol < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][col];
+    atomic_add_f32(out + gcol, s);
+  }
 }
 
 int ew_grid(size_t total) {
@@ -496,9 +510,10 @@ extern "C" int clite_image_to_nhwc4(int dtype, const float* img, void* out, int 
 
 extern "C" int clite_colsum(int dtype, const void* x, float* out, int M, int N, void* stream) {
   if (M <= 0 || N <= 0 || N % 8) return -1;
-  int gx = (N / 8 + 255) / 256;
-  int slabs = 96 / gx;            // every slab ends in one float atomic per column: keep same-address adds to a few dozen
-  if (slabs < 16) slabs = 16;
+  int gx = (N / 8 + 31) / 32;
+  int slabs = 256 / gx;           // ~256 workgroups; every slab ends in one float atomic per column (a few dozen per address)
+  if (slabs < 8) slabs = 8;
+  if (slabs > 64) slabs = 64;
   if (slabs > M) slabs = M;
   int rpb = (M + slabs - 1) / slabs;
   slabs = (M + rpb - 1) / rpb;

@@ -1,0 +1,178 @@
+"""GPU tests of the update path and the step glue (through the C ABI): fused clip + SGD + Lookahead against the oracle's
+torch.optim.SGD + Lookahead restatement over several steps (covers the lr-0 first step, the Lookahead sync at step 5 and a step
+where clipping is active), checkpoint save / resume equivalence (reference utils/checkpointing.py layout), dropout statistics,
+eval mode, and the gradient-exchange stream logic forced on a single rank."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from detfill import det_fill, det_tensor
+from oracle import ref_model as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(lowp=False, layers=1, mode="sbert"):
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    te = TextEncoder(mode=mode, num_hidden_layers=layers)
+    if mode == "train_sbert":
+        te.strans.hidden_dropout_prob = te.strans.attention_probs_dropout_prob = 0.0
+    M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), mode, is_amp=lowp)).to("cuda").train()
+    Mo = det_fill(O.build_oracle_model("resnet18", mode, layers, dropout=0.0)).train()
+    return M, Mo
+
+
+def _optim(M, k=5):
+    from clip_lite_amd.optim import FusedSGD, Lookahead
+    groups = [{"params": [p], "lr": 0.2 if "image_encoder" in n else 1e-3, "weight_decay": 1e-4} for n, p in M.named_parameters()]
+    return Lookahead(FusedSGD(groups, momentum=0.9), k=k, alpha=0.5)
+
+
+def _batch(i, B=4, S=64):
+    return {"image": det_tensor(f"img{i}", (B, 3, S, S), "normal"), "caption_encodings": det_tensor(f"cap{i}", (B, 768), "normal")}
+
+
+def test_six_train_steps_match_oracle():
+    """reference train.py:211-226 semantics, fp32 mode. Tolerance: parameters after 6 steps within 2e-4 of max|param| per tensor
+    (gradient differences of ~1e-3 relative are scaled by lr <= 0.2 * schedule multiplier)."""
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    M, Mo = _models()
+    opt = _optim(M)
+    sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
+    opt_o = O.build_optimizer(Mo.named_parameters(), cnn_lr=0.2, trans_lr=1e-3, lr=1e-3, k=5, alpha=0.5)
+    for step in range(6):
+        b = _batch(step)
+        u = (det_tensor(f"u1{step}", (4, 512), "uniform"), det_tensor(f"u2{step}", (4, 768), "uniform"))
+        M.loss.set_prior_noise(u[0].cuda(), u[1].cuda())
+        Mo.loss.noise = u
+        opt.zero_grad()
+        out = M({k: v.cuda() for k, v in b.items()})
+        out["loss"].backward()
+        opt.clip_grad_norm(0.5 if step == 2 else 10.0)      # step 2: clipping certainly active
+        opt.step()
+        sched.step()
+        ref, _ = O.train_step(Mo, opt_o, b, step, sched=("cosine", 40, 3, 0.0), clip=0.5 if step == 2 else 10.0)
+        assert abs(out["loss"].item() - ref["loss"].item()) < 2e-4, (step, out["loss"].item(), ref["loss"].item())
+    so = Mo.state_dict()
+    for k, v in M.state_dict().items():
+        if v.dtype.is_floating_point:
+            err = (v.float().cpu() - so[k]).abs().max().item()
+            assert err <= 2e-4 * max(so[k].abs().max().item(), 1.0), (k, err)
+    assert not M.runtime.arena.flat_g.any()          # the update kernel zeroed the gradients
+
+
+def test_checkpoint_resume_equivalence(tmp_path):
+    """Train 2 steps, checkpoint ({model, optimizer, scheduler, scaler, iteration}), train 2 more; a fresh process state restored
+    from the checkpoint must reproduce the same parameters after the same 2 steps (Lookahead slow weights are re-seeded from the
+    fast weights on load, like reference optim/lookahead.py:68-78, so k is chosen larger than the horizon)."""
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    from clip_lite_amd.utils.checkpointing import CheckpointManager
+    from clip_lite_amd.utils.common import GradScaler
+
+    def run(M, opt, sched, steps):
+        for s in steps:
+            M.loss.set_prior_noise(det_tensor(f"u1{s}", (4, 512), "uniform").cuda(), det_tensor(f"u2{s}", (4, 768), "uniform").cuda())
+            opt.zero_grad()
+            M({k: v.cuda() for k, v in _batch(s).items()})["loss"].backward()
+            opt.clip_grad_norm(10.0)
+            opt.step()
+            sched.step()
+
+    M, _ = _models()
+    opt = _optim(M, k=50)
+    sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
+    run(M, opt, sched, [0, 1])
+    cm = CheckpointManager(str(tmp_path), model=M, optimizer=opt, scheduler=sched, scaler=GradScaler())
+    cm.step(2)
+    ck = torch.load(tmp_path / "checkpoint_2.pth", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "scheduler", "scaler", "iteration"}
+    assert "momentum_buffer" in ck["optimizer"]["state"][0] and ck["model"]["image_encoder.img_encoder.conv1.weight"].shape == (64, 3, 7, 7)
+    run(M, opt, sched, [2, 3])
+    want = {k: v.float().cpu().clone() for k, v in M.state_dict().items()}
+
+    M2, _ = _models()
+    with torch.no_grad():
+        for p in M2.parameters():
+            p.add_(0.123)                       # make sure the load really restores
+    opt2 = _optim(M2, k=50)
+    sched2 = LinearWarmupCosineAnnealingLR(opt2, total_steps=40, warmup_steps=3)
+    it = CheckpointManager(model=M2, optimizer=opt2, scheduler=sched2, scaler=GradScaler()).load(str(tmp_path / "checkpoint_2.pth"))
+    assert it == 2
+    run(M2, opt2, sched2, [2, 3])
+    for k, v in M2.state_dict().items():
+        assert torch.allclose(v.float().cpu(), want[k], rtol=1e-5, atol=1e-6), k
+
+
+def test_eval_mode_and_projection_heads():
+    """eval(): BatchNorm uses running statistics, no dropout, buffers untouched; `loss.global_d.img_block` works as the stand-alone
+    projector the eval CLIs use (reference retrieval.py:70-74)."""
+    M, Mo = _models()
+    M.eval(); Mo.eval()
+    b = _batch(0)
+    u = (det_tensor("u1", (4, 512), "uniform"), det_tensor("u2", (4, 768), "uniform"))
+    M.loss.set_prior_noise(u[0].cuda(), u[1].cuda())
+    Mo.loss.noise = u
+    before = {k: v.clone() for k, v in M.state_dict().items() if "running" in k or "num_batches" in k}
+    with torch.no_grad():
+        out = M({k: v.cuda() for k, v in b.items()})
+        ref = Mo(b)
+        feats = M.image_encoder(b["image"].cuda())
+        proj = M.loss.global_d.img_block(feats)
+        pref = Mo.loss.global_d.img_block(Mo.image_encoder(b["image"]))
+    assert abs(out["loss"].item() - ref["loss"].item()) < 1e-4
+    assert torch.allclose(proj.float().cpu(), pref, rtol=1e-3, atol=1e-4)
+    for k, v in M.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k
+
+
+def test_dropout_is_active_reproducible_and_unbiased():
+    from clip_lite_amd import hip
+    M, C = 512, 768
+    x = torch.randn(M, C, device="cuda")
+    g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    out1, out2, st = torch.empty_like(x), torch.empty_like(x), torch.empty(M, 2, device="cuda")
+    hip.layernorm_fwd(hip.F32, x, g, b, 1e-12, out1, st, M, C, (0.1, 123, 5))
+    hip.layernorm_fwd(hip.F32, x, g, b, 1e-12, out2, st, M, C, (0.1, 123, 5))
+    assert torch.equal(out1, out2)
+    keep = (out1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    ref = torch.nn.functional.layer_norm(x, (C,))
+    assert abs((out1.sum() / ref.abs().sum()).item()) < 0.05 and abs((out1[out1 != 0] / ref[out1 != 0]).mean().item() - 1 / 0.9) < 1e-3
+    hip.layernorm_fwd(hip.F32, x, g, b, 1e-12, out2, st, M, C, (0.1, 124, 5))
+    assert not torch.equal(out1, out2)
+
+
+def test_gradient_exchange_stream_logic_single_rank():
+    """The overlapped exchange (side stream, regions reported from inside backward) forced on with world_size 1: an all-reduce over
+    one rank is the identity, so two steps must give bit-identical parameters with and without it."""
+    import torch.distributed as tdist
+    from clip_lite_amd.utils import distributed as D
+    if not tdist.is_initialized():
+        tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1)
+    res = []
+    for use in (False, True):
+        M, _ = _models(lowp=True)
+        opt = _optim(M)
+        ex = None
+        if use:
+            ex = D.GradientExchange(M.runtime.arena, bucket_elems=1 << 20)
+            ex.world = 2                      # pretend: exercise the send path (SUM over the single real rank)
+            M.runtime.exchange = ex
+        for s in range(2):
+            M.loss.set_prior_noise(det_tensor(f"u1{s}", (4, 512), "uniform").cuda(), det_tensor(f"u2{s}", (4, 768), "uniform").cuda())
+            opt.zero_grad()
+            M({k: v.cuda() for k, v in _batch(s).items()})["loss"].backward()
+            if ex is not None:
+                assert ex.finish() == 0.5
+                assert not ex._pending and not ex._covered
+            opt.clip_grad_norm(10.0)
+            opt.step()
+        torch.cuda.synchronize()
+        res.append(M.runtime.arena.flat_p.clone())
+    assert torch.equal(res[0], res[1])
+    tdist.destroy_process_group()
