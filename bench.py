@@ -176,11 +176,12 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = t.item()
     loss = out["loss"].item()
+    # every rank runs the instrumented steps (they contain the gradient exchange, a collective); rank 0 reports its timings
+    gemm_ms, n_launch = kernel_roofline(step, batches)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
-        gemm_ms, n_launch = kernel_roofline(step, batches)
         gemm_tflops = FLOP_PER_PAIR * args.batch / (gemm_ms * 1e-3) / 1e12 if args.visual == "resnet50" and args.layers == 12 else None
         res = {
             "metric": "image-caption pairs/sec (global batch) — ResNet-50+BERT bs1024, 1/2/4/8 MI355X",

@@ -12,6 +12,36 @@ namespace {
 
 struct BnCoef { float a[8], b[8]; };
 
+// Fold NV per-thread partial sums over all threads of the workgroup that own the same 8-channel chunk (threads tid with equal
+// tid % CPR), leaving the total in the threads with tid < CPR (CPR <= 64) or, for CPR > 64, in the threads of wave 0..(CPR/64-1)
+// that own distinct chunks. Lanes of one wave that share a chunk are CPR apart -> xor-shuffle tree; the 4 waves meet in LDS.
+template <int NV>
+DEV bool chunk_fold(float (&v)[NV], int CPR, float* red /* [4][64][NV] */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int m = 32; m >= CPR && m >= 1; m >>= 1) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] += wave_shfl_xor(v[e], m);
+  }
+  // after the tree, lanes 0..min(CPR,64)-1 of every wave hold that wave's totals for chunk (wave*64 + lane) % CPR
+#pragma unroll
+  for (int e = 0; e < NV; ++e) red[(wave * 64 + lane) * NV + e] = v[e];
+  __syncthreads();
+  if (CPR <= 64) {
+    if (tid >= CPR) return false;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = red[tid * NV + e] + red[(64 + tid) * NV + e] + red[(128 + tid) * NV + e] + red[(192 + tid) * NV + e];
+    return true;
+  }
+  // CPR = 128: waves 0,2 and 1,3 own the same chunks; CPR = 256: every thread owns a distinct chunk
+  if (CPR == 128) {
+    if (tid >= 128) return false;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) v[e] = red[tid * NV + e] + red[(128 + tid) * NV + e];
+    return true;
+  }
+  return true;
+}
+
 // sum of the R partial accumulators of 8 consecutive channels of one statistic (32-byte vector loads)
 DEV void rsum8(const float* p, int replicas, int rstride, float (&s)[8]) {
   load8(p, s);
@@ -52,7 +82,7 @@ DEV void bn_coef(const float* stats, int R, int RS, const float* gamma, const fl
 
 // out = relu?( y*a + b  [+ res | + res*a' + b'] ).  Workgroup = 256 threads = (256/CPR) rows x CPR 8-channel chunks.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, const T* res, T* out, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
   const float inv_count = 1.0f / (float)p.M;
@@ -76,6 +106,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, c
   }
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > p.M) row_end = p.M;
+#pragma unroll 4
   for (int r = row_begin + r0; r < row_end; r += RPS) {
     size_t idx = (size_t)r * p.C + c0;
     float v[8];
@@ -104,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* y, c
 // dstats[0][c] += sum dz, dstats[1][c] += sum dz*(y - mean_c), with dz = dout * (mask > 0) and mean_c = stats[0][c]/M.
 // Centering y here (instead of forming sum dz*y - mean*sum dz afterwards) avoids cancellation on channels with |mean| >> std.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const T* mask, const T* y, const float* stats, float* dstats, int R, int RS, int M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ mask, const T* __restrict__ y, const float* stats, float* dstats, int R, int RS, int M, int C, int rows_per_block) {
   __shared__ float red[256 * 16];
   const int CPR = C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
@@ -115,6 +146,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const
   for (int e = 0; e < 8; ++e) mean[e] /= (float)M;
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > M) row_end = M;
+#pragma unroll 4
   for (int r = row_begin + r0; r < row_end; r += RPS) {
     size_t idx = (size_t)r * C + c0;
     float d[8], yv[8];
@@ -129,21 +161,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* dout, const
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] += d[e]; s2[e] += d[e] * (yv[e] - mean[e]); }
   }
+  float v[16];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = s1[e]; red[tid * 16 + 8 + e] = s2[e]; }
-  __syncthreads();
-  if (r0 == 0) {
-    for (int e = 0; e < 16; ++e) {
-      float s = 0.f;
-      for (int r = 0; r < RPS; ++r) s += red[(r * CPR + cc) * 16 + e];
-      atomic_add_f32(dstats + (size_t)(blockIdx.x % R) * RS + (e >= 8 ? C : 0) + c0 + (e & 7), s);
-    }
+  for (int e = 0; e < 8; ++e) { v[e] = s1[e]; v[8 + e] = s2[e]; }
+  if (chunk_fold<16>(v, CPR, red)) {
+    float* dst = dstats + (size_t)(blockIdx.x % R) * RS + c0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { atomic_add_f32(dst + e, v[e]); atomic_add_f32(dst + C + e, v[8 + e]); }
   }
 }
 
 // second pass of a two-pass variance: stats[2][c] += sum (y - mean_c)^2 with mean_c = stats[0][c] / M
 template <typename T>
-__global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* y, float* stats, int R, int RS, int M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* __restrict__ y, float* stats, int R, int RS, int M, int C, int rows_per_block) {
   __shared__ float red[256 * 8];
   const int CPR = C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
@@ -154,28 +184,24 @@ __global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* y, float*
   for (int e = 0; e < 8; ++e) { mean[e] *= inv_count; s[e] = 0.f; }
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > M) row_end = M;
+#pragma unroll 4
   for (int r = row_begin + r0; r < row_end; r += RPS) {
     float v[8];
     load8(y + (size_t)r * C + c0, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) { float d = v[e] - mean[e]; s[e] += d * d; }
   }
+  if (chunk_fold<8>(s, CPR, red)) {
+    float* dst = stats + (size_t)(blockIdx.x % R) * RS + 2 * C + c0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[tid * 8 + e] = s[e];
-  __syncthreads();
-  if (r0 == 0) {
-    for (int e = 0; e < 8; ++e) {
-      float t = 0.f;
-      for (int r = 0; r < RPS; ++r) t += red[(r * CPR + cc) * 8 + e];
-      atomic_add_f32(stats + (size_t)(blockIdx.x % R) * RS + 2 * C + c0 + e, t);
-    }
+    for (int e = 0; e < 8; ++e) atomic_add_f32(dst + e, s[e]);
   }
 }
 
 // dy = gamma*rstd*(dz - S1/M - xhat*G/M), G = sum dz*xhat = rstd*S2 (S2 = sum dz*(y-mean) from the reduce kernel); dgamma += G, dbeta += S1
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* dout, const T* mask, const T* y, const float* dstats,
-                                                           T* dy, T* dz_out, float* dgamma, float* dbeta, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* __restrict__ dout, const T* __restrict__ mask, const T* __restrict__ y, const float* dstats,
+                                                           T* __restrict__ dy, T* __restrict__ dz_out, float* dgamma, float* dbeta, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
   const float inv_count = 1.0f / (float)p.M;
@@ -204,6 +230,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
   }
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > p.M) row_end = p.M;
+#pragma unroll 4
   for (int r = row_begin + r0; r < row_end; r += RPS) {
     size_t idx = (size_t)r * p.C + c0;
     float d[8], yv[8];
