@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--f32", action="store_true", help="exact-f32 parity kernels instead of bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL over xGMI); gloo is for single-GPU logic tests")
+    ap.add_argument("--single-device", action="store_true", help="logic test only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,15 +142,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        tdist.init_process_group(backend="nccl", init_method="env://")
+        tdist.init_process_group(backend=args.backend, init_method="env://")
 
     from clip_lite_amd.train_loop import TrainStep
     from clip_lite_amd.utils import distributed as cdist
     from clip_lite_amd.utils.common import GradScaler
-    model, opt, sched = build(args, device)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the encoders print a construction banner like the reference's; keep stdout = the JSON line
+        model, opt, sched = build(args, device)
     cdist.broadcast_parameters(model)
     exchange = None
     if world > 1:
