@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--f32", action="store_true", help="exact-f32 parity kernels instead of bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL over xGMI); gloo is for single-GPU logic tests")
     ap.add_argument("--single-device", action="store_true", help="logic test only: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
@@ -160,10 +161,11 @@ def main():
     if world > 1:
         exchange = cdist.GradientExchange(model.runtime.arena)
         model.runtime.exchange = exchange
-    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange)
+    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange, graph=not args.no_graph)
+    eager_step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange)      # per-launch timing needs eager launches
     batches = synthetic_batches(args, device, rank)
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 3 if step.graph else 0)):      # graph mode: 2 eager steps, then the capture + first replay
         step(batches[i % len(batches)])
     torch.cuda.synchronize()
     if world > 1:
@@ -183,7 +185,7 @@ def main():
         dt = t.item()
     loss = out["loss"].item()
     # every rank runs the instrumented steps (they contain the gradient exchange, a collective); rank 0 reports its timings
-    gemm_ms, n_launch = kernel_roofline(step, batches)
+    gemm_ms, n_launch = kernel_roofline(eager_step, batches)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -197,7 +199,7 @@ def main():
             "config": {"workload": f"{args.visual} + BERT-base({args.layers}L) + JSD-MI heads/priors, per-GPU batch {args.batch}, 224x224 images, "
                                    f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-            "loss": loss,
+            "loss": loss, "launch": "hipGraph replay" if step.graph else "eager",
             "roofline": {"bound": "mfma", "kernel": "clite::igemm_kernel (all conv/linear fwd+dgrad+wgrad launches of one step)",
                          "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": None,

@@ -26,6 +26,7 @@ DEV void apply_dropout8(const Drop& d, size_t idx, float (&v)[8]) {
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, float eps, T* out,
                                                             float* stats, int M, int C, Drop drop) {
+  seed_resolve(drop.seed, drop.site);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = C / 8;
   const float invC = 1.0f / (float)C;
@@ -75,6 +76,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_masked,
                                                             float* dgamma, float* dbeta, int M, int C, Drop drop_in, Drop drop_out) {
+  seed_resolve(drop_in.seed, drop_in.site);
+  seed_resolve(drop_out.seed, drop_out.site);
   __shared__ float red[4][64 * LN_MAXCH * 8];   // [wave][per-lane partials], used once for dgamma and once for dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = C / 8;
@@ -260,6 +263,7 @@ DEV void attn_probs(AttnSmem& sm, const int64_t* mask_row, int L, int lane) {
 
 template <typename T>
 __global__ __launch_bounds__(64) void attention_fwd_kernel(const T* qkv, const int64_t* mask, T* ctx, int B, int L, int H, Drop drop) {
+  seed_resolve(drop.seed, drop.site);
   __shared__ AttnSmem sm;
   const int lane = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -287,6 +291,7 @@ struct AttnBwdSmem {
 
 template <typename T>
 __global__ __launch_bounds__(64) void attention_bwd_kernel(const T* qkv, const int64_t* mask, const T* dctx, T* dqkv, int B, int L, int H, Drop drop) {
+  seed_resolve(drop.seed, drop.site);
   __shared__ AttnBwdSmem sm;
   const int lane = threadIdx.x;
   const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -401,6 +406,7 @@ DEV void am_store_T(bf16* base, size_t ld, int L, int d0, const f32x16& a, float
 }
 
 __global__ __launch_bounds__(256) void attention_mfma_fwd_kernel(const bf16* qkv, const int64_t* mask, bf16* ctx, int B, int L, int H, Drop drop) {
+  seed_resolve(drop.seed, drop.site);
   __shared__ __attribute__((aligned(16))) AmFwdSmem sm[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int bh = blockIdx.x * 4 + wave;
@@ -451,6 +457,7 @@ __global__ __launch_bounds__(256) void attention_mfma_fwd_kernel(const bf16* qkv
 }
 
 __global__ __launch_bounds__(128) void attention_mfma_bwd_kernel(const bf16* qkv, const int64_t* mask, const bf16* dctx, bf16* dqkv, int B, int L, int H, Drop drop) {
+  seed_resolve(drop.seed, drop.site);
   __shared__ __attribute__((aligned(16))) AmBwdSmem sm[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int bh = blockIdx.x * 2 + wave;

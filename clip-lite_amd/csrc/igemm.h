@@ -304,6 +304,9 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cha
   const int ecol = (tid % CPRE) * 8;
   const int erow0 = tid / CPRE;
   const float keep_scale = ep.drop_p > 0.f ? 1.0f / (1.0f - ep.drop_p) : 1.0f;
+  uint64_t drop_seed = ep.drop_seed;
+  uint32_t drop_site = ep.drop_site;
+  if (ep.drop_p > 0.f) seed_resolve(drop_seed, drop_site);
   float csum[8], csq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; }
@@ -359,7 +362,7 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cha
         }
         if (ep.drop_p > 0.f) {
           float u[8];
-          dropout_uniform8(ep.drop_seed, ep.drop_site, gidx, u);
+          dropout_uniform8(drop_seed, drop_site, gidx, u);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = u[e] >= ep.drop_p ? v[e] * keep_scale : 0.f;
         }

@@ -157,6 +157,7 @@ __global__ void loss_finalize_kernel(const float* acc, float prior_weight, float
 
 template <typename T>
 __global__ __launch_bounds__(256) void uniform_fill_kernel(T* out, size_t n, uint64_t seed, uint32_t site) {
+  seed_resolve(seed, site);
   size_t nch = n / 8;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nch; i += (size_t)gridDim.x * 256) {
     float u[8];

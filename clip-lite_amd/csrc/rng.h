@@ -26,6 +26,15 @@ DEV Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
   return o;
 }
 
+// CLITE_SEED_INDIRECT (include/clite.h): a site with bit 31 set means the seed argument is the device address of a uint64
+// holding the seed (wave-uniform scalar load), so a captured hipGraph re-reads the seed of the current step at every replay.
+DEV void seed_resolve(uint64_t& seed, uint32_t& site) {
+  if (site & 0x80000000u) {
+    seed = *(const uint64_t*)(uintptr_t)seed;
+    site &= 0x7fffffffu;
+  }
+}
+
 DEV float u32_to_unit(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 
 // uniforms for elements idx..idx+3 (idx % 4 == 0)

@@ -15,6 +15,7 @@ ABI_VERSION = 1
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 DACT_RELU, DACT_GELU, DACT_TANH = 1, 2, 3
+SEED_INDIRECT = 0x80000000   # OR-ed into a dropout site: the seed argument is the device address of a uint64 (CLITE_SEED_INDIRECT)
 
 TORCH_DTYPE = {BF16: torch.bfloat16, F32: torch.float32}
 

@@ -87,14 +87,25 @@ class FusedSGD(torch.optim.Optimizer):
     def step(self, closure=None, lookahead_sync=False, alpha=1.0):
         if self.before_step is not None:
             self.before_step()
-        self._build_items()
+        self.upload_hp(lookahead_sync, alpha)
+        self.launch()
+        self.max_norm = 0.0
+        return None
+
+    # step() = upload_hp() + launch(). A captured hipGraph of the train step contains only launch() (and the sumsq of
+    # clip_grad_norm); the host uploads this step's hyper-parameters into `hp` before every replay.
+    def upload_hp(self, lookahead_sync=False, alpha=1.0, max_norm=None):
+        """Host -> device: (lr multiplier of the schedule, momentum, clip norm, Lookahead sync flag, alpha, gradient pre-scale)."""
         mom = self.param_groups[0]["momentum"]
-        self.hp.copy_(torch.tensor([self._lr_mult(), mom, self.max_norm, 1.0 if lookahead_sync else 0.0, alpha, self.grad_prescale, 0, 0]))
+        mn = self.max_norm if max_norm is None else float(max_norm)
+        self.hp.copy_(torch.tensor([self._lr_mult(), mom, mn, 1.0 if lookahead_sync else 0.0, alpha, self.grad_prescale, 0, 0]), non_blocking=True)
+
+    @torch.no_grad()
+    def launch(self):
+        self._build_items()
         hip.sgd_step(self.arena.flat_p, self.arena.flat_g, self.flat_v, self.flat_slow, self.arena.flat_lp,
                      C.c_void_p(self._items.data_ptr()), self._n_items, self.hp, self.sumsq)
-        self.max_norm = 0.0
         self._dirty = False
-        return None
 
     # -- torch.optim.SGD-compatible checkpoint layout -----------------------------------------------------------------
     def state_dict(self):
@@ -155,12 +166,16 @@ class Lookahead(object):
         self.optimizer.load_state_dict(state_dict)
         self.optimizer.flat_slow.copy_(self.optimizer.arena.flat_p)      # reference lookahead.py:73-78
 
-    def step(self, closure: Callable = None):
+    def advance(self) -> bool:
+        """Count one fast step; True when this step ends with the slow-weight synchronisation (reference lookahead.py:88-101)."""
         self._k_counter += 1
         sync = self._k_counter >= self.k
         if sync:
             self._k_counter = 0
-        return self.optimizer.step(closure, lookahead_sync=sync, alpha=self.alpha)
+        return sync
+
+    def step(self, closure: Callable = None):
+        return self.optimizer.step(closure, lookahead_sync=self.advance(), alpha=self.alpha)
 
     def load_slow_weights(self):
         a = self.optimizer.arena

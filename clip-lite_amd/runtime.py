@@ -108,15 +108,18 @@ class Arena:
 
 
 class StepState:
-    """Per-forward kernel state: dropout seed of this step and a bump allocator of dropout sites."""
+    """Per-forward kernel state: dropout seed of this step and a bump allocator of dropout sites. With `indirect` the seed
+    is the device address of a uint64 (hip.SEED_INDIRECT is OR-ed into every site), which is how a captured hipGraph of the
+    step sees a fresh seed at every replay."""
 
-    def __init__(self, seed, training):
+    def __init__(self, seed, training, indirect=False):
         self.seed, self.training = seed, training
         self._site = 0
+        self._flag = hip.SEED_INDIRECT if indirect else 0
 
     def site(self):
         self._site += 1
-        return self._site
+        return self._site | self._flag
 
 
 class ZeroPool:
@@ -158,6 +161,7 @@ class DeviceRuntime:
         self.exchange = None
         self._spans = {}
         self.steps = 0
+        self.seed_dev, self._capturing, self._slots, self.graph_slots, self._graph_next = None, False, 0, 0, -1
         # flatten num_batches_tracked buffers per top-level owner
         self.counters = {}
         owners = {}
@@ -194,6 +198,42 @@ class DeviceRuntime:
         if owner in self.counters:
             self.counters[owner] += n
 
+    # -- dropout / prior-noise seeds ---------------------------------------------------------------------------------------
+    # Eager: the k-th forward executor of the process gets seed base*1000003 + k by value. Captured (hipGraph) steps read the
+    # same sequence from `seed_dev`: slot j of the captured step holds the seed of its j-th executor, and the graph's last node
+    # advances every slot by the number of slots, so eager and replayed steps draw identical masks.
+    SEED_SLOTS = 16
+
     def next_step(self, training):
+        if self._capturing:
+            j = self._slots
+            self._slots += 1
+            assert j < self.SEED_SLOTS
+            return StepState(self.seed_dev.data_ptr() + 8 * j, training, indirect=True)
         self.steps += 1
         return StepState(self.base_seed * 1000003 + self.steps, training)
+
+    def begin_capture(self):
+        if self.seed_dev is None:
+            self.seed_dev = torch.zeros(self.SEED_SLOTS, device=self.device, dtype=torch.int64)
+        self._capturing, self._slots = True, 0
+        self._saved_zpool, self.zpool = self.zpool, ZeroPool(self.device)
+
+    def end_capture(self):
+        """Call inside the capture, after the last kernel of the step: advances the device seeds for the next replay."""
+        self.seed_dev.add_(self._slots)
+        self._capturing = False
+        self.graph_slots = self._slots
+        self.zpool = self._saved_zpool
+
+    def abort_capture(self):
+        self._capturing = False
+        self.zpool = self._saved_zpool
+
+    def sync_graph_seeds(self):
+        """Before a replay: make the device seeds continue the host sequence (no-op while only replays advance it)."""
+        if self._graph_next != self.steps:
+            vals = [self.base_seed * 1000003 + self.steps + 1 + j for j in range(self.SEED_SLOTS)]
+            self.seed_dev.copy_(torch.tensor(vals, dtype=torch.int64))
+        self.steps += self.graph_slots
+        self._graph_next = self.steps

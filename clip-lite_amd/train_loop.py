@@ -45,14 +45,25 @@ def init_dataloaders(_C, _A, type="normal"):
 
 
 class TrainStep:
-    """One optimisation step on one rank: reference train.py:211-226."""
+    """One optimisation step on one rank: reference train.py:211-226.
 
-    def __init__(self, model, optimizer, scheduler, scaler, clip_grad_norm, exchange=None):
+    `graph=True` records the whole step (forward, backward, squared gradient norm, fused clip + SGD + Lookahead update: ~900
+    kernel launches) into one hipGraph after `graph_warmup` eager steps and replays it afterwards, which takes the Python/launch
+    cost off the critical path. What changes per step is fed from the host before each replay: the batch (copied into the captured
+    input buffers), the update kernel's hyper-parameters (LR schedule value, Lookahead sync flag) and, on the device, the dropout
+    seeds (runtime.DeviceRuntime.sync_graph_seeds). Eager and replayed steps run the same kernels on the same arguments."""
+
+    def __init__(self, model, optimizer, scheduler, scaler, clip_grad_norm, exchange=None, graph=False, graph_warmup=2):
         self.model, self.optimizer, self.scheduler, self.scaler = model, optimizer, scheduler, scaler
         self.clip, self.exchange = clip_grad_norm, exchange
         self.inner = optimizer.optimizer if hasattr(optimizer, "optimizer") else optimizer
+        self.graph = bool(graph) and exchange is None
+        self.graph_warmup = graph_warmup
+        self._eager_steps = 0
+        self._g = None
+        self._static_batch = self._static_out = None
 
-    def __call__(self, batch):
+    def _eager(self, batch):
         self.optimizer.zero_grad()
         output_dict = self.model(batch)
         loss = output_dict["loss"]
@@ -66,6 +77,59 @@ class TrainStep:
         self.scaler.update()
         self.scheduler.step()
         return output_dict
+
+    def _capture(self, batch):
+        rt = self.model.runtime
+        self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        self.optimizer.zero_grad()            # no-op after a completed step (the update kernel leaves the gradients zeroed)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        rt.begin_capture()
+        try:
+            with torch.cuda.graph(g):
+                out = self.model(self._static_batch)
+                self.scaler.scale(out["loss"]).backward()
+                if self.clip and self.clip > 0:
+                    self.inner.sumsq.zero_()
+                    hip_sumsq(self.inner)
+                self.inner.launch()
+                rt.end_capture()
+        except BaseException:
+            rt.abort_capture()
+            raise
+        self._g, self._static_out = g, out
+
+    def _replay(self, batch):
+        rt = self.model.runtime
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                dst = self._static_batch[k]
+                if dst.shape != v.shape or dst.dtype != v.dtype:
+                    raise RuntimeError(f"graph mode needs fixed batch shapes: {k} was {tuple(dst.shape)}, now {tuple(v.shape)}")
+                dst.copy_(v, non_blocking=True)
+        sync = self.optimizer.advance() if hasattr(self.optimizer, "advance") else False
+        alpha = getattr(self.optimizer, "alpha", 1.0)
+        self.inner.upload_hp(sync, alpha, max_norm=self.clip if self.clip and self.clip > 0 else 0.0)
+        rt.sync_graph_seeds()
+        self._g.replay()
+        self.scaler.update()
+        self.scheduler.step()
+        return self._static_out
+
+    def __call__(self, batch):
+        if not self.graph:
+            return self._eager(batch)
+        if self._g is None:
+            if self._eager_steps < self.graph_warmup:
+                self._eager_steps += 1
+                return self._eager(batch)
+            self._capture(batch)
+        return self._replay(batch)
+
+
+def hip_sumsq(opt):
+    from . import hip
+    hip.sumsq(opt.arena.flat_g, opt.arena.total, opt.sumsq)
 
 
 def main(_A: argparse.Namespace):

@@ -30,6 +30,12 @@ int clite_abi_version(void);
  * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 MFMA rate). Accumulation is f32 in both. */
 enum { CLITE_BF16 = 0, CLITE_F32 = 1 };
 
+/* Dropout / noise seeds. Every (seed, site) pair below is normally passed by value. When CLITE_SEED_INDIRECT is OR-ed into the
+ * site, the 64-bit seed argument is instead the DEVICE ADDRESS of a uint64_t holding the seed: the kernel loads it (one scalar
+ * load per wave) and masks the flag off the site. A captured hipGraph of the train step uses this form so that every replay
+ * draws fresh masks from a device-side counter without re-recording kernel arguments. */
+#define CLITE_SEED_INDIRECT 0x80000000u
+
 enum { CLITE_ACT_NONE = 0, CLITE_ACT_RELU = 1, CLITE_ACT_GELU = 2, CLITE_ACT_TANH = 3 };
 
 /* Fused GEMM epilogue. v = alpha*acc + bias; preact <- v; v = act(v); v *= act'(dact_aux);
