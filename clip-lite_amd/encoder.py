@@ -31,6 +31,7 @@ class _ResNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         resnet_backward(ctx.rt, ctx.enc.img_encoder, ctx.saved, dfeat.contiguous())
+        ctx.rt.arena.note_stream_work()
         return None, None, None, None, None
 
 
@@ -84,6 +85,14 @@ class _BertFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         bert_backward(ctx.rt, ctx.enc.strans, ctx.saved, dout.contiguous())
+        rt = ctx.rt
+        ev = rt.arena.note_stream_work()     # gradients were written on this node's stream: consumers of the arena join it
+        # ... and so does everything the caller enqueues after backward() on the stream forward was called on (reading .grad,
+        # a hand-written update): this node runs after the image encoder's (it was created first), so the join does not
+        # serialise the two backward passes.
+        main = getattr(rt, "main_stream", None)
+        if ev is not None and main is not None and main != torch.cuda.current_stream(rt.device):
+            main.wait_event(ev)
         return None, None, None, None, None, None
 
 

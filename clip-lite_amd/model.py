@@ -33,6 +33,7 @@ class VLInfoModel(nn.Module):
         self.loss = loss
         self.mode = mode
         self.is_amp = is_amp
+        self.overlap_encoders = True     # text encoder on a second stream, concurrent with the image encoder
         self._rt = None
 
     # -- device placement builds the arena ---------------------------------------------------------------------------
@@ -59,13 +60,29 @@ class VLInfoModel(nn.Module):
 
     def forward(self, batch):
         rt = self.runtime
-        image_features = self.image_encoder(batch["image"])
         if self.mode == "sbert":
+            image_features = self.image_encoder(batch["image"])
             text_features = self.text_encoder(batch["caption_encodings"])
         elif self.mode == "train_sbert":
             if any(k in batch for k in ("neg_input_ids", "aug_image", "aug_input_ids")):
                 raise NotImplementedError("negative / augmented branches (reference model.py:61-92) are outside the accelerated hot path")
-            text_features = self.text_encoder({"input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"]})
+            # The two encoders are independent until the loss: the text encoder is enqueued on a second HIP stream so its
+            # (small-grid, latency-bound) BERT kernels share the chip with the ResNet's. Autograd replays each backward on the
+            # stream its forward ran on, so the two backward passes overlap the same way; under graph capture the fork/join
+            # becomes two parallel branches of the hipGraph.
+            text_in = {"input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"]}
+            if self.overlap_encoders and rt.device.type == "cuda":
+                if rt.side_stream is None:
+                    rt.side_stream = torch.cuda.Stream(device=rt.device)
+                main = rt.main_stream = torch.cuda.current_stream(rt.device)
+                rt.side_stream.wait_stream(main)
+                with torch.cuda.stream(rt.side_stream):
+                    text_features = self.text_encoder(text_in)
+                image_features = self.image_encoder(batch["image"])
+                main.wait_stream(rt.side_stream)
+            else:
+                image_features = self.image_encoder(batch["image"])
+                text_features = self.text_encoder(text_in)
         else:
             raise NotImplementedError(f"mode {self.mode!r}")
         loss_dict = self.loss(image_features=image_features, text_features=text_features)

@@ -73,12 +73,14 @@ class FusedSGD(torch.optim.Optimizer):
         """torch.nn.utils.clip_grad_norm_ over every parameter: the squared norm is reduced now, the scaling is applied
         inside the update kernel. Returns the (device) total norm of the pre-scaled gradients."""
         self.max_norm = float(max_norm)
+        self.arena.join()
         self.sumsq.zero_()
         hip.sumsq(self.arena.flat_g, self.arena.total, self.sumsq)
         return self.sumsq.sqrt() * self.grad_prescale
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are zeroed by the update kernel itself; this only clears a backward that was not followed by step()."""
+        self.arena.join()
         if getattr(self, "_dirty", True):
             self.arena.flat_g.zero_()
         self._dirty = True
@@ -102,6 +104,7 @@ class FusedSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def launch(self):
+        self.arena.join()
         self._build_items()
         hip.sgd_step(self.arena.flat_p, self.arena.flat_g, self.flat_v, self.flat_slow, self.arena.flat_lp,
                      C.c_void_p(self._items.data_ptr()), self._n_items, self.hp, self.sumsq)

@@ -39,7 +39,8 @@ class Arena:
                 if m not in placed:
                     order.append(m)
                     placed.add(m)
-        self.device, self.lowp = device, lowp
+        self.device, self.lowp = torch.device(device), lowp
+        self._pending = []
         self.index = {}
         off = 0
         for n in order:
@@ -72,6 +73,26 @@ class Arena:
             K, Cc, R, S = p.shape
             return flat[o:o + numel].view(K, R, S, Cc).permute(0, 3, 1, 2)
         return flat[o:o + numel].view(p.shape)
+
+    # cross-stream ordering ---------------------------------------------------------------------------------------
+    # The backward executors write parameter gradients straight into flat_g on whatever stream autograd runs them on (the two
+    # encoders use different streams), and no AccumulateGrad node exists to make autograd join those streams at the end of
+    # backward(). So each executor leaves an event here and every reader of the arena (gradient norm, update kernel, gradient
+    # exchange) waits for the outstanding events on its own stream first.
+    def note_stream_work(self):
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._pending.append(ev)
+            return ev
+        return None
+
+    def join(self):
+        if self._pending:
+            cur = torch.cuda.current_stream(self.device)
+            for ev in self._pending:
+                cur.wait_event(ev)
+            self._pending = []
 
     # kernel-side views -------------------------------------------------------------------------------------------
     def w(self, p):
@@ -157,7 +178,8 @@ class DeviceRuntime:
         self.precise_bn = not lowp
         self.arena = Arena(model.named_parameters(), self.device, lowp, contiguous_groups)
         self.base_seed = int(seed)
-        self.zpool = ZeroPool(self.device)
+        self._zpools = {}          # one pre-zeroed pool per launch stream (the two encoders run on different streams)
+        self.side_stream = None    # the text encoder's stream (model.py), created on first use
         self.exchange = None
         self._spans = {}
         self.steps = 0
@@ -176,6 +198,14 @@ class DeviceRuntime:
             self.counters[owner] = flat
         for mod in model.modules():
             mod._clite_rt = self
+
+    @property
+    def zpool(self):
+        key = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        pool = self._zpools.get(key)
+        if pool is None:
+            pool = self._zpools[key] = ZeroPool(self.device)
+        return pool
 
     def new_stats(self, Cc):
         """Zeroed replicated accumulator for per-channel statistics of a [rows][Cc] tensor."""
@@ -217,18 +247,18 @@ class DeviceRuntime:
         if self.seed_dev is None:
             self.seed_dev = torch.zeros(self.SEED_SLOTS, device=self.device, dtype=torch.int64)
         self._capturing, self._slots = True, 0
-        self._saved_zpool, self.zpool = self.zpool, ZeroPool(self.device)
+        self._saved_zpools, self._zpools = self._zpools, {}     # chunks taken during capture live in the graph's memory pool
 
     def end_capture(self):
         """Call inside the capture, after the last kernel of the step: advances the device seeds for the next replay."""
         self.seed_dev.add_(self._slots)
         self._capturing = False
         self.graph_slots = self._slots
-        self.zpool = self._saved_zpool
+        self._zpools = self._saved_zpools
 
     def abort_capture(self):
         self._capturing = False
-        self.zpool = self._saved_zpool
+        self._zpools = self._saved_zpools
 
     def sync_graph_seeds(self):
         """Before a replay: make the device seeds continue the host sequence (no-op while only replays advance it)."""

@@ -89,6 +89,7 @@ class TrainStep:
             with torch.cuda.graph(g):
                 out = self.model(self._static_batch)
                 self.scaler.scale(out["loss"]).backward()
+                self.inner.arena.join()
                 if self.clip and self.clip > 0:
                     self.inner.sumsq.zero_()
                     hip_sumsq(self.inner)

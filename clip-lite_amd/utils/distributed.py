@@ -143,6 +143,7 @@ class GradientExchange:
         exactly once per step whatever the executors announced. Returns the factor that turns the SUM into the mean."""
         if self.world == 1:
             return 1.0
+        self.arena.join()       # backward executors may have written gradients on other streams than the caller's
         for lo, hi in self._pending:
             self._send(lo, hi)
         self._pending = []

@@ -187,13 +187,16 @@ def test_gradient_exchange_stream_logic_single_rank():
 
 def test_graph_replay_matches_eager_steps():
     """TrainStep(graph=True) — the whole step captured into one hipGraph and replayed — must walk the same trajectory as the eager
-    step: same batches, same LR schedule, Lookahead sync inside the horizon (k=3), and BERT dropout ON so the device-side seed
-    sequence of the replayed steps has to reproduce the eager one (a wrong or frozen seed changes the masks and the losses by far
-    more than the tolerance). bf16 kernels, 7 steps (2 eager warm-up + capture + 5 replays). Tolerance: float-atomic summation
-    order of bf16 steps only (loss 2e-3; parameter vector 1e-3 in relative L2, 5e-3 max abs)."""
+    step: same batches, same LR schedule, Lookahead sync inside the horizon (k=3), and BERT dropout + prior noise ON so the
+    device-side seed sequence of the replayed steps has to reproduce the eager one (a wrong or frozen seed changes the masks and
+    moves the loss by >1e-2). bf16 kernels, 7 steps (2 eager warm-up + capture + 5 replays), text encoder on its own stream.
+    Learning rates are kept small: this 8-sample, randomly initialised problem amplifies the float-atomic summation-order noise of
+    a step ~10x per step at the reference's rates (two eager runs of it diverge the same way), which would test the problem's
+    conditioning instead of the replay. Tolerance: loss 2e-3 per step; total parameter movement within 2 % (relative L2)."""
     from clip_lite_amd.encoder import ImageEncoder, TextEncoder
     from clip_lite_amd.loss import JSDInfoMaxLoss
     from clip_lite_amd.model import VLInfoModel
+    from clip_lite_amd.optim import FusedSGD, Lookahead
     from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
     from clip_lite_amd.train_loop import TrainStep
     from clip_lite_amd.utils.common import GradScaler
@@ -209,7 +212,9 @@ def test_graph_replay_matches_eager_steps():
         te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
         M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=True))
         M = M.to("cuda").train()
-        opt = _optim(M, k=3)
+        p_init = M.runtime.arena.flat_p.clone()
+        groups = [{"params": [p], "lr": 1e-3 if "image_encoder" in n else 1e-4, "weight_decay": 1e-4} for n, p in M.named_parameters()]
+        opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
         sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
         step = TrainStep(M, opt, sched, GradScaler(True), 10.0, None, graph=graph, graph_warmup=2)
         losses = []
@@ -217,11 +222,11 @@ def test_graph_replay_matches_eager_steps():
             losses.append(step(batches[s % 3])["loss"].item())
         assert step.graph == graph and (step._g is not None) == graph
         torch.cuda.synchronize()
-        results.append((losses, M.runtime.arena.flat_p.clone(), {k: v.clone() for k, v in M.state_dict().items() if "num_batches" in k or "running" in k}))
-    (l0, p0, b0), (l1, p1, b1) = results
+        results.append((losses, M.runtime.arena.flat_p - p_init, {k: v.clone() for k, v in M.state_dict().items() if "num_batches" in k or "running" in k}))
+    (l0, d0, b0), (l1, d1, b1) = results
     assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
-    assert len(set(round(x, 4) for x in l1)) > 3          # the replays really see different batches / masks
-    rel = ((p0 - p1).norm() / p0.norm()).item()
-    assert rel < 1e-3 and (p0 - p1).abs().max().item() < 5e-3, (rel, (p0 - p1).abs().max().item())
+    assert len(set(round(x, 3) for x in l1)) > 3          # the replays really see different batches / masks
+    rel = ((d0 - d1).norm() / d0.norm()).item()
+    assert d0.norm().item() > 1e-3 and rel < 2e-2, (d0.norm().item(), rel)
     for k in b0:
         assert torch.allclose(b0[k].float(), b1[k].float(), rtol=5e-3, atol=1e-4), k

@@ -1,0 +1,107 @@
+"""Per-launch profile of the implicit-GEMM engine inside one train step: every conv / linear forward, dgrad and wgrad launch with its
+GEMM shape, duration (HIP events on the launch stream), TFLOP/s and minimum-HBM-traffic GB/s. Usage (on the GPU box):
+    python tools/layer_profile.py [--batch 128] [--visual resnet50] [--layers 12] > gpurun_out/layers.txt"""
+import argparse
+import collections
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def describe(name, a, esz):
+    """-> (label, M, N, K, min_bytes)"""
+    if name.startswith("clite_conv"):
+        cv = a[2]._obj
+        P, Q = cv.N * cv.Ho * cv.Wo, cv.N * cv.H * cv.W
+        kk = cv.R * cv.S * cv.C
+        lab = f"{cv.C:4d}->{cv.K:4d} {cv.R}x{cv.S}/{cv.stride} {cv.H:3d}->{cv.Ho:3d}"
+        if name == "clite_conv_fwd":
+            return lab, P, cv.K, kk, esz * (Q * cv.C + P * cv.K + cv.K * kk)
+        if name == "clite_conv_dgrad":
+            return lab, Q, cv.C, cv.R * cv.S * cv.K, esz * (Q * cv.C + P * cv.K + cv.K * kk)
+        return lab, cv.K, kk, P, esz * (Q * cv.C + P * cv.K) + 4 * cv.K * kk
+    if name.startswith("clite_stem"):
+        N, Ho, Wo = a[3], a[6], a[7]
+        P = N * Ho * Wo
+        if name == "clite_stem_fwd":
+            return "stem 7x7", P, 64, 224, esz * (N * a[4] * a[5] * 4 + P * 64)
+        return "stem 7x7", 64, 224, P, esz * (N * a[4] * a[5] * 4 + P * 64)
+    M, N, K = a[4], a[5], a[6]
+    if name == "clite_gemm_tn":
+        return "linear", M, N, K, esz * (K * M + K * N) + 4 * M * N
+    return "linear", M, N, K, esz * (M * K + N * K + M * N)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--visual", default="resnet50")
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--f32", action="store_true")
+    args = ap.parse_args()
+    from clip_lite_amd import hip
+    from clip_lite_amd.train_loop import TrainStep
+    from clip_lite_amd.utils.common import GradScaler
+    device = torch.device("cuda", 0)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        model, opt, sched = bench.build(args, device)
+    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, None)
+    batches = bench.synthetic_batches(args, device, 0)
+    for i in range(3):
+        step(batches[i % 2])
+    torch.cuda.synchronize()
+    names = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_wgrad", "clite_stem_fwd", "clite_stem_wgrad")
+    lib = hip.lib()
+    recs = []
+
+    def wrap(name):
+        fn = getattr(lib, name)
+
+        def timed(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            recs.append((name, describe(name, a, 4 if args.f32 else 2), e0, e1))
+            return rc
+        return timed
+    wrapped = {n: wrap(n) for n in names}
+
+    class Proxy:
+        def __getattr__(self, k):
+            return wrapped.get(k) or getattr(lib, k)
+    hip._lib = Proxy()
+    REP = 3
+    for i in range(REP):
+        step(batches[i % 2])
+    torch.cuda.synchronize()
+    hip._lib = lib
+    agg = collections.OrderedDict()
+    for name, d, e0, e1 in recs:
+        key = (name, d)
+        agg.setdefault(key, []).append(e0.elapsed_time(e1))
+    rows = []
+    for (name, (lab, M, N, K, nbytes)), ts in agg.items():
+        n = len(ts) // REP
+        us = sum(ts) / len(ts) * 1e3
+        rows.append((name[6:], lab, M, N, K, n, us, 2.0 * M * N * K / us / 1e6, nbytes / us / 1e3))
+    tot = sum(r[5] * r[6] for r in rows)
+    print(f"{'op':12s} {'layer':28s} {'M':>8s} {'N':>6s} {'K':>8s} {'n':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s} {'%':>5s}")
+    for r in sorted(rows, key=lambda r: -r[5] * r[6]):
+        print(f"{r[0]:12s} {r[1]:28s} {r[2]:8d} {r[3]:6d} {r[4]:8d} {r[5]:3d} {r[6]:8.1f} {r[7]:7.1f} {r[8]:7.0f} {100 * r[5] * r[6] / tot:5.1f}")
+    print(f"total igemm time per step: {tot / 1e3:.3f} ms over {sum(r[5] for r in rows)} launches")
+    by = collections.defaultdict(float)
+    for r in rows:
+        by[r[0]] += r[5] * r[6]
+    for k, v in sorted(by.items(), key=lambda kv: -kv[1]):
+        print(f"  {k:12s} {v / 1e3:8.3f} ms")
+
+
+if __name__ == "__main__":
+    main()
