@@ -33,6 +33,7 @@ class FusedSGD(torch.optim.Optimizer):
         self.max_norm = 0.0
         self.grad_prescale = 1.0
         self._items = None
+        self._hp_ring = None
         self._items_key = None
         self.before_step: Callable = None     # hook: e.g. wait for the gradient all-reduce stream
 
@@ -100,7 +101,24 @@ class FusedSGD(torch.optim.Optimizer):
         """Host -> device: (lr multiplier of the schedule, momentum, clip norm, Lookahead sync flag, alpha, gradient pre-scale)."""
         mom = self.param_groups[0]["momentum"]
         mn = self.max_norm if max_norm is None else float(max_norm)
-        self.hp.copy_(torch.tensor([self._lr_mult(), mom, mn, 1.0 if lookahead_sync else 0.0, alpha, self.grad_prescale, 0, 0]), non_blocking=True)
+        vals = [self._lr_mult(), mom, mn, 1.0 if lookahead_sync else 0.0, alpha, self.grad_prescale, 0.0, 0.0]
+        if not self.hp.is_cuda:
+            self.hp.copy_(torch.tensor(vals))
+            return
+        # asynchronous upload from a small ring of pinned slots: a slot is rewritten only after the copy that read it has executed
+        if self._hp_ring is None:
+            self._hp_ring = [(torch.empty(8, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._hp_used = [False] * 8
+            self._hp_next = 0
+        i = self._hp_next
+        self._hp_next = (i + 1) % len(self._hp_ring)
+        host, ev = self._hp_ring[i]
+        if self._hp_used[i]:
+            ev.synchronize()
+        host.copy_(torch.tensor(vals))
+        self.hp.copy_(host, non_blocking=True)
+        ev.record()
+        self._hp_used[i] = True
 
     @torch.no_grad()
     def launch(self):

@@ -47,20 +47,23 @@ def init_dataloaders(_C, _A, type="normal"):
 class TrainStep:
     """One optimisation step on one rank: reference train.py:211-226.
 
-    `graph=True` records the whole step (forward, backward, squared gradient norm, fused clip + SGD + Lookahead update: ~900
-    kernel launches) into one hipGraph after `graph_warmup` eager steps and replays it afterwards, which takes the Python/launch
-    cost off the critical path. What changes per step is fed from the host before each replay: the batch (copied into the captured
-    input buffers), the update kernel's hyper-parameters (LR schedule value, Lookahead sync flag) and, on the device, the dropout
-    seeds (runtime.DeviceRuntime.sync_graph_seeds). Eager and replayed steps run the same kernels on the same arguments."""
+    `graph=True` records the step (forward, backward, squared gradient norm, fused clip + SGD + Lookahead update: ~900 kernel
+    launches) into hipGraphs after `graph_warmup` eager steps and replays them afterwards, which takes the Python/launch cost off
+    the critical path. What changes per step is fed from the host before each replay: the batch (copied into the captured input
+    buffers), the update kernel's hyper-parameters (LR schedule value, Lookahead sync flag) and, on the device, the dropout seeds
+    (runtime.DeviceRuntime.sync_graph_seeds). Eager and replayed steps run the same kernels on the same arguments.
+
+    Data parallel (`exchange` given): the step is recorded as two graphs — [forward + backward] and [gradient norm + update] —
+    with the RCCL all-reduce of the flat gradient arena issued eagerly between them (collectives stay outside the captures)."""
 
     def __init__(self, model, optimizer, scheduler, scaler, clip_grad_norm, exchange=None, graph=False, graph_warmup=2):
         self.model, self.optimizer, self.scheduler, self.scaler = model, optimizer, scheduler, scaler
         self.clip, self.exchange = clip_grad_norm, exchange
         self.inner = optimizer.optimizer if hasattr(optimizer, "optimizer") else optimizer
-        self.graph = bool(graph) and exchange is None
+        self.graph = bool(graph)
         self.graph_warmup = graph_warmup
         self._eager_steps = 0
-        self._g = None
+        self._g = self._g_update = None
         self._static_batch = self._static_out = None
 
     def _eager(self, batch):
@@ -78,25 +81,38 @@ class TrainStep:
         self.scheduler.step()
         return output_dict
 
+    def _capture_update(self):
+        self.inner.arena.join()
+        if self.clip and self.clip > 0:
+            self.inner.sumsq.zero_()
+            hip_sumsq(self.inner)
+        self.inner.launch()
+
     def _capture(self, batch):
         rt = self.model.runtime
         self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         self.optimizer.zero_grad()            # no-op after a completed step (the update kernel leaves the gradients zeroed)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        saved_exchange, rt.exchange = rt.exchange, None      # no collectives inside a capture: the executors must not start buckets
         rt.begin_capture()
         try:
             with torch.cuda.graph(g):
                 out = self.model(self._static_batch)
                 self.scaler.scale(out["loss"]).backward()
-                self.inner.arena.join()
-                if self.clip and self.clip > 0:
-                    self.inner.sumsq.zero_()
-                    hip_sumsq(self.inner)
-                self.inner.launch()
+                if self.exchange is None:
+                    self._capture_update()
+                else:
+                    self.inner.arena.join()
                 rt.end_capture()
+            if self.exchange is not None:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g.pool()):
+                    self._capture_update()
+                self._g_update = g2
         except BaseException:
             rt.abort_capture()
+            rt.exchange = saved_exchange
             raise
         self._g, self._static_out = g, out
 
@@ -110,9 +126,14 @@ class TrainStep:
                 dst.copy_(v, non_blocking=True)
         sync = self.optimizer.advance() if hasattr(self.optimizer, "advance") else False
         alpha = getattr(self.optimizer, "alpha", 1.0)
+        if self.exchange is not None:
+            self.inner.grad_prescale = 1.0 / self.exchange.world
         self.inner.upload_hp(sync, alpha, max_norm=self.clip if self.clip and self.clip > 0 else 0.0)
         rt.sync_graph_seeds()
         self._g.replay()
+        if self.exchange is not None:
+            self.exchange.reduce_all()
+            self._g_update.replay()
         self.scaler.update()
         self.scheduler.step()
         return self._static_out

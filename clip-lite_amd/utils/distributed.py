@@ -138,6 +138,16 @@ class GradientExchange:
             lo0, hi0 = self._pending.pop(0)
             self._send(lo0, hi0)
 
+    def reduce_all(self, chunk_elems: int = 64 * 1024 * 1024):
+        """Non-overlapped form used between the two hipGraphs of a captured step: all-reduce (SUM) the whole gradient arena on
+        the caller's stream, in chunks of at most `chunk_elems` (256 MB of f32) so RCCL pipelines the rings. The update kernel
+        applies 1/world_size."""
+        if self.world == 1:
+            return
+        total = self.arena.total
+        for lo in range(0, total, chunk_elems):
+            dist.all_reduce(self.arena.flat_g[lo:min(total, lo + chunk_elems)], op=dist.ReduceOp.SUM, group=self.group)
+
     def finish(self):
         """Flush pending regions, then exchange every part of the arena that was never reported, so each element is reduced
         exactly once per step whatever the executors announced. Returns the factor that turns the SUM into the mean."""

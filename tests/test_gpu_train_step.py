@@ -189,7 +189,7 @@ def test_graph_replay_matches_eager_steps():
     """TrainStep(graph=True) — the whole step captured into one hipGraph and replayed — must walk the same trajectory as the eager
     step: same batches, same LR schedule, Lookahead sync inside the horizon (k=3), and BERT dropout + prior noise ON so the
     device-side seed sequence of the replayed steps has to reproduce the eager one (a wrong or frozen seed changes the masks and
-    moves the loss by >1e-2). bf16 kernels, 7 steps (2 eager warm-up + capture + 5 replays), text encoder on its own stream.
+    moves the loss by >1e-2). bf16 kernels, 5 steps (2 eager warm-up + capture + 3 replays), text encoder on its own stream.
     Learning rates are kept small: this 8-sample, randomly initialised problem amplifies the float-atomic summation-order noise of
     a step ~10x per step at the reference's rates (two eager runs of it diverge the same way), which would test the problem's
     conditioning instead of the replay. Tolerance: loss 2e-3 per step; total parameter movement within 2 % (relative L2)."""
@@ -218,15 +218,57 @@ def test_graph_replay_matches_eager_steps():
         sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
         step = TrainStep(M, opt, sched, GradScaler(True), 10.0, None, graph=graph, graph_warmup=2)
         losses = []
-        for s in range(7):
+        for s in range(5):
             losses.append(step(batches[s % 3])["loss"].item())
         assert step.graph == graph and (step._g is not None) == graph
         torch.cuda.synchronize()
         results.append((losses, M.runtime.arena.flat_p - p_init, {k: v.clone() for k, v in M.state_dict().items() if "num_batches" in k or "running" in k}))
     (l0, d0, b0), (l1, d1, b1) = results
     assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
-    assert len(set(round(x, 3) for x in l1)) > 3          # the replays really see different batches / masks
+    assert len(set(round(x, 3) for x in l1)) >= 3         # the replays really see different batches / masks
     rel = ((d0 - d1).norm() / d0.norm()).item()
     assert d0.norm().item() > 1e-3 and rel < 2e-2, (d0.norm().item(), rel)
     for k in b0:
         assert torch.allclose(b0[k].float(), b1[k].float(), rtol=5e-3, atol=1e-4), k
+
+
+def test_graph_two_segment_step_with_exchange_single_rank():
+    """Data-parallel form of the captured step: [forward + backward] graph, eager all-reduce of the whole gradient arena, [norm +
+    update] graph. Forced on with one real rank pretending world_size 2 (the SUM over one rank is the identity; the update applies
+    the 1/2), against the eager step with the overlapped exchange under the same pretence. Tolerances as in the test above."""
+    import torch.distributed as tdist
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    from clip_lite_amd.optim import FusedSGD, Lookahead
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    from clip_lite_amd.train_loop import TrainStep
+    from clip_lite_amd.utils import distributed as D
+    from clip_lite_amd.utils.common import GradScaler
+    if not tdist.is_initialized():
+        tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:29612", rank=0, world_size=1)
+    B, L = 8, 12
+    ids = torch.randint(1000, 30522, (B, L), generator=torch.Generator().manual_seed(3))
+    batch = {"image": det_tensor("ximg", (B, 3, 64, 64), "normal").cuda(), "input_ids": ids.cuda(), "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()}
+    results = []
+    for graph in (False, True):
+        torch.manual_seed(11)
+        te = TextEncoder(mode="train_sbert", num_hidden_layers=1)
+        M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=True)).to("cuda").train()
+        p_init = M.runtime.arena.flat_p.clone()
+        groups = [{"params": [p], "lr": 1e-3 if "image_encoder" in n else 1e-4, "weight_decay": 1e-4} for n, p in M.named_parameters()]
+        opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
+        sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
+        ex = D.GradientExchange(M.runtime.arena, bucket_elems=1 << 20)
+        ex.world = 2
+        M.runtime.exchange = ex
+        step = TrainStep(M, opt, sched, GradScaler(True), 10.0, ex, graph=graph, graph_warmup=1)
+        losses = [step(batch)["loss"].item() for _ in range(5)]
+        torch.cuda.synchronize()
+        assert (step._g_update is not None) == graph
+        results.append((losses, M.runtime.arena.flat_p - p_init))
+    tdist.destroy_process_group()
+    (l0, d0), (l1, d1) = results
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
+    rel = ((d0 - d1).norm() / d0.norm()).item()
+    assert d0.norm().item() > 1e-3 and rel < 2e-2, (d0.norm().item(), rel)

@@ -20,7 +20,7 @@ for i in range(3):
     batches.append({"image": det_tensor(f"gimg{i}", (B, 3, 64, 64), "normal").cuda(), "input_ids": ids.cuda(), "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()})
 
 
-def run(graph, overlap, drop=0.1, lowp=True):
+def run(graph, overlap, drop=0.1, lowp=True, k=3, clip=10.0):
     torch.manual_seed(7)
     with contextlib.redirect_stdout(sys.stderr):
         te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
@@ -28,19 +28,16 @@ def run(graph, overlap, drop=0.1, lowp=True):
     M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=lowp)).to("cuda").train()
     M.overlap_encoders = overlap
     groups = [{"params": [p], "lr": 0.01 if "image_encoder" in n else 1e-3, "weight_decay": 1e-4} for n, p in M.named_parameters()]
-    opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
+    opt = Lookahead(FusedSGD(groups, momentum=0.9), k=k, alpha=0.5)
     sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
-    step = TrainStep(M, opt, sched, GradScaler(True), 10.0, None, graph=graph, graph_warmup=2)
+    step = TrainStep(M, opt, sched, GradScaler(True), clip, None, graph=graph, graph_warmup=2)
     losses = [step(batches[s % 3])["loss"].item() for s in range(7)]
     torch.cuda.synchronize()
     return losses, M.runtime.arena.flat_p.clone()
 
 
-for name, kw in [("eager/no-ov #1", dict(graph=False, overlap=False)), ("eager/no-ov #2", dict(graph=False, overlap=False)),
-                 ("eager/ov", dict(graph=False, overlap=True)), ("eager/ov #2", dict(graph=False, overlap=True)),
-                 ("graph/no-ov", dict(graph=True, overlap=False)), ("graph/ov", dict(graph=True, overlap=True)), ("graph/ov #2", dict(graph=True, overlap=True)),
-                 ("f32 eager/no-ov", dict(graph=False, overlap=False, lowp=False)), ("f32 eager/no-ov #2", dict(graph=False, overlap=False, lowp=False)),
-                 ("f32 graph/ov", dict(graph=True, overlap=True, lowp=False)),
-                 ("nodrop eager/no-ov", dict(graph=False, overlap=False, drop=0.0)), ("nodrop graph/ov", dict(graph=True, overlap=True, drop=0.0))]:
+for name, kw in [("eager ov", dict(graph=False, overlap=True)), ("eager no-ov", dict(graph=False, overlap=False)),
+                 ("graph ov", dict(graph=True, overlap=True)), ("graph no-ov", dict(graph=True, overlap=False)),
+                 ("eager ov f32", dict(graph=False, overlap=True, lowp=False)), ("eager no-ov f32", dict(graph=False, overlap=False, lowp=False))]:
     l, p = run(**kw)
     print(f"{name:20s}", " ".join(f"{x:.5f}" for x in l), f"|p|={p.norm().item():.6f}")
