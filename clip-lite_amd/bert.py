@@ -131,10 +131,13 @@ def _linear_grads(rt, lin, dy, x, M, dw=None, db=None):
     if dw is None:
         dw = rt.arena.g(lin.weight) if lin.weight.requires_grad else None
         db = rt.arena.g(lin.bias) if (lin.bias is not None and lin.bias.requires_grad) else None
-    if dw is not None:
-        hip.gemm_tn(rt.dt, dy, x, N, K, M, hip.epilogue(dw, K, atomic=True, out_f32=True))
-    if db is not None:
-        hip.colsum(rt.dt, dy, db, M, N)
+
+    def launch():
+        if dw is not None:
+            hip.gemm_tn(rt.dt, dy, x, N, K, M, hip.epilogue(dw, K, atomic=True, out_f32=True))
+        if db is not None:
+            hip.colsum(rt.dt, dy, db, M, N)
+    rt.aux_launch(launch, dy, x)       # off the dgrad chain: runtime.DeviceRuntime.aux_launch
 
 
 def bert_forward(rt, net, input_ids, attention_mask, step):
@@ -244,4 +247,5 @@ def bert_backward(rt, net, ctx, dpooled):
                       drop_in=ctx["d0"])
     hip.embed_bwd(dt, ctx["ids"], ds0, A.g(emb.word_embeddings.weight), A.g(emb.position_embeddings.weight), M, L, Hd, net.vocab)
     hip.colsum(dt, ds0, A.g(emb.token_type_embeddings.weight)[0], M, Hd)
+    rt.join_aux()
     rt.grads_ready(emb)

@@ -125,6 +125,7 @@ class _TransformFn(torch.autograd.Function):
         _linear_grads(rt, enc.fc1, dh, x, B)
         dx = torch.empty(B, D, device=rt.device, dtype=rt.tdtype)
         hip.gemm_nn(rt.dt, dh, rt.arena.w(enc.fc1.weight), B, D, E, hip.epilogue(dx, D))
+        rt.join_aux()
         return dx, None, None
 
 

@@ -247,5 +247,6 @@ class _JSDLossFn(torch.autograd.Function):
         dtxt = prior_backward(rt, mod.text_prior_d, pctx_t, gout, mod.prior_weight, None) if pctx_t is not None else None
         dimg = mi_block_backward(rt, gd.img_block, c1, df1, dimg)
         dtxt = mi_block_backward(rt, gd.text_block, c2, df2, dtxt)
+        rt.join_aux()
         rt.grads_ready(mod)
         return dimg.to(ctx.in_dtypes[0]), dtxt.to(ctx.in_dtypes[1]), None, None, None

@@ -235,7 +235,7 @@ def resnet_backward(rt, net, ctx, dfeat):
         for i in range(len(units) - 1, -1, -1):
             u = units[i]
             if u.conv.weight.requires_grad:
-                hip.conv_wgrad(dy, u.x, u.cv, rt.arena.g(u.conv.weight))
+                rt.aux_launch(lambda dy=dy, u=u: hip.conv_wgrad(dy, u.x, u.cv, rt.arena.g(u.conv.weight)), dy)
             Cin = u.conv.in_channels
             dx = _alloc(rt, u.x.shape[0], Cin)
             if i > 0:
@@ -247,7 +247,7 @@ def resnet_backward(rt, net, ctx, dfeat):
                 hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None))
                 if ud is not None:
                     if ud.conv.weight.requires_grad:
-                        hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight))
+                        rt.aux_launch(lambda dyd=dyd, ud=ud: hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight)), dyd)
                     dx2 = _alloc(rt, u.x.shape[0], Cin)
                     hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx2, Cin, residual=dx))
                     dx = dx2
@@ -263,5 +263,6 @@ def resnet_backward(rt, net, ctx, dfeat):
         dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)
         hip.stem_wgrad(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, dwv)
         hip.stem_unpack_grad(dwv, rt.arena.g(net.conv1.weight))
+    rt.join_aux()
     rt.grads_ready(net.conv1)
     rt.grads_ready(net.bn1)
