@@ -201,52 +201,64 @@ def prior_backward(rt, pd, ctx, gout, scale, dfeat_residual):
     return dfeat
 
 
+def jsd_forward(rt, mod, img, txt, step):
+    """image/text features -> (out f32[4] = [total, cross, prior, 0], saved state for jsd_backward). No autograd involved: the
+    autograd Function below and the captured multi-graph step (train_loop.TrainStep) both drive the heads through this pair."""
+    dt = rt.dt
+    training = step.training
+    img = img.to(rt.tdtype).contiguous()
+    txt = txt.to(rt.tdtype).contiguous()
+    B = img.shape[0]
+    acc = torch.zeros(4, device=rt.device, dtype=torch.float32)
+    noise = mod._noise or (None, None)
+    pctx_i = pctx_t = None
+    if mod.image_prior:
+        pctx_i = prior_forward(rt, mod.prior_d, img, noise[0], acc[2:3], step, step.site())
+    if mod.text_prior:
+        pctx_t = prior_forward(rt, mod.text_prior_d, txt, noise[1], acc[3:4], step, step.site())
+    gd = mod.global_d
+    f1, c1 = mi_block_forward(rt, gd.img_block, img, training)
+    f2, c2 = mi_block_forward(rt, gd.text_block, txt, training)
+    if training:
+        rt.bump_counters("loss", 2)
+    work = torch.empty(B, 8, device=rt.device, dtype=torch.float32)
+    hip.critic_jsd_fwd(dt, f1, f2, gd.temperature, B, gd.img_block.units, work, acc)
+    out = torch.empty(4, device=rt.device, dtype=torch.float32)
+    hip.loss_finalize(acc, mod.prior_weight, out)
+    return out, (f1, f2, c1, c2, work, pctx_i, pctx_t, B)
+
+
+def jsd_backward(rt, mod, saved, gout):
+    """gout: f32[1] device scalar dL/d(total). Returns (d image_features, d text_features) in the compute dtype; parameter
+    gradients accumulate into the arena."""
+    dt, A = rt.dt, rt.arena
+    f1, f2, c1, c2, work, pctx_i, pctx_t, B = saved
+    gd = mod.global_d
+    U = gd.img_block.units
+    df1, df2 = _alloc(rt, B, U), _alloc(rt, B, U)
+    hip.critic_jsd_bwd(dt, f1, f2, gd.temperature, work, gout, 1.0 - mod.prior_weight, B, U, df1, df2, A.g(gd.temperature).view(1))
+    dimg = prior_backward(rt, mod.prior_d, pctx_i, gout, mod.prior_weight, None) if pctx_i is not None else None
+    dtxt = prior_backward(rt, mod.text_prior_d, pctx_t, gout, mod.prior_weight, None) if pctx_t is not None else None
+    dimg = mi_block_backward(rt, gd.img_block, c1, df1, dimg)
+    dtxt = mi_block_backward(rt, gd.text_block, c2, df2, dtxt)
+    rt.join_aux()
+    rt.grads_ready(mod)
+    return dimg, dtxt
+
+
 class _JSDLossFn(torch.autograd.Function):
     """image/text features -> (total, [total, cross, prior, 0]); backward drives the head kernels and returns feature grads."""
 
     @staticmethod
     def forward(ctx, img, txt, mod, rt, step):
-        dt = rt.dt
-        training = step.training
-        in_dtypes = (img.dtype, txt.dtype)
-        img = img.to(rt.tdtype).contiguous()
-        txt = txt.to(rt.tdtype).contiguous()
-        B = img.shape[0]
-        acc = torch.zeros(4, device=rt.device, dtype=torch.float32)
-        noise = mod._noise or (None, None)
-        pctx_i = pctx_t = None
-        if mod.image_prior:
-            pctx_i = prior_forward(rt, mod.prior_d, img, noise[0], acc[2:3], step, step.site())
-        if mod.text_prior:
-            pctx_t = prior_forward(rt, mod.text_prior_d, txt, noise[1], acc[3:4], step, step.site())
-        gd = mod.global_d
-        f1, c1 = mi_block_forward(rt, gd.img_block, img, training)
-        f2, c2 = mi_block_forward(rt, gd.text_block, txt, training)
-        if training:
-            rt.bump_counters("loss", 2)
-        work = torch.empty(B, 8, device=rt.device, dtype=torch.float32)
-        hip.critic_jsd_fwd(dt, f1, f2, gd.temperature, B, gd.img_block.units, work, acc)
-        out = torch.empty(4, device=rt.device, dtype=torch.float32)
-        hip.loss_finalize(acc, mod.prior_weight, out)
-        ctx.mod, ctx.rt, ctx.saved = mod, rt, (f1, f2, c1, c2, work, pctx_i, pctx_t, B)
-        ctx.in_dtypes = (in_dtypes[0], in_dtypes[1])
+        out, saved = jsd_forward(rt, mod, img, txt, step)
+        ctx.mod, ctx.rt, ctx.saved = mod, rt, saved
+        ctx.in_dtypes = (img.dtype, txt.dtype)
         ctx.mark_non_differentiable(out)
         return out[0].clone(), out
 
     @staticmethod
     def backward(ctx, gtotal, _gcomps):
-        mod, rt = ctx.mod, ctx.rt
-        dt, A = rt.dt, rt.arena
-        f1, f2, c1, c2, work, pctx_i, pctx_t, B = ctx.saved
-        gd = mod.global_d
-        U = gd.img_block.units
         gout = gtotal.to(torch.float32).contiguous().view(1)
-        df1, df2 = _alloc(rt, B, U), _alloc(rt, B, U)
-        hip.critic_jsd_bwd(dt, f1, f2, gd.temperature, work, gout, 1.0 - mod.prior_weight, B, U, df1, df2, A.g(gd.temperature).view(1))
-        dimg = prior_backward(rt, mod.prior_d, pctx_i, gout, mod.prior_weight, None) if pctx_i is not None else None
-        dtxt = prior_backward(rt, mod.text_prior_d, pctx_t, gout, mod.prior_weight, None) if pctx_t is not None else None
-        dimg = mi_block_backward(rt, gd.img_block, c1, df1, dimg)
-        dtxt = mi_block_backward(rt, gd.text_block, c2, df2, dtxt)
-        rt.join_aux()
-        rt.grads_ready(mod)
+        dimg, dtxt = jsd_backward(ctx.rt, ctx.mod, ctx.saved, gout)
         return dimg.to(ctx.in_dtypes[0]), dtxt.to(ctx.in_dtypes[1]), None, None, None

@@ -122,6 +122,17 @@ class Arena:
         src = self.flat_g if grad else (self.flat_lp if (self.lowp and lowp) else self.flat_p)
         return src[o:end]
 
+    def region(self, prefix):
+        """[lo, hi) element range of the flat buffers covered by the tensors whose name starts with `prefix` (they are adjacent:
+        the arena follows named_parameters() order, which lists one top-level module after the other)."""
+        offs = [self.index[n] for n in self.names if n.startswith(prefix)]
+        if not offs:
+            return (0, 0)
+        lo = min(o for o, _ in offs)
+        hi = max((o + n + ALIGN - 1) // ALIGN * ALIGN for o, n in offs)
+        assert sum((n + ALIGN - 1) // ALIGN * ALIGN for _, n in offs) == hi - lo, f"tensors under {prefix!r} are not contiguous"
+        return (lo, min(hi, self.total))
+
     def refresh_lowp(self):
         """Re-derive the bf16 copy from the f32 masters (after load_state_dict or any out-of-band weight edit)."""
         if self.lowp:

@@ -63,7 +63,7 @@ class TrainStep:
         self.graph = bool(graph)
         self.graph_warmup = graph_warmup
         self._eager_steps = 0
-        self._g = self._g_update = None
+        self._g = self._g_update = self._graphs = None
         self._static_batch = self._static_out = None
 
     def _eager(self, batch):
@@ -88,7 +88,118 @@ class TrainStep:
             hip_sumsq(self.inner)
         self.inner.launch()
 
+    # ---- captured step ------------------------------------------------------------------------------------------------
+    # One hipGraph per phase, replayed on two HIP streams: HIP executes the nodes of a single captured graph almost serially
+    # (measured: 84 % of a one-graph step had exactly one kernel in flight), so real concurrency between the two encoders needs
+    # separate graphs on separate streams:
+    #
+    #   main : [image fwd] ------------> [heads fwd + bwd] --> [image bwd] --------------------> [norm + update]
+    #   side : [text  fwd] --(join)--^          (fork)-----> [text  bwd] --(join)---------------^
+    #   comm :                                     all-reduce(heads)  all-reduce(text)  all-reduce(image)     (data parallel)
+    #
+    # Graphs that replay on the same stream share a memory pool (they run in capture order); the two streams use different pools,
+    # and every tensor that crosses a stream (features, their gradients) is kept referenced for the lifetime of the graphs.
+    def _direct_ok(self):
+        m = self.model
+        return (getattr(m, "mode", None) == "train_sbert" and not m.text_encoder.transform_embedding and m.training
+                and not getattr(m.image_encoder, "frozen", False)
+                and all(p.requires_grad for p in m.parameters()))
+
     def _capture(self, batch):
+        if not self._direct_ok():
+            return self._capture_single(batch)
+        from .bert import bert_backward, bert_forward
+        from .loss import jsd_backward, jsd_forward
+        from .resnet import resnet_backward, resnet_forward
+        m, rt = self.model, self.model.runtime
+        sb = self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        self.optimizer.zero_grad()            # no-op after a completed step (the update kernel leaves the gradients zeroed)
+        torch.cuda.synchronize()
+        saved_exchange, rt.exchange = rt.exchange, None      # the executors must not start collectives inside a capture
+        pool_main, pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        graphs, keep = {}, {}
+
+        def capture(name, pool, fn):
+            rt._zpools = {}                   # a segment zeroes the accumulators it uses itself
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                fn()
+            graphs[name] = g
+
+        def image_fwd():
+            keep["img"], keep["ctx_i"] = resnet_forward(rt, m.image_encoder.img_encoder, sb["image"].to(torch.float32).contiguous(), True)
+            rt.bump_counters("image_encoder", 1)
+
+        def text_fwd():
+            keep["step_t"] = rt.next_step(True)
+            keep["txt"], keep["ctx_t"] = bert_forward(rt, m.text_encoder.strans, sb["input_ids"], sb["attention_mask"], keep["step_t"])
+
+        def heads():
+            out, saved = jsd_forward(rt, m.loss, keep["img"], keep["txt"], rt.next_step(True))
+            keep["out"], keep["gout"] = out, torch.ones(1, device=rt.device, dtype=torch.float32)
+            keep["dimg"], keep["dtxt"] = jsd_backward(rt, m.loss, saved, keep["gout"])
+            keep["loss_saved"] = saved
+            keep["result"] = {"loss": out[0].clone(), "loss_components": {"total_loss": out[0].clone(), "cross_modal_loss": out[1].clone(),
+                                                                          "visual_loss": out[3].clone(), "textual_loss": out[3].clone()}}
+
+        def image_bwd():
+            resnet_backward(rt, m.image_encoder.img_encoder, keep["ctx_i"], keep["dimg"].contiguous())
+
+        def text_bwd():
+            bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous())
+
+        def update():
+            self._capture_update()
+            rt.end_capture()
+
+        rt.begin_capture()
+        try:
+            with torch.no_grad():
+                capture("image_fwd", pool_main, image_fwd)
+                capture("text_fwd", pool_side, text_fwd)
+                capture("heads", pool_main, heads)
+                capture("text_bwd", pool_side, text_bwd)
+                capture("image_bwd", pool_main, image_bwd)
+                capture("update", pool_main, update)
+        except BaseException:
+            rt.abort_capture()
+            rt.exchange = saved_exchange
+            raise
+        A = rt.arena
+        self._regions = {k: A.region(k + ".") for k in ("text_encoder", "image_encoder", "loss")}
+        self._g, self._graphs, self._keep, self._static_out = graphs["update"], graphs, keep, keep["result"]
+
+    def _replay_direct(self):
+        rt, G, ex = self.model.runtime, self._graphs, self.exchange
+        main, side = torch.cuda.current_stream(rt.device), rt.side_stream
+        side.wait_stream(main)
+        G["image_fwd"].replay()
+        with torch.cuda.stream(side):
+            G["text_fwd"].replay()
+        main.wait_stream(side)
+        G["heads"].replay()
+        side.wait_stream(main)
+        if ex is not None:
+            ex.reduce_span(*self._regions["loss"], after=main)
+        with torch.cuda.stream(side):
+            G["text_bwd"].replay()
+        G["image_bwd"].replay()
+        if ex is not None:
+            ex.reduce_span(*self._regions["text_encoder"], after=side)
+            ex.reduce_span(*self._regions["image_encoder"], after=main)
+            covered = sorted(self._regions.values())
+            pos = 0
+            for lo, hi in covered:                 # anything outside the three top-level modules (nothing, for VLInfoModel)
+                if lo > pos:
+                    ex.reduce_span(pos, lo, after=main)
+                pos = max(pos, hi)
+            if pos < rt.arena.total:
+                ex.reduce_span(pos, rt.arena.total, after=main)
+            ex.wait()
+        main.wait_stream(side)
+        G["update"].replay()
+
+    def _capture_single(self, batch):
         rt = self.model.runtime
         self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
         self.optimizer.zero_grad()            # no-op after a completed step (the update kernel leaves the gradients zeroed)
@@ -130,10 +241,13 @@ class TrainStep:
             self.inner.grad_prescale = 1.0 / self.exchange.world
         self.inner.upload_hp(sync, alpha, max_norm=self.clip if self.clip and self.clip > 0 else 0.0)
         rt.sync_graph_seeds()
-        self._g.replay()
-        if self.exchange is not None:
-            self.exchange.reduce_all()
-            self._g_update.replay()
+        if self._graphs is not None:
+            self._replay_direct()
+        else:
+            self._g.replay()
+            if self.exchange is not None:
+                self.exchange.reduce_all()
+                self._g_update.replay()
         self.scaler.update()
         self.scheduler.step()
         return self._static_out

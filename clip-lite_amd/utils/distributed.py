@@ -138,6 +138,26 @@ class GradientExchange:
             lo0, hi0 = self._pending.pop(0)
             self._send(lo0, hi0)
 
+    def reduce_span(self, lo, hi, after=None):
+        """All-reduce (SUM) flat_g[lo:hi] on the exchange's side stream once the work already enqueued on stream `after` (default:
+        the current stream) is done; returns immediately. `wait()` later orders the caller's stream after every such reduction."""
+        if self.world == 1 or hi <= lo:
+            return
+        buf = self.arena.flat_g[lo:hi]
+        if self.on_gpu:
+            self.stream.wait_stream(after if after is not None else torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        if self.on_gpu and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._works = []
+
     def reduce_all(self, chunk_elems: int = 64 * 1024 * 1024):
         """Non-overlapped form used between the two hipGraphs of a captured step: all-reduce (SUM) the whole gradient arena on
         the caller's stream, in chunks of at most `chunk_elems` (256 MB of f32) so RCCL pipelines the rings. The update kernel

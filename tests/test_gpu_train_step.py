@@ -233,8 +233,9 @@ def test_graph_replay_matches_eager_steps():
 
 
 def test_graph_two_segment_step_with_exchange_single_rank():
-    """Data-parallel form of the captured step: [forward + backward] graph, eager all-reduce of the whole gradient arena, [norm +
-    update] graph. Forced on with one real rank pretending world_size 2 (the SUM over one rank is the identity; the update applies
+    """Data-parallel form of the captured step: one hipGraph per phase (image/text forward, heads, image/text backward, update)
+    with the all-reduces of the three gradient regions issued eagerly on the exchange stream between them. Forced on with one
+    real rank pretending world_size 2 (the SUM over one rank is the identity; the update applies
     the 1/2), against the eager step with the overlapped exchange under the same pretence. Tolerances as in the test above."""
     import torch.distributed as tdist
     from clip_lite_amd.encoder import ImageEncoder, TextEncoder
@@ -265,7 +266,7 @@ def test_graph_two_segment_step_with_exchange_single_rank():
         step = TrainStep(M, opt, sched, GradScaler(True), 10.0, ex, graph=graph, graph_warmup=1)
         losses = [step(batch)["loss"].item() for _ in range(5)]
         torch.cuda.synchronize()
-        assert (step._g_update is not None) == graph
+        assert (step._graphs is not None) == graph           # phase graphs on two streams with the all-reduces between them
         results.append((losses, M.runtime.arena.flat_p - p_init))
     tdist.destroy_process_group()
     (l0, d0), (l1, d1) = results
