@@ -34,6 +34,8 @@ template <typename T> struct Cfg {
   static constexpr int BK = 64 / (int)sizeof(T);        // 64 bytes of K per tile row: bf16 -> 32, f32 -> 16
   typedef TileCfg<128, 128, BK, 64, 64> C128;
   typedef TileCfg<256, 64, BK, 64, 64> C256x64;
+  typedef TileCfg<64, 128, BK, 64, 32> C64x128;     // weight gradients of convs with <= 64 output channels
+  typedef TileCfg<128, 64, BK, 32, 64> C128x64;     // ... or <= 64 (r, s, ci) columns
 };
 
 // The LDS-DMA pipelined kernel is the default; CLITE_IGEMM_LEGACY=1 selects the register-staged kernel (A/B timing, debugging).
@@ -62,7 +64,7 @@ template <typename T, int COLS, int BK> struct ToDma<GatherXC<T, COLS, BK>> {
 };
 
 template <typename T, class CFG, class LA, class LB>
-int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, int Ktot, int splits, hipStream_t st) {
+int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, int Ktot, int splits, hipStream_t st, RowMap rm = RowMap{}) {
   int ktiles = (Ktot + CFG::BK - 1) / CFG::BK;
   if (splits < 1) splits = 1;
   if (splits > ktiles) splits = ktiles;
@@ -76,13 +78,13 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
     constexpr int STAGE = DA::BYTES + DB::BYTES;
     bool deep = 4 * STAGE <= 65536 && (long)tiles * splits <= 2 * 256 && per >= 4 && stages_pref() != 3;
     if (deep || (stages_pref() == 4 && 4 * STAGE <= 65536))
-      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 4>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep,
+      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 4>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
                          M, N, ktiles, per);
     else
-      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep,
+      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
                          M, N, ktiles, per);
   } else {
-    hipLaunchKernelGGL((igemm_kernel<T, CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, M, N, ktiles, per);
+    hipLaunchKernelGGL((igemm_kernel<T, CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, rm, M, N, ktiles, per);
   }
   return (int)hipGetLastError();
 }
@@ -90,8 +92,8 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
 // Split-K factor for float-atomic accumulation (weight gradients). Every split adds a full output tile of atomic traffic
 // (chip-wide ~1.3 TB/s) plus a prologue/epilogue, so split only as far as needed to give every CU about two workgroups, and
 // never below 8 K tiles per split.
-int pick_splits(int M, int N, int ktiles) {
-  long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+int pick_splits(int M, int N, int ktiles, int BM = 128, int BN = 128) {
+  long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   long want = (512 + tiles - 1) / tiles;
   long cap = ktiles / 8;
   if (cap < 1) cap = 1;
@@ -200,6 +202,22 @@ int conv_dgrad(const void* dy, const void* w, const clite_conv& c, const clite_e
   constexpr int BK = Cfg<T>::BK;
   int M = c.N * c.H * c.W, Ktot = c.R * c.S * c.K;
   uint32_t yb = (uint32_t)((size_t)c.N * c.Ho * c.Wo * c.K * sizeof(T)), wb = (uint32_t)((size_t)c.K * c.R * c.S * c.C * sizeof(T));
+  if (c.R == 1 && c.S == 1 && c.pad == 0 && c.stride > 1 && ep->residual == ep->out && !ep->colsum && !ep->preact && !ep->dact_aux) {
+    // 1x1 / stride-s shortcut conv accumulated in place (dx += dgrad): only every s-th pixel of dx receives a contribution, so run
+    // the dense GEMM dy[P][K] * W[K][C] over the P output pixels and scatter-add its rows (RowMap) instead of gathering a mostly
+    // empty im2col over all N*H*W input pixels (s*s times the work)
+    int P = c.N * c.Ho * c.Wo;
+    RowMap rm;
+    rm.on = 1; rm.div_hw = fastdiv_make(c.Ho * c.Wo); rm.div_w = fastdiv_make(c.Wo); rm.H = c.H; rm.W = c.W; rm.stride = c.stride;
+    if (c.C <= 64) {
+      GatherKC<T, 256, BK, false> la{dy, yb, geom_dense(P, c.K)};
+      StridedXC<T, 64, BK> lb{w, wb, c.C, c.C, c.K, 1};
+      return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, P, c.C, c.K, 1, st, rm);
+    }
+    GatherKC<T, 128, BK, false> la{dy, yb, geom_dense(P, c.K)};
+    StridedXC<T, 128, BK> lb{w, wb, c.C, c.C, c.K, 1};
+    return launch<T, typename Cfg<T>::C128>(la, lb, *ep, P, c.C, c.K, 1, st, rm);
+  }
   if (c.C <= 64) {
     GatherKC<T, 256, BK, true> la{dy, yb, geom_dgrad(c)};
     StridedXC<T, 64, BK> lb{w, wb, c.R * c.S * c.C, c.C, c.K, c.R * c.S};
@@ -217,6 +235,16 @@ int conv_wgrad(const void* dy, const void* x, const clite_conv& c, float* dw, hi
   uint32_t yb = (uint32_t)((size_t)P * c.K * sizeof(T)), xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * sizeof(T));
   clite_epilogue ep = {};
   ep.out = dw; ep.ldc = Ncols; ep.out_f32 = 1; ep.atomic = 1; ep.alpha = 1.f;
+  if (c.K <= 64) {          // a 128-row tile would be half empty
+    StridedXC<T, 64, BK> la{dy, yb, c.K, c.K, P, 1};
+    GatherXC<T, 128, BK> lb{x, xb, geom_fwd(c)};
+    return launch<T, typename Cfg<T>::C64x128>(la, lb, ep, c.K, Ncols, P, pick_splits(c.K, Ncols, (P + BK - 1) / BK, 64, 128), st);
+  }
+  if (Ncols <= 64) {
+    StridedXC<T, 128, BK> la{dy, yb, c.K, c.K, P, 1};
+    GatherXC<T, 64, BK> lb{x, xb, geom_fwd(c)};
+    return launch<T, typename Cfg<T>::C128x64>(la, lb, ep, c.K, Ncols, P, pick_splits(c.K, Ncols, (P + BK - 1) / BK, 128, 64), st);
+  }
   StridedXC<T, 128, BK> la{dy, yb, c.K, c.K, P, 1};
   GatherXC<T, 128, BK> lb{x, xb, geom_fwd(c)};
   int splits = pick_splits(c.K, Ncols, (P + BK - 1) / BK);

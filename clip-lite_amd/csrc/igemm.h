@@ -266,6 +266,23 @@ DEV float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// Optional remap of GEMM rows to rows of the output (and of the residual / aux tensors): GEMM row p = (n, ho, wo) over an
+// [N][Ho][Wo] grid lands on pixel (n, ho*stride, wo*stride) of an [N][H][W] tensor. Used by the 1x1 / stride-2 dgrad, which is a
+// dense GEMM over the output pixels scattered into every stride-th input pixel.
+struct RowMap {
+  int on;
+  FastDiv div_hw, div_w;   // by Ho*Wo and by Wo
+  int H, W, stride;
+};
+DEV size_t map_row(const RowMap& rm, int row) {
+  if (!rm.on) return (size_t)row;
+  uint32_t n = fd_div(row, rm.div_hw);
+  uint32_t rem = row - n * rm.div_hw.d;
+  uint32_t ho = fd_div(rem, rm.div_w);
+  uint32_t wo = rem - ho * rm.div_w.d;
+  return ((size_t)n * rm.H + ho * rm.stride) * rm.W + wo * rm.stride;
+}
+
 template <int BM_, int BN_, int BK_, int WM_, int WN_>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
@@ -279,7 +296,7 @@ struct TileCfg {
 // Fused epilogue shared by the register-staged and the LDS-DMA kernels. `smem` must be free (all waves past their last
 // fragment read) and at least max(CFG::EPI_BYTES, 16 KB) large.
 template <typename T, class CFG>
-DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, char* smem, int M, int N, int m0, int n0,
+DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
                         int tid, int lane, int wave, int wm0, int wn0) {
   constexpr int BN = CFG::BN;
   constexpr int RM = CFG::RM, RN = CFG::RN;
@@ -336,7 +353,7 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cha
         const float* src = (const float*)(smem + rr * CFG::EPI_PITCH + ecol * 4);
         f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        size_t gidx = (size_t)grow * ep.ldc + gcol;
+        size_t gidx = map_row(rm, grow) * ep.ldc + gcol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
         if (ep.preact) store8((T*)ep.preact + gidx, v);
@@ -408,7 +425,7 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cha
 }
 
 template <typename T, class CFG, class LA, class LB>
-__global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, int M, int N, int ktiles, int ktiles_per_split) {
+__global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
@@ -499,7 +516,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, i
     __syncthreads();
   }
 
-  igemm_epilogue<T, CFG>(acc, ep, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  igemm_epilogue<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
 }
 
 }  // namespace clite

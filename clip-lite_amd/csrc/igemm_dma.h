@@ -256,7 +256,7 @@ template <typename T, int ROWS, int BK, bool D> struct DmaIssue<DmaKC<T, ROWS, B
 };
 
 template <typename T, class CFG, class LA, class LB, int NSTAGE>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, int M, int N, int ktiles, int ktiles_per_split) {
+__global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
     if (++buf == NSTAGE) buf = 0;
   }
   barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
-  igemm_epilogue<T, CFG>(acc, ep, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  igemm_epilogue<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
 }
 
 }  // namespace clite

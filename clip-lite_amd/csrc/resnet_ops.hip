@@ -164,11 +164,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   float v[16];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { v[e] = s1[e]; v[8 + e] = s2[e]; }
-  if (chunk_fold<16>(v, CPR, red)) {
-    float* dst = dstats + (size_t)(blockIdx.x % R) * RS + c0;
+  const bool owner = chunk_fold<16>(v, CPR, red);
+  __syncthreads();            // everyone is done reading `red`
+  if (owner) {                // re-stage as [2][C] so that consecutive lanes add to consecutive addresses (full-rate float atomics)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { atomic_add_f32(dst + e, v[e]); atomic_add_f32(dst + C + e, v[8 + e]); }
+    for (int e = 0; e < 8; ++e) { red[c0 + e] = v[e]; red[C + c0 + e] = v[8 + e]; }
   }
+  __syncthreads();
+  float* dst = dstats + (size_t)(blockIdx.x % R) * RS;
+  for (int i = tid; i < 2 * C; i += 256) atomic_add_f32(dst + i, red[i]);
 }
 
 // second pass of a two-pass variance: stats[2][c] += sum (y - mean_c)^2 with mean_c = stats[0][c] / M

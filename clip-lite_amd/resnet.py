@@ -248,9 +248,8 @@ def resnet_backward(rt, net, ctx, dfeat):
                 if ud is not None:
                     if ud.conv.weight.requires_grad:
                         rt.aux_launch(lambda dyd=dyd, ud=ud: hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight)), dyd)
-                    dx2 = _alloc(rt, u.x.shape[0], Cin)
-                    hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx2, Cin, residual=dx))
-                    dx = dx2
+                    # shortcut branch accumulated in place (dx += dgrad); a strided 1x1 shortcut takes the scatter-add path of clite_conv_dgrad
+                    hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx, Cin, residual=dx))
                 dout = dx
         rt.grads_ready(blocks[bi])
     xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq = ctx["stem"]

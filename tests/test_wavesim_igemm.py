@@ -105,7 +105,7 @@ def conv_wgrad_ref(dy, x, wshape, stride, pad):
 
 
 CASES = [(2, 8, 8, 32, 64, 3, 3, 1, 1), (2, 9, 7, 64, 32, 3, 3, 2, 1), (3, 6, 6, 64, 128, 1, 1, 1, 0),
-         (2, 8, 8, 32, 64, 1, 1, 2, 0), (1, 10, 10, 32, 160, 3, 3, 1, 1)]
+         (2, 8, 8, 32, 64, 1, 1, 2, 0), (1, 10, 10, 32, 160, 3, 3, 1, 1), (2, 9, 7, 128, 136, 1, 1, 2, 0), (2, 6, 6, 136, 64, 1, 1, 1, 0), (2, 6, 6, 32, 136, 1, 1, 1, 0)]
 
 
 @pytest.mark.parametrize("dtype,N,H,W,Cc,K,R,S,st,pad", [(BF16,) + c for c in CASES] + [(F32,) + CASES[1], (F32,) + CASES[3]])
@@ -134,6 +134,13 @@ def test_conv_fwd_dgrad_wgrad(dtype, N, H, W, Cc, K, R, S, st, pad):
     dw = np.zeros((K, R, S, Cc), np.float32)
     assert lib().clite_conv_wgrad(ptr(dyb), ptr(xb), C.byref(cv), ptr(dw), None) == 0
     _close(dw, conv_wgrad_ref(dy, x, w.shape, st, pad))
+    # in-place accumulation dx += dgrad (residual == out, both in the call's dtype): the strided 1x1 case takes the dense-GEMM +
+    # scatter-add path
+    r0, r0b = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), dtype)
+    buf = r0b.copy()
+    want = r0 + conv_dgrad_ref(dy, w, x.shape, st, pad)
+    assert lib().clite_conv_dgrad(ptr(dyb), ptr(wb), C.byref(cv), C.byref(make_ep(buf, Cc, out_f32=False, residual=buf)), None) == 0
+    _close(from_bf16(buf) if dtype == BF16 else buf, want, 8e-3 if dtype == BF16 else 2e-3)
 
 
 @pytest.mark.parametrize("dtype", [BF16, F32])
