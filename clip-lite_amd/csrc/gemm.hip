@@ -49,6 +49,13 @@ int stages_pref() {      // CLITE_IGEMM_STAGES=3|4 forces a ring depth (timing e
   if (v < 0) { const char* e = getenv("CLITE_IGEMM_STAGES"); v = e ? atoi(e) : 0; }
   return v;
 }
+int g2_pref() {          // CLITE_IGEMM_G2=0 disables, =2 forces the two-K-group kernel (timing experiments); default 1: small grids only
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CLITE_IGEMM_G2"); v = e ? atoi(e) : 1; }
+  return v;
+}
+template <class L> struct IsDgrad { static constexpr bool value = false; };
+template <typename T, int ROWS, int BK> struct IsDgrad<GatherKC<T, ROWS, BK, true>> { static constexpr bool value = true; };
 template <class L> struct ToDma;
 template <typename T, int ROWS, int BK, bool D> struct ToDma<GatherKC<T, ROWS, BK, D>> {
   typedef DmaKC<T, ROWS, BK, D> type;
@@ -76,6 +83,22 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
     typedef typename ToDma<LB>::type DB;
     // a grid that gives each CU at most ~2 workgroups hides DMA latency with a deeper ring instead (4 stages x 16 KB = 64 KB)
     constexpr int STAGE = DA::BYTES + DB::BYTES;
+    if (ep.bn_y || ep.mask_after_residual) {     // BatchNorm-backward epilogue: its own (register-heavier) instantiation, dgrad loaders only
+      if constexpr (IsDgrad<LA>::value) {
+        hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, true>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+                           M, N, ktiles, per);
+        return (int)hipGetLastError();
+      } else {
+        return -1;
+      }
+    }
+    // at most one workgroup per CU: two K-groups per workgroup (8 waves, in-workgroup split-K) instead of one wave per SIMD. bf16 only:
+    // the exact-f32 parity mode keeps one k-ordered fmaf chain per output, which is what tracks the CPU reference most closely
+    if (g2_pref() != 0 && 6 * STAGE <= 160 * 1024 && (((long)tiles * splits <= 256 && per >= 8 && sizeof(T) == 2) || g2_pref() == 2)) {
+      hipLaunchKernelGGL((igemm_dma_kernel_g2<T, CFG, DA, DB, 3>), dim3(tiles, 1, splits), dim3(512), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+                         M, N, ktiles, per);
+      return (int)hipGetLastError();
+    }
     bool deep = 4 * STAGE <= 65536 && (long)tiles * splits <= 2 * 256 && per >= 4 && stages_pref() != 3;
     if (deep || (stages_pref() == 4 && 4 * STAGE <= 65536))
       hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 4>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,

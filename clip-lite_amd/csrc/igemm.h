@@ -295,7 +295,10 @@ struct TileCfg {
 
 // Fused epilogue shared by the register-staged and the LDS-DMA kernels. `smem` must be free (all waves past their last
 // fragment read) and at least max(CFG::EPI_BYTES, 16 KB) large.
-template <typename T, class CFG>
+// HEAVY = the BatchNorm-backward form (clite_epilogue.bn_y / mask_after_residual, operands prefetched two rows at a time). It costs
+// ~45 more registers than the plain form, which would take every kernel from 3 to 2 workgroups per CU, so it is a separate
+// instantiation used only by the launches that ask for it (conv dgrad inside the ResNet backward).
+template <typename T, class CFG, bool HEAVY = false>
 DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
                         int tid, int lane, int wave, int wm0, int wn0) {
   constexpr int BN = CFG::BN;
@@ -328,7 +331,36 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
 #pragma unroll
   for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; }
 
+  // per-column constants of this thread's 8 columns
+  const int gcol = n0 + ecol;
+  const bool colok = gcol < N;
+  constexpr int ITER = CFG::WM / RPSE;      // rows of a pass handled by one thread
+  static_assert(CFG::WM % RPSE == 0, "tile shape");
+
   for (int pass = 0; pass < CFG::WAVES_M; ++pass) {
+    // the epilogue operands (activation-derivative aux, BatchNorm input, residual) of all rows this thread will write in this pass
+    // are requested up front, before the accumulators go through LDS: their latency overlaps the staging instead of being paid
+    // once per row
+    constexpr int PF = !HEAVY ? 1 : (ITER < 2 ? ITER : 2);       // rows prefetched at a time (register budget: 3 operands x PF x 16 B)
+    Raw8<T> pa[PF], py[PF], pr[PF];
+    uint32_t gix[PF];       // element offsets (every tensor of the step has < 2^30 elements: gemm.hip fits32)
+    bool okr[PF];
+    auto prefetch = [&](int it0) {
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        int grow = m0 + pass * CFG::WM + erow0 + (it0 + q) * RPSE;
+        okr[q] = colok && grow < M;
+        gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
+        if constexpr (HEAVY) {
+          if (okr[q]) {
+            if (ep.dact_aux) pa[q].ld((const T*)ep.dact_aux + gix[q]);
+            if (ep.bn_y) py[q].ld((const T*)ep.bn_y + gix[q]);
+            if (ep.residual) pr[q].ld((const T*)ep.residual + gix[q]);
+          }
+        }
+      }
+    };
+    prefetch(0);
     if (wave / CFG::WAVES_N == pass) {
 #pragma unroll
       for (int i = 0; i < RM; ++i)
@@ -342,62 +374,85 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
           }
     }
     __syncthreads();
-    const int gcol = n0 + ecol;
-    if (gcol < N) {
-      float bias[8];
+    float bias[8], bn_mean[8];          // per-column constants (L2-resident; reloaded per pass to keep them out of the staging phase's registers)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bias[e] = ep.bias ? ep.bias[gcol + e] : 0.f;
-      for (int rr = erow0; rr < CFG::WM; rr += RPSE) {
-        int grow = m0 + pass * CFG::WM + rr;
-        if (grow >= M) break;
-        const float* src = (const float*)(smem + rr * CFG::EPI_PITCH + ecol * 4);
-        f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        size_t gidx = map_row(rm, grow) * ep.ldc + gcol;
+    for (int e = 0; e < 8; ++e) { bias[e] = (colok && ep.bias) ? ep.bias[gcol + e] : 0.f; bn_mean[e] = 0.f; }
+    if (HEAVY && colok && ep.bn_y) {
+      for (int r = 0; r < ep.bn_replicas; ++r)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
-        if (ep.preact) store8((T*)ep.preact + gidx, v);
-        if (ep.act == ACT_RELU) {
+        for (int e = 0; e < 8; ++e) bn_mean[e] += ep.bn_stats[(size_t)r * ep.bn_rstride + gcol + e];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (ep.act == ACT_GELU) {
+      for (int e = 0; e < 8; ++e) bn_mean[e] *= ep.bn_inv_count;
+    }
+    for (int it0 = 0; it0 < ITER; it0 += PF) {
+      if (it0 > 0) prefetch(it0);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-        } else if (ep.act == ACT_TANH) {
+      for (int q = 0; q < PF; ++q) {
+      if (!okr[q]) continue;
+      const int rr = erow0 + (it0 + q) * RPSE;
+      const float* src = (const float*)(smem + rr * CFG::EPI_PITCH + ecol * 4);
+      f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const size_t gidx = gix[q];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
+      if (ep.preact) store8((T*)ep.preact + gidx, v);
+      if (ep.act == ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (ep.act == ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      } else if (ep.act == ACT_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+      }
+      float dfac[8];
+      if (ep.dact_aux) {
+        float av[8];
+        if constexpr (HEAVY) pa[q].get(av); else load8((const T*)ep.dact_aux + gidx, av);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float a = av[e];
+          dfac[e] = ep.dact == 1 ? (a > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_f(a) : (1.f - a * a);
         }
-        if (ep.dact_aux) {
-          float av[8];
-          load8((const T*)ep.dact_aux + gidx, av);
+        if (!HEAVY || !ep.mask_after_residual) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float a = av[e];
-            float d = ep.dact == 1 ? (a > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_f(a) : (1.f - a * a);
-            v[e] *= d;
-          }
+          for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
         }
-        if (ep.drop_p > 0.f) {
-          float u[8];
-          dropout_uniform8(drop_seed, drop_site, gidx, u);
+      }
+      if (ep.drop_p > 0.f) {
+        float u[8];
+        dropout_uniform8(drop_seed, drop_site, gidx, u);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = u[e] >= ep.drop_p ? v[e] * keep_scale : 0.f;
-        }
-        if (ep.residual) {
-          float rv[8];
-          load8((const T*)ep.residual + gidx, rv);
+        for (int e = 0; e < 8; ++e) v[e] = u[e] >= ep.drop_p ? v[e] * keep_scale : 0.f;
+      }
+      if (ep.residual) {
+        float rv[8];
+        if constexpr (HEAVY) pr[q].get(rv); else load8((const T*)ep.residual + gidx, rv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rv[e];
-        }
-        if (ep.out_f32 || sizeof(T) == 4) {
-          store8((float*)ep.out + gidx, v);
-        } else {
-          store8((bf16*)ep.out + gidx, v);
-          round8_bf16(v);   // statistics of what was stored
-        }
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (HEAVY && ep.dact_aux && ep.mask_after_residual) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
+      }
+      if (ep.out_f32 || sizeof(T) == 4) {
+        store8((float*)ep.out + gidx, v);
+      } else {
+        store8((bf16*)ep.out + gidx, v);
+        round8_bf16(v);   // statistics of what was stored
+      }
+      if (HEAVY && ep.bn_y) {
+        float yv[8];
+        py[q].get(yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * (yv[e] - bn_mean[e]); }
+      } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
       }
+    }
     }
     __syncthreads();
   }

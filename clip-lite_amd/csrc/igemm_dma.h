@@ -16,6 +16,9 @@
 //   XC image [BK][cols*sizeof(T)]: 64-B segment s of k-row k sits in segment s ^ f(k)   -> conflict-free ds_read_b64_tr_b16
 #ifndef CLITE_IGEMM_DMA_H
 #define CLITE_IGEMM_DMA_H
+#ifndef CLITE_ABLATE
+#define CLITE_ABLATE 0      // diagnostic builds only (tools/ablate.sh): 1 = main loop without LDS reads / MFMAs, 2 = without the DMA loads
+#endif
 #include "igemm.h"
 
 namespace clite {
@@ -255,7 +258,7 @@ template <typename T, int ROWS, int BK, bool D> struct DmaIssue<DmaKC<T, ROWS, B
   DEV static void go(const L& l, typename L::State& st, char* lds, int wave, int, int) { l.issue(st, lds, wave); }
 };
 
-template <typename T, class CFG, class LA, class LB, int NSTAGE>
+template <typename T, class CFG, class LA, class LB, int NSTAGE, bool HEAVY = false>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
@@ -321,13 +324,16 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
     else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
     else wait_vmcnt<0>();
     barrier_raw();
+#if CLITE_ABLATE != 2
     if (t + NSTAGE - 1 < t_end) {
       int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
       DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
       DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
     }
+#endif
     const char* abuf = smem + buf * STAGE;
     const char* bbuf = abuf + LA::BYTES;
+#if CLITE_ABLATE != 1
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
@@ -355,10 +361,160 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
           for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
       }
     }
+#else
+    asm volatile("" :: "v"(abuf), "v"(bbuf));
+#endif
     if (++buf == NSTAGE) buf = 0;
   }
   barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
-  igemm_epilogue<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  igemm_epilogue<T, CFG, HEAVY>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+}
+
+
+// ---- two K-groups per workgroup -------------------------------------------------------------------------------------------
+// Small grids (at most one workgroup per CU: the BERT GEMMs with N = 768, the 7x7-resolution convs) leave each SIMD with a single
+// wave whose DMA issue, LDS reads and MFMAs serialise. Here a workgroup has 8 waves = 2 groups of 4; group g runs the pipeline
+// above over its own half of the K tiles with its own LDS ring (an in-workgroup split-K that shares only the barriers), so every
+// SIMD hosts two independent MFMA streams. Group 1 then hands its accumulators to group 0 through LDS and group 0 runs the fused
+// epilogue; group 1 only keeps the barrier count.
+template <typename T, class CFG, class LA, class LB, int NSTAGE>
+__global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int RING = NSTAGE * STAGE;
+  constexpr int XCHG = BM * BN * 4;                         // group 1's accumulators, f32, thread-major
+  constexpr int NEED = 2 * RING > XCHG ? 2 * RING : XCHG;
+  constexpr int SMEM = NEED > CFG::EPI_BYTES ? NEED : CFG::EPI_BYTES;
+  constexpr int LOADS_PER_TILE = LA::NI + LB::NI;
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x & 255;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;                                // wave index inside the group
+  const int group = threadIdx.x >> 8;
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tm = wg / tiles_n;
+  const int tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int s_begin = blockIdx.z * ktiles_per_split;
+  int s_end = s_begin + ktiles_per_split;
+  if (s_end > ktiles) s_end = ktiles;
+  const int half = (s_end - s_begin + 1) >> 1;              // group 0 takes the first `half` tiles, group 1 the rest
+  const int t_begin = s_begin + group * half;
+  const int t_end = group == 0 ? s_begin + half : s_end;
+  char* ring = smem + group * RING;
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, wave, lane, t_begin);
+  lb.init(sb, n0, wave, lane, t_begin);
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int aoff[RM][BK / 16 > 0 ? BK / 16 : 1], boff[RN][BK / 16 > 0 ? BK / 16 : 1];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i) aoff[i][ks] = LA::frag_off(wm0 + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) boff[j][ks] = LB::frag_off(wn0 + j * 32, ks, lane);
+    }
+  }
+
+#pragma unroll
+  for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+    if (t_begin + pz < t_end) {
+      DmaIssue<LA>::go(la, sa, ring + pz * STAGE, wave, lane, m0);
+      DmaIssue<LB>::go(lb, sb, ring + pz * STAGE + LA::BYTES, wave, lane, n0);
+    }
+  }
+  int buf = 0;
+  for (int it = 0; it < half; ++it) {                       // both groups run `half` iterations: the barriers are workgroup-wide
+    const int t = t_begin + it;
+    const bool live = t < t_end;
+    const int after = t_end - 1 - t;
+    if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LOADS_PER_TILE>();
+    else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
+    else wait_vmcnt<0>();
+    barrier_raw();
+    if (t + NSTAGE - 1 < t_end) {
+      int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+      DmaIssue<LA>::go(la, sa, ring + nb * STAGE, wave, lane, m0);
+      DmaIssue<LB>::go(lb, sb, ring + nb * STAGE + LA::BYTES, wave, lane, n0);
+    }
+    if (live) {
+      const char* abuf = ring + buf * STAGE;
+      const char* bbuf = abuf + LA::BYTES;
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          bf16x8 af[RM], bfr[RN];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) af[i] = LA::frag_at(abuf + aoff[i][ks]);
+#pragma unroll
+          for (int j = 0; j < RN; ++j) bfr[j] = LB::frag_at(bbuf + boff[j][ks]);
+#pragma unroll
+          for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+          float af[RM], bfr[RN];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
+#pragma unroll
+          for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
+#pragma unroll
+          for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+        }
+      }
+    }
+    if (++buf == NSTAGE) buf = 0;
+  }
+  __syncthreads();          // (no DMA is outstanding any more) every wave is past its last fragment read: the LDS is free
+  // group 1 -> group 0: element (i, j, r) of thread tid at ((i*RN + j)*16 + r)*256 + tid  (consecutive lanes, consecutive words)
+  float* xchg = (float*)smem;
+  if (group == 1) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xchg[((i * RN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
+  }
+  __syncthreads();
+  if (group == 0) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += xchg[((i * RN + j) * 16 + r) * 256 + tid];
+  }
+  __syncthreads();
+  if (group == 0) {
+    igemm_epilogue<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  } else if (!ep.atomic) {   // keep the workgroup barrier count of igemm_epilogue
+    for (int pass = 0; pass < CFG::WAVES_M; ++pass) { __syncthreads(); __syncthreads(); }
+    if (ep.colsum) __syncthreads();
+  }
 }
 
 }  // namespace clite

@@ -32,6 +32,26 @@ DEV void round8_bf16(float (&v)[8]) {
   for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
 }
 
+// 8 consecutive elements held raw (as loaded) until they are needed: lets a kernel issue several loads before converting any
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+  u32x4 a;
+  DEV void ld(const bf16* p) { a = *(const u32x4*)p; }
+  DEV void get(float (&v)[8]) const {
+    Chunk16 c;
+    c.u = a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = bf2f(c.e[e]);
+  }
+};
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  DEV void ld(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+  DEV void get(float (&v)[8]) const {
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  }
+};
+
 DEV void zero8(float (&v)[8]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;

@@ -9,8 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libclite_hip.so")
-ABI_VERSION = 1
+LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
+ABI_VERSION = 2
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -27,6 +27,8 @@ class Epilogue(C.Structure):
         ("dact_aux", C.c_void_p), ("dact", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
         ("drop_site", C.c_uint32), ("residual", C.c_void_p), ("colsum", C.c_void_p),
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32),
+        ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
+        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32),
     ]
 
 
@@ -153,7 +155,8 @@ class Stats:
 
 
 def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
-             drop=None, residual=None, colsum=None, out_f32=None):
+             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False):
+    """bn = (y, stats: Stats, rows): accumulate the BatchNorm-backward reductions (sum v, sum v*(y - mean)) into `colsum`."""
     ep = Epilogue()
     ep.out = p(out)
     ep.ldc = ldc if ldc is not None else out.shape[-1]
@@ -172,6 +175,10 @@ def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, pr
         ep.colsum, ep.colsum_replicas, ep.colsum_stride = p(colsum.t), colsum.R, colsum.rstride
     else:
         ep.colsum = p(colsum)
+    if bn is not None:
+        y, st, rows = bn
+        ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = p(y), p(st.t), st.R, st.rstride, 1.0 / rows
+    ep.mask_after_residual = int(mask_after_residual)
     return ep
 
 

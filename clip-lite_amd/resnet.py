@@ -215,41 +215,81 @@ def _bn_backward(rt, u, dout, mask, N, want_dz=False, train_params=True):
     return dy, dz
 
 
+def _bn_backward_apply(rt, u, dz, dstats):
+    """BN backward of unit u given dz (gradient w.r.t. the BN output, ReLU mask already applied) and its two reductions `dstats`
+    (sum dz, sum dz*(y - mean)), both produced by the epilogue of the GEMM that wrote dz."""
+    M, Cc = u.y.shape
+    bn = u.bn
+    dy = _alloc(rt, M, Cc)
+    desc = hip.bn_desc(M, Cc, u.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn)
+    dg = rt.arena.g(bn.weight) if bn.weight.requires_grad else None
+    db = rt.arena.g(bn.bias) if bn.bias.requires_grad else None
+    hip.bn_bwd_apply(rt.dt, desc, dz, None, u.y, dstats, dy, None, dg, db)
+    return dy
+
+
 def resnet_backward(rt, net, ctx, dfeat):
-    """dfeat: [N][C] gradient of the pooled features (compute dtype). Accumulates parameter gradients into the arena."""
+    """dfeat: [N][C] gradient of the pooled features (compute dtype). Accumulates parameter gradients into the arena.
+
+    BatchNorm backward needs two per-channel reductions over the masked incoming gradient before it can produce its output. Where
+    that gradient is written by a dgrad GEMM, the GEMM's epilogue applies the ReLU mask and accumulates both reductions while it
+    stores (clite_epilogue.bn_y), so the separate reduction pass (3 tensor reads) disappears: inside a block for every unit but the
+    last, and across blocks whenever the block-input gradient comes out of one kernel (identity shortcut)."""
     N = ctx["N"]
     dt = rt.dt
     Hc, Wc, Cout = ctx["final"]
     dout = _alloc(rt, N * Hc * Wc, Cout)
     hip.avgpool_bwd(dt, dfeat, dout, N, Hc * Wc, Cout)
     blocks = list(net.blocks())
-    for bi, (units, ud, Hin, Win) in reversed(list(enumerate(ctx["recs"]))):
+    recs = ctx["recs"]
+    pre = None          # when set: `dout` is already masked by the block-output ReLU and `pre` holds the last unit's reductions
+    for bi in range(len(recs) - 1, -1, -1):
+        units, ud, Hin, Win = recs[bi]
         last = units[-1]
-        xin = units[0].x
         identity = ud is None
         # block output = relu(bn_last(y_last) + shortcut): the mask is the block output itself
-        dy, dz = _bn_backward(rt, last, dout, last.out, N, want_dz=identity)
         dyd = None
-        if ud is not None:
-            dyd, _ = _bn_backward(rt, ud, dout, last.out, N)
+        if pre is None:
+            dy, dz = _bn_backward(rt, last, dout, last.out, N, want_dz=identity)
+            if ud is not None:
+                dyd, _ = _bn_backward(rt, ud, dout, last.out, N)
+        else:
+            dz = dout
+            dy = _bn_backward_apply(rt, last, dz, pre)
+            if ud is not None:
+                dyd, _ = _bn_backward(rt, ud, dz, None, N)
+        pre = None
         for i in range(len(units) - 1, -1, -1):
             u = units[i]
             if u.conv.weight.requires_grad:
                 rt.aux_launch(lambda dy=dy, u=u: hip.conv_wgrad(dy, u.x, u.cv, rt.arena.g(u.conv.weight)), dy)
             Cin = u.conv.in_channels
             dx = _alloc(rt, u.x.shape[0], Cin)
-            if i > 0:
+            if i > 0 and not rt.fuse_bn_backward:
                 hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin))
                 prev = units[i - 1]
                 dy, _ = _bn_backward(rt, prev, dx, prev.out, N)
+            elif i > 0:
+                prev = units[i - 1]
+                dstats = rt.new_stats(Cin)
+                hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv,
+                               hip.epilogue(dx, Cin, dact_aux=prev.out, dact=hip.DACT_RELU, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0])))
+                dy = _bn_backward_apply(rt, prev, dx, dstats)
             else:
                 # gradient w.r.t. the block input: main path + shortcut
-                hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None))
-                if ud is not None:
-                    if ud.conv.weight.requires_grad:
-                        rt.aux_launch(lambda dyd=dyd, ud=ud: hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight)), dyd)
-                    # shortcut branch accumulated in place (dx += dgrad); a strided 1x1 shortcut takes the scatter-add path of clite_conv_dgrad
-                    hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx, Cin, residual=dx))
+                if identity and bi > 0 and rt.fuse_bn_backward:
+                    pl = recs[bi - 1][0][-1]          # the previous block's last unit consumes this gradient
+                    pre = rt.new_stats(Cin)
+                    hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv,
+                                   hip.epilogue(dx, Cin, residual=dz, dact_aux=pl.out, dact=hip.DACT_RELU, mask_after_residual=True, colsum=pre,
+                                                bn=(pl.y, pl.stats, pl.y.shape[0])))
+                else:
+                    hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None))
+                    if ud is not None:
+                        if ud.conv.weight.requires_grad:
+                            rt.aux_launch(lambda dyd=dyd, ud=ud: hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight)), dyd)
+                        # shortcut branch accumulated in place (dx += dgrad); a strided 1x1 shortcut takes the scatter-add path of clite_conv_dgrad
+                        hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx, Cin, residual=dx))
                 dout = dx
         rt.grads_ready(blocks[bi])
     xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq = ctx["stem"]

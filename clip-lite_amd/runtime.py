@@ -193,6 +193,8 @@ class DeviceRuntime:
         self.side_stream = None    # the text encoder's stream (model.py), created on first use
         self.exchange = None
         self._spans = {}
+        import os
+        self.fuse_bn_backward = os.environ.get("CLITE_FUSE_BN", "1") != "0"     # BatchNorm-backward reductions inside the dgrad epilogues (resnet.py)
         self._aux_streams, self._aux_busy, self._aux_keep, self.overlap_wgrad = {}, set(), {}, False
         self.steps = 0
         self.seed_dev, self._capturing, self._slots, self.graph_slots, self._graph_next = None, False, 0, 0, -1

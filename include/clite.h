@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 1
+#define CLITE_ABI_VERSION 2
 int clite_abi_version(void);
 
 /* storage type of activations / weights handed to a kernel. CLITE_F32 selects the exact-f32 parity mode
@@ -39,7 +39,10 @@ enum { CLITE_BF16 = 0, CLITE_F32 = 1 };
 enum { CLITE_ACT_NONE = 0, CLITE_ACT_RELU = 1, CLITE_ACT_GELU = 2, CLITE_ACT_TANH = 3 };
 
 /* Fused GEMM epilogue. v = alpha*acc + bias; preact <- v; v = act(v); v *= act'(dact_aux);
- * v = dropout(v); v += residual; out <- v; colsum += (sum, sum of squares) of the stored values. */
+ * v = dropout(v); v += residual; [mask_after_residual: the act'(dact_aux) factor is applied here instead]; out <- v;
+ * colsum += (sum, sum of squares) of the stored values — or, when bn_y is given, (sum v, sum v*(bn_y - mean)): the two
+ * reductions of a BatchNorm backward over the tensor this GEMM produces (dz = masked gradient, bn_y = that BN's input,
+ * mean_c = sum over replicas of bn_stats[r*bn_rstride + c] * bn_inv_count), which saves the separate reduction pass. */
 typedef struct clite_epilogue {
   void* out;            /* [M][ldc] in the call's dtype, or f32 when out_f32 = 1 */
   int32_t ldc;
@@ -58,6 +61,12 @@ typedef struct clite_epilogue {
   float* colsum;        /* f32 [2][N] or NULL */
   int32_t colsum_replicas;  /* R > 1: workgroup b accumulates into colsum + (b % R) * colsum_stride (spreads same-address atomics) */
   int32_t colsum_stride;    /* elements between replicas */
+  const void* bn_y;         /* [M][ldc] in the call's dtype, or NULL (plain sum of squares) */
+  const float* bn_stats;    /* forward statistics of that BatchNorm: replicated [R][3][N] sums (row 0 = sum of y) */
+  int32_t bn_replicas;
+  int32_t bn_rstride;
+  float bn_inv_count;       /* 1 / rows of the BatchNorm */
+  int32_t mask_after_residual;
 } clite_epilogue;
 
 /* NHWC convolution problem. x: [N][H][W][C], w: [K][R][S][C], y: [N][Ho][Wo][K], all of `dtype`. */

