@@ -51,6 +51,7 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
         model, opt, sched = bench.build(args, device)
+    model.overlap_encoders = False      # per-launch timing: nothing else may share the chip
     step = TrainStep(model, opt, sched, GradScaler(True), 10.0, None)
     batches = bench.synthetic_batches(args, device, 0)
     for i in range(3):
