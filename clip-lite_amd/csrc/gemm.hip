@@ -84,6 +84,8 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
     // a grid that gives each CU at most ~2 workgroups hides DMA latency with a deeper ring instead (4 stages x 16 KB = 64 KB)
     constexpr int STAGE = DA::BYTES + DB::BYTES;
     if (ep.bn_y || ep.mask_after_residual) {     // BatchNorm-backward epilogue: its own (register-heavier) instantiation, dgrad loaders only
+      // it implements exactly: out = [(alpha*acc) (* relu'(aux))] (+ residual) [(* relu'(aux))], colsum; nothing else
+      if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || splits != 1) return -1;
       if constexpr (IsDgrad<LA>::value) {
         hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, true>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
                            M, N, ktiles, per);

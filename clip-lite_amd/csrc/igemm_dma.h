@@ -263,7 +263,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
-  constexpr int SMEM = (NSTAGE * STAGE > CFG::EPI_BYTES) ? NSTAGE * STAGE : CFG::EPI_BYTES;
+  constexpr int EPI = HEAVY ? CFG::BM * CFG::EPI_PITCH : CFG::EPI_BYTES;      // the BatchNorm-backward epilogue stages the whole tile
+  constexpr int SMEM = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
   constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
     if (++buf == NSTAGE) buf = 0;
   }
   barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
-  igemm_epilogue<T, CFG, HEAVY>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  if constexpr (HEAVY) igemm_epilogue_bn<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  else igemm_epilogue<T, CFG, false>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
 }
 
 
