@@ -87,6 +87,19 @@ def cpu_baseline(args):
         return {"value": None, "unit": "pairs/s", "cores": None, "kind": "port", "sample": f"cpu baseline did not finish within 240 s ({type(e).__name__})"}
 
 
+def pmc_traffic(args):
+    """HBM-side bytes of the igemm family per step (all 335 launches), from the committed PMC passes of this configuration
+    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be
+    collected inside a timed run, so this is the profiles/ measurement, not a live one. None for other configurations."""
+    if args.visual != "resnet50" or args.layers != 12 or args.batch != 128 or args.f32:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_igemm_hbm_traffic.json")) as f:
+            return json.load(f)["igemm_hbm_GB_per_step"] * 1e9
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def kernel_roofline(step_fn, batches, steps=3):
     """Average duration of the dominant kernel family (the implicit-GEMM engine: every conv / linear forward, dgrad and wgrad launch),
     measured with events recorded on the stream the kernels are launched on, against its algorithmic FLOPs."""
@@ -204,8 +217,9 @@ def main():
             "loss": loss, "launch": "hipGraph replay" if step.graph else "eager",
             "roofline": {"bound": "mfma", "kernel": "clite::igemm_kernel (all conv/linear fwd+dgrad+wgrad launches of one step)",
                          "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": None,
+                         "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": pmc_traffic(args),
                          "launches_per_step": n_launch, "kernel_ms_per_step": gemm_ms,
+                         "algorithmic_bytes": 21.0e9, "traffic_note": "bytes per step over the same launches; PMC passes in profiles/r1_igemm_hbm_traffic.json",
                          "whole_step_frac": FLOP_PER_PAIR * args.batch / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if gemm_tflops else None},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -119,7 +119,12 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
 // never below 8 K tiles per split.
 int pick_splits(int M, int N, int ktiles, int BM = 128, int BN = 128) {
   long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  long want = (512 + tiles - 1) / tiles;
+  static int target = -1;       // CLITE_SPLIT_TARGET: workgroups to aim for (timing experiments)
+  if (target < 0) { const char* e = getenv("CLITE_SPLIT_TARGET"); target = e ? atoi(e) : 0; }
+  // measured on the BERT weight gradients (K = 3840): few-tile outputs are fastest at ~1 workgroup per CU (768x768: 36 -> 27 us,
+  // 2304x768: 47 -> 45 us), larger ones at ~2 per CU
+  long tgt = target > 0 ? target : (tiles < 128 ? 256 : 512);
+  long want = (tgt + tiles - 1) / tiles;
   long cap = ktiles / 8;
   if (cap < 1) cap = 1;
   if (want > cap) want = cap;

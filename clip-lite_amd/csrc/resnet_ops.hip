@@ -256,7 +256,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
 int bn_grid(int M, int C, int* rows_per_block) {
   int CPR = C / 8, RPS = 256 / CPR;
   int sweeps = (M + RPS - 1) / RPS;
-  int want = (sweeps + 15) / 16;            // >= 16 row sweeps per workgroup amortise the per-channel coefficient prologue
+  // 16 row sweeps per workgroup amortise the per-channel coefficient prologue on large tensors; small tensors (layer3/4: a few MB)
+  // are latency-bound instead and want every CU busy: down to 4 sweeps per workgroup until there are ~1024 workgroups
+  int spw = sweeps / 1024;
+  spw = spw < 4 ? 4 : (spw > 16 ? 16 : spw);
+  int want = (sweeps + spw - 1) / spw;
   int grid = want < 1 ? 1 : (want > 1024 ? 1024 : want);
   int spb = (sweeps + grid - 1) / grid;
   *rows_per_block = spb * RPS;
