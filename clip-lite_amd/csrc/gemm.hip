@@ -78,6 +78,11 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
   int per = (ktiles + splits - 1) / splits;
   splits = (ktiles + per - 1) / per;
   int tiles = ((M + CFG::BM - 1) / CFG::BM) * ((N + CFG::BN - 1) / CFG::BN);
+  // >= 8 K splits: 1-D grid in which each XCD owns whole splits (igemm_dma.h); CLITE_XCD_SPLIT=0 keeps the (tile, split) grid
+  static int xs_pref = -1;
+  if (xs_pref < 0) { const char* e = getenv("CLITE_XCD_SPLIT"); xs_pref = e ? atoi(e) : 1; }
+  const int xsplits = (xs_pref && splits >= 8 && use_dma()) ? splits : 0;
+  const dim3 grid = xsplits ? dim3(8 * ((splits + 7) / 8) * tiles, 1, 1) : dim3(tiles, 1, splits);
   if (use_dma()) {
     typedef typename ToDma<LA>::type DA;
     typedef typename ToDma<LB>::type DB;
@@ -87,8 +92,8 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
       // it implements exactly: out = [(alpha*acc) (* relu'(aux))] (+ residual) [(* relu'(aux))], colsum; nothing else
       if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || splits != 1) return -1;
       if constexpr (IsDgrad<LA>::value) {
-        hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, true>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
-                           M, N, ktiles, per);
+        hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, true>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+                           M, N, ktiles, per, xsplits);
         return (int)hipGetLastError();
       } else {
         return -1;
@@ -97,17 +102,17 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
     // at most one workgroup per CU: two K-groups per workgroup (8 waves, in-workgroup split-K) instead of one wave per SIMD. bf16 only:
     // the exact-f32 parity mode keeps one k-ordered fmaf chain per output, which is what tracks the CPU reference most closely
     if (g2_pref() != 0 && 6 * STAGE <= 160 * 1024 && (((long)tiles * splits <= 256 && per >= 8 && sizeof(T) == 2) || g2_pref() == 2)) {
-      hipLaunchKernelGGL((igemm_dma_kernel_g2<T, CFG, DA, DB, 3>), dim3(tiles, 1, splits), dim3(512), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
-                         M, N, ktiles, per);
+      hipLaunchKernelGGL((igemm_dma_kernel_g2<T, CFG, DA, DB, 3>), grid, dim3(512), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+                         M, N, ktiles, per, xsplits);
       return (int)hipGetLastError();
     }
     bool deep = 4 * STAGE <= 65536 && (long)tiles * splits <= 2 * 256 && per >= 4 && stages_pref() != 3;
     if (deep || (stages_pref() == 4 && 4 * STAGE <= 65536))
-      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 4>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
-                         M, N, ktiles, per);
+      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 4>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+                         M, N, ktiles, per, xsplits);
     else
-      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3>), dim3(tiles, 1, splits), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
-                         M, N, ktiles, per);
+      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+                         M, N, ktiles, per, xsplits);
   } else {
     hipLaunchKernelGGL((igemm_kernel<T, CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, rm, M, N, ktiles, per);
   }
@@ -117,13 +122,13 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
 // Split-K factor for float-atomic accumulation (weight gradients). Every split adds a full output tile of atomic traffic
 // (chip-wide ~1.3 TB/s) plus a prologue/epilogue, so split only as far as needed to give every CU about two workgroups, and
 // never below 8 K tiles per split.
-int pick_splits(int M, int N, int ktiles, int BM = 128, int BN = 128) {
+int pick_splits(int M, int N, int ktiles, int BM = 128, int BN = 128, bool window = false) {
   long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   static int target = -1;       // CLITE_SPLIT_TARGET: workgroups to aim for (timing experiments)
   if (target < 0) { const char* e = getenv("CLITE_SPLIT_TARGET"); target = e ? atoi(e) : 0; }
-  // measured on the BERT weight gradients (K = 3840): few-tile outputs are fastest at ~1 workgroup per CU (768x768: 36 -> 27 us,
-  // 2304x768: 47 -> 45 us), larger ones at ~2 per CU
-  long tgt = target > 0 ? target : (tiles < 128 ? 256 : 512);
+  // measured inside the step (tools/layer_profile.py): dense / 1x1 weight gradients with few output tiles are fastest at ~1
+  // workgroup per CU (BERT 768x768: 39 -> 32 us; the 1x1 convs 5-15 % faster), windowed (3x3, 7x7) ones and larger outputs at ~2
+  long tgt = target > 0 ? target : ((tiles < 64 && !window) ? 256 : 512);
   long want = (tgt + tiles - 1) / tiles;
   long cap = ktiles / 8;
   if (cap < 1) cap = 1;
@@ -268,16 +273,16 @@ int conv_wgrad(const void* dy, const void* x, const clite_conv& c, float* dw, hi
   if (c.K <= 64) {          // a 128-row tile would be half empty
     StridedXC<T, 64, BK> la{dy, yb, c.K, c.K, P, 1};
     GatherXC<T, 128, BK> lb{x, xb, geom_fwd(c)};
-    return launch<T, typename Cfg<T>::C64x128>(la, lb, ep, c.K, Ncols, P, pick_splits(c.K, Ncols, (P + BK - 1) / BK, 64, 128), st);
+    return launch<T, typename Cfg<T>::C64x128>(la, lb, ep, c.K, Ncols, P, pick_splits(c.K, Ncols, (P + BK - 1) / BK, 64, 128, c.R * c.S > 1), st);
   }
   if (Ncols <= 64) {
     StridedXC<T, 128, BK> la{dy, yb, c.K, c.K, P, 1};
     GatherXC<T, 64, BK> lb{x, xb, geom_fwd(c)};
-    return launch<T, typename Cfg<T>::C128x64>(la, lb, ep, c.K, Ncols, P, pick_splits(c.K, Ncols, (P + BK - 1) / BK, 128, 64), st);
+    return launch<T, typename Cfg<T>::C128x64>(la, lb, ep, c.K, Ncols, P, pick_splits(c.K, Ncols, (P + BK - 1) / BK, 128, 64, c.R * c.S > 1), st);
   }
   StridedXC<T, 128, BK> la{dy, yb, c.K, c.K, P, 1};
   GatherXC<T, 128, BK> lb{x, xb, geom_fwd(c)};
-  int splits = pick_splits(c.K, Ncols, (P + BK - 1) / BK);
+  int splits = pick_splits(c.K, Ncols, (P + BK - 1) / BK, 128, 128, c.R * c.S > 1);
   return launch<T, typename Cfg<T>::C128>(la, lb, ep, c.K, Ncols, P, splits, st);
 }
 
@@ -314,7 +319,7 @@ int stem_wgrad(const void* dy, const void* xpad, int N, int Hp, int Wp, int Ho, 
   ep.out = dwv; ep.ldc = 224; ep.out_f32 = 1; ep.atomic = 1; ep.alpha = 1.f;
   StridedXC<T, 128, BK> la{dy, (uint32_t)((size_t)P * 64 * sizeof(T)), 64, 64, P, 1};
   GatherXC<T, 128, BK> lb{xpad, (uint32_t)((size_t)N * Hp * Wp * 4 * sizeof(T)), geom_stem(N, Hp, Wp, Ho, Wo)};
-  int splits = pick_splits(64, 224, (P + BK - 1) / BK);
+  int splits = pick_splits(64, 224, (P + BK - 1) / BK, 128, 128, true);
   return launch<T, typename Cfg<T>::C128>(la, lb, ep, 64, 224, P, splits, st);
 }
 

@@ -259,7 +259,7 @@ template <typename T, int ROWS, int BK, bool D> struct DmaIssue<DmaKC<T, ROWS, B
 };
 
 template <typename T, class CFG, class LA, class LB, int NSTAGE, bool HEAVY = false>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split) {
+__global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split, int xsplits) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
@@ -274,13 +274,25 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
   const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
   const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
 
-  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
-  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
   const int tiles_n = (N + BN - 1) / BN;
+  int wg, zsplit;
+  if (xsplits > 0) {
+    // split-K with >= 8 splits (weight gradients): all output tiles of one K range run on ONE XCD (workgroups b and b+8 share an XCD),
+    // so each operand panel is fetched into one L2 instead of eight; XCD x takes the splits x, x+8, ...
+    const int ntile = ((M + BM - 1) / BM) * tiles_n;
+    const int j = blockIdx.x >> 3;
+    zsplit = (blockIdx.x & 7) + 8 * (j / ntile);
+    wg = j % ntile;
+    if (zsplit >= xsplits) return;
+  } else {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+    wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    zsplit = blockIdx.z;
+  }
   const int tm = wg / tiles_n;
   const int tn = wg - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int t_begin = blockIdx.z * ktiles_per_split;
+  const int t_begin = zsplit * ktiles_per_split;
   int t_end = t_begin + ktiles_per_split;
   if (t_end > ktiles) t_end = ktiles;
 
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
 // SIMD hosts two independent MFMA streams. Group 1 then hands its accumulators to group 0 through LDS and group 0 runs the fused
 // epilogue; group 1 only keeps the barrier count.
 template <typename T, class CFG, class LA, class LB, int NSTAGE>
-__global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split) {
+__global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split, int xsplits) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
@@ -398,13 +410,25 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogu
   const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
   const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
 
-  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
-  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
   const int tiles_n = (N + BN - 1) / BN;
+  int wg, zsplit;
+  if (xsplits > 0) {
+    // split-K with >= 8 splits (weight gradients): all output tiles of one K range run on ONE XCD (workgroups b and b+8 share an XCD),
+    // so each operand panel is fetched into one L2 instead of eight; XCD x takes the splits x, x+8, ...
+    const int ntile = ((M + BM - 1) / BM) * tiles_n;
+    const int j = blockIdx.x >> 3;
+    zsplit = (blockIdx.x & 7) + 8 * (j / ntile);
+    wg = j % ntile;
+    if (zsplit >= xsplits) return;
+  } else {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+    wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    zsplit = blockIdx.z;
+  }
   const int tm = wg / tiles_n;
   const int tn = wg - tm * tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int s_begin = blockIdx.z * ktiles_per_split;
+  const int s_begin = zsplit * ktiles_per_split;
   int s_end = s_begin + ktiles_per_split;
   if (s_end > ktiles) s_end = ktiles;
   const int half = (s_end - s_begin + 1) >> 1;              // group 0 takes the first `half` tiles, group 1 the rest
