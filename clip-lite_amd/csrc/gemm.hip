@@ -21,7 +21,7 @@ ConvGeom geom_dense(int rows, int K, int ld = 0) {  // [rows][K] (row stride ld)
   ConvGeom g;
   g.H = 1; g.W = 1; g.C = K;
   g.sN = ld ? ld : K; g.sH = 0; g.sW = 0;
-  g.RH = 1; g.RW = 1; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0;
+  g.RH = 1; g.RW = 1; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.padw = 0;
   g.rows = rows;
   g.div_hw = fastdiv_make(1);
   g.div_w = fastdiv_make(1);
@@ -200,7 +200,7 @@ ConvGeom geom_fwd(const clite_conv& c) {   // rows = output pixels, gather x
   ConvGeom g;
   g.H = c.H; g.W = c.W; g.C = c.C;
   g.sN = c.H * c.W * c.C; g.sH = c.W * c.C; g.sW = c.C;
-  g.RH = c.Ho; g.RW = c.Wo; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad;
+  g.RH = c.Ho; g.RW = c.Wo; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
   g.rows = c.N * c.Ho * c.Wo;
   g.div_hw = fastdiv_make(c.Ho * c.Wo);
   g.div_w = fastdiv_make(c.Wo);
@@ -210,7 +210,7 @@ ConvGeom geom_dgrad(const clite_conv& c) {  // rows = input pixels, gather dy
   ConvGeom g;
   g.H = c.Ho; g.W = c.Wo; g.C = c.K;
   g.sN = c.Ho * c.Wo * c.K; g.sH = c.Wo * c.K; g.sW = c.K;
-  g.RH = c.H; g.RW = c.W; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad;
+  g.RH = c.H; g.RW = c.W; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
   g.rows = c.N * c.H * c.W;
   g.div_hw = fastdiv_make(c.H * c.W);
   g.div_w = fastdiv_make(c.W);
@@ -243,7 +243,7 @@ int conv_dgrad(const void* dy, const void* w, const clite_conv& c, const clite_e
     // empty im2col over all N*H*W input pixels (s*s times the work)
     int P = c.N * c.Ho * c.Wo;
     RowMap rm;
-    rm.on = 1; rm.div_hw = fastdiv_make(c.Ho * c.Wo); rm.div_w = fastdiv_make(c.Wo); rm.H = c.H; rm.W = c.W; rm.stride = c.stride;
+    rm.on = 1; rm.div_hw = fastdiv_make(c.Ho * c.Wo); rm.div_w = fastdiv_make(c.Wo); rm.H = c.H; rm.W = c.W; rm.stride = c.stride; rm.off_h = 0; rm.off_w = 0;
     if (c.C <= 64) {
       GatherKC<T, 256, BK, false> la{dy, yb, geom_dense(P, c.K)};
       StridedXC<T, 64, BK> lb{w, wb, c.C, c.C, c.K, 1};
@@ -261,6 +261,39 @@ int conv_dgrad(const void* dy, const void* w, const clite_conv& c, const clite_e
   GatherKC<T, 128, BK, true> la{dy, yb, geom_dgrad(c)};
   StridedXC<T, 128, BK> lb{w, wb, c.R * c.S * c.C, c.C, c.K, c.R * c.S};
   return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.C, Ktot, 1, st);
+}
+
+// One parity class (ph, pw) of the dgrad of a 3x3 / stride-2 / pad-1 conv: input pixels (2*hq + ph, 2*wq + pw) only receive the
+// taps r = r0 + 2a, s = s0 + 2b with r0 = (ph + 1) & 1, s0 = (pw + 1) & 1, and ho = hq + ch - a with ch = (ph + 1 - r0) / 2: a
+// stride-1 dgrad with an na x nb window and padding (ch, cw) over the [N][H/2][W/2] sub-grid, scattered to its pixels by RowMap.
+// `wsub` holds that class's taps packed as [K][na][nb][C]. The four classes together cost 9 taps per output quad instead of the
+// 36 that a gather over all pixels and all taps (3/4 of them structurally zero) performs.
+template <typename T>
+int conv_dgrad_s2class(const void* dy, const void* wsub, const clite_conv& c, int ph, int pw, const clite_epilogue* ep, hipStream_t st) {
+  constexpr int BK = Cfg<T>::BK;
+  const int r0 = (ph + 1) & 1, s0 = (pw + 1) & 1;
+  const int na = r0 ? 1 : 2, nb = s0 ? 1 : 2;
+  const int ch = (ph + 1 - r0) / 2, cw = (pw + 1 - s0) / 2;
+  const int Hq = c.H / 2, Wq = c.W / 2;
+  ConvGeom g;
+  g.H = c.Ho; g.W = c.Wo; g.C = c.K;
+  g.sN = c.Ho * c.Wo * c.K; g.sH = c.Wo * c.K; g.sW = c.K;
+  g.RH = Hq; g.RW = Wq; g.R = na; g.S = nb; g.stride = 1; g.pad = ch; g.padw = cw;
+  g.rows = c.N * Hq * Wq;
+  g.div_hw = fastdiv_make(Hq * Wq);
+  g.div_w = fastdiv_make(Wq);
+  RowMap rm;
+  rm.on = 1; rm.div_hw = g.div_hw; rm.div_w = g.div_w; rm.H = c.H; rm.W = c.W; rm.stride = 2; rm.off_h = ph; rm.off_w = pw;
+  const int M = g.rows, Ktot = na * nb * c.K;
+  uint32_t yb = (uint32_t)((size_t)c.N * c.Ho * c.Wo * c.K * sizeof(T)), wb = (uint32_t)((size_t)c.K * na * nb * c.C * sizeof(T));
+  if (c.C <= 64) {
+    GatherKC<T, 256, BK, true> la{dy, yb, g};
+    StridedXC<T, 64, BK> lb{wsub, wb, na * nb * c.C, c.C, c.K, na * nb};
+    return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, c.C, Ktot, 1, st, rm);
+  }
+  GatherKC<T, 128, BK, true> la{dy, yb, g};
+  StridedXC<T, 128, BK> lb{wsub, wb, na * nb * c.C, c.C, c.K, na * nb};
+  return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.C, Ktot, 1, st, rm);
 }
 
 template <typename T>
@@ -292,7 +325,7 @@ ConvGeom geom_stem(int N, int Hp, int Wp, int Ho, int Wo) {
   ConvGeom g;
   g.H = Hp; g.W = Wp; g.C = 32;
   g.sN = Hp * Wp * 4; g.sH = Wp * 4; g.sW = 4;
-  g.RH = Ho; g.RW = Wo; g.R = 7; g.S = 1; g.stride = 2; g.pad = 0;
+  g.RH = Ho; g.RW = Wo; g.R = 7; g.S = 1; g.stride = 2; g.pad = 0; g.padw = 0;
   g.rows = N * Ho * Wo;
   g.div_hw = fastdiv_make(Ho * Wo);
   g.div_w = fastdiv_make(Wo);
@@ -369,6 +402,13 @@ extern "C" int clite_conv_fwd(const void* x, const void* w, const clite_conv* cv
 extern "C" int clite_conv_dgrad(const void* dy, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
   if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
   return cv->dtype == CLITE_BF16 ? conv_dgrad<bf16>(dy, w, *cv, ep, (hipStream_t)stream) : conv_dgrad<float>(dy, w, *cv, ep, (hipStream_t)stream);
+}
+extern "C" int clite_conv_dgrad_s2class(const void* dy, const void* wsub, const clite_conv* cv, int ph, int pw, const clite_epilogue* ep, void* stream) {
+  if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
+  if (cv->R != 3 || cv->S != 3 || cv->stride != 2 || cv->pad != 1 || (cv->H & 1) || (cv->W & 1) || (unsigned)ph > 1 || (unsigned)pw > 1) return -1;
+  if (cv->C % 64 || cv->K % 64) return -1;
+  return cv->dtype == CLITE_BF16 ? conv_dgrad_s2class<bf16>(dy, wsub, *cv, ph, pw, ep, (hipStream_t)stream)
+                                 : conv_dgrad_s2class<float>(dy, wsub, *cv, ph, pw, ep, (hipStream_t)stream);
 }
 extern "C" int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream) {
   if (check_conv(cv) || !dw) return -1;

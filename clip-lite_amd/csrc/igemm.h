@@ -38,7 +38,7 @@ struct ConvGeom {
   int sN, sH, sW;     // element strides of the gathered tensor
   int RH, RW;         // spatial extent of the row space (output pixels for fwd/wgrad, input pixels for dgrad)
   int R, S;           // window
-  int stride, pad;
+  int stride, pad, padw;   // pad: rows (h), padw: columns (w); equal except in the parity-class dgrads of strided convs
   int rows;           // N * RH * RW
   FastDiv div_hw, div_w;  // by RH*RW and by RW
 };
@@ -76,8 +76,8 @@ struct GatherKC {
         uint32_t rh = fd_div(rem, g.div_w);
         uint32_t rw = rem - rh * g.div_w.d;
         st.base[i] = n * g.sN;
-        if (DGRAD) { st.h0[i] = rh + g.pad; st.w0[i] = rw + g.pad; }
-        else { st.h0[i] = rh * g.stride - g.pad; st.w0[i] = rw * g.stride - g.pad; }
+        if (DGRAD) { st.h0[i] = rh + g.pad; st.w0[i] = rw + g.padw; }
+        else { st.h0[i] = rh * g.stride - g.pad; st.w0[i] = rw * g.stride - g.padw; }
       } else {
         st.base[i] = -1; st.h0[i] = 0; st.w0[i] = 0;
       }
@@ -236,7 +236,7 @@ struct GatherXC {
       uint32_t ho = fd_div(rem, g.div_w);
       uint32_t wo = rem - ho * g.div_w.d;
       int hi = (int)ho * g.stride - g.pad + st.r;
-      int wi = (int)wo * g.stride - g.pad + st.s;
+      int wi = (int)wo * g.stride - g.padw + st.s;
       v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
       uint32_t off = v ? (uint32_t)((int)n * g.sN + hi * g.sH + wi * g.sW + st.xoff) * (uint32_t)sizeof(T) : OOB_OFF;
       regs[i] = buf_load16(st.rs_, off);
@@ -273,6 +273,7 @@ struct RowMap {
   int on;
   FastDiv div_hw, div_w;   // by Ho*Wo and by Wo
   int H, W, stride;
+  int off_h, off_w;        // pixel (n, ho*stride + off_h, wo*stride + off_w)
 };
 DEV size_t map_row(const RowMap& rm, int row) {
   if (!rm.on) return (size_t)row;
@@ -280,7 +281,7 @@ DEV size_t map_row(const RowMap& rm, int row) {
   uint32_t rem = row - n * rm.div_hw.d;
   uint32_t ho = fd_div(rem, rm.div_w);
   uint32_t wo = rem - ho * rm.div_w.d;
-  return ((size_t)n * rm.H + ho * rm.stride) * rm.W + wo * rm.stride;
+  return ((size_t)n * rm.H + ho * rm.stride + rm.off_h) * rm.W + wo * rm.stride + rm.off_w;
 }
 
 template <int BM_, int BN_, int BK_, int WM_, int WN_>

@@ -74,8 +74,8 @@ struct DmaKC {
         uint32_t rh = fd_div(rem, g.div_w);
         uint32_t rw = rem - rh * g.div_w.d;
         st.base[j] = n * g.sN;
-        if (DGRAD) { st.h0[j] = rh + g.pad; st.w0[j] = rw + g.pad; }
-        else { st.h0[j] = rh * g.stride - g.pad; st.w0[j] = rw * g.stride - g.pad; }
+        if (DGRAD) { st.h0[j] = rh + g.pad; st.w0[j] = rw + g.padw; }
+        else { st.h0[j] = rh * g.stride - g.pad; st.w0[j] = rw * g.stride - g.padw; }
       } else {
         st.base[j] = -1; st.h0[j] = 0; st.w0[j] = 0;
       }
@@ -237,7 +237,7 @@ struct DmaXCGather {
       uint32_t ho = fd_div(rem, g.div_w);
       uint32_t wo = rem - ho * g.div_w.d;
       int hi = (int)ho * g.stride - g.pad + st.r[j];
-      int wi = (int)wo * g.stride - g.pad + st.s[j];
+      int wi = (int)wo * g.stride - g.padw + st.s[j];
       v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
       uint32_t off = v ? (uint32_t)((int)n * g.sN + hi * g.sH + wi * g.sW + st.xoff[j]) * (uint32_t)sizeof(T) : OOB_OFF;
       buf_load16_lds(st.rs_, off, lds + (wave * NI + j) * 1024);

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "clite_gemm_tn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
     "clite_conv_fwd": [_V, _V, _V, _V, _V],
     "clite_conv_dgrad": [_V, _V, _V, _V, _V],
+    "clite_conv_dgrad_s2class": [_V, _V, _V, _I, _I, _V, _V],
     "clite_conv_wgrad": [_V, _V, _V, _V, _V],
     "clite_stem_fwd": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
     "clite_stem_wgrad": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
@@ -207,6 +208,20 @@ def conv_fwd(x, w, cv, ep):
 
 def conv_dgrad(dy, w, cv, ep):
     check(lib().clite_conv_dgrad(p(dy), p(w), C.byref(cv), C.byref(ep), stream_ptr(dy)), "conv_dgrad")
+
+
+def conv_dgrad_s2(dy, w, cv, make_ep):
+    """dgrad of a 3x3 / stride-2 / pad-1 conv as its four input-parity classes (a quarter of the MACs of the gathered form).
+    `make_ep()` builds the epilogue (called once per class: the classes write disjoint rows of the same output)."""
+    for ph in (0, 1):
+        for pw in (0, 1):
+            wsub = w[:, (ph + 1) & 1::2, (pw + 1) & 1::2, :].contiguous()
+            ep = make_ep()
+            check(lib().clite_conv_dgrad_s2class(p(dy), p(wsub), C.byref(cv), ph, pw, C.byref(ep), stream_ptr(dy)), "conv_dgrad_s2class")
+
+
+def s2_classes_ok(cv):
+    return cv.R == 3 and cv.S == 3 and cv.stride == 2 and cv.pad == 1 and cv.H % 2 == 0 and cv.W % 2 == 0 and cv.C % 64 == 0 and cv.K % 64 == 0
 
 
 def conv_wgrad(dy, x, cv, dw):

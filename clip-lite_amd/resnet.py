@@ -272,8 +272,11 @@ def resnet_backward(rt, net, ctx, dfeat):
             elif i > 0:
                 prev = units[i - 1]
                 dstats = rt.new_stats(Cin)
-                hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv,
-                               hip.epilogue(dx, Cin, dact_aux=prev.out, dact=hip.DACT_RELU, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0])))
+                mk = lambda: hip.epilogue(dx, Cin, dact_aux=prev.out, dact=hip.DACT_RELU, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0]))
+                if rt.s2_classes and hip.s2_classes_ok(u.cv):
+                    hip.conv_dgrad_s2(dy, rt.arena.w(u.conv.weight), u.cv, mk)       # 3x3 / stride 2: four parity classes, no zero taps
+                else:
+                    hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, mk())
                 dy = _bn_backward_apply(rt, prev, dx, dstats)
             else:
                 # gradient w.r.t. the block input: main path + shortcut

@@ -194,6 +194,7 @@ class DeviceRuntime:
         self.exchange = None
         self._spans = {}
         import os
+        self.s2_classes = os.environ.get("CLITE_S2_CLASSES", "1") != "0"     # 3x3/stride-2 dgrads as four parity-class GEMMs
         self.fuse_bn_backward = os.environ.get("CLITE_FUSE_BN", "1") != "0"     # BatchNorm-backward reductions inside the dgrad epilogues (resnet.py)
         self._aux_streams, self._aux_busy, self._aux_keep, self.overlap_wgrad = {}, set(), {}, False
         self.steps = 0

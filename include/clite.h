@@ -92,6 +92,11 @@ int clite_gemm_tn(const void* A, int lda, const void* B, int ldb, int M, int N, 
 int clite_conv_fwd(const void* x, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream);
 /* dx = conv_transpose(dy, w): autograd of the same call. Epilogue applies to dx viewed as [N*H*W][C]. */
 int clite_conv_dgrad(const void* dy, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream);
+/* One parity class (ph, pw in {0,1}) of the dgrad of a 3x3 / stride-2 / pad-1 conv (H, W even; C, K multiples of 64): writes only the
+ * input pixels (2*hq + ph, 2*wq + pw). wsub = the taps that reach this class, w[:, r0::2, s0::2, :] with r0 = (ph+1)&1, s0 = (pw+1)&1,
+ * packed [K][na][nb][C]. The four classes together equal clite_conv_dgrad at a quarter of the work (no structurally-zero taps). The
+ * epilogue (incl. the BatchNorm-backward form) applies to the rows of the class. */
+int clite_conv_dgrad_s2class(const void* dy, const void* wsub, const clite_conv* cv, int ph, int pw, const clite_epilogue* ep, void* stream);
 /* dw[K][R][S][C] (f32) += dy^T * im2col(x): autograd of the same call; float-atomic split-K. */
 int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream);
 

@@ -163,7 +163,7 @@ def test_gradient_exchange_stream_logic_single_rank():
         tdist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1)
     res = []
     for use in (False, True):
-        M, _ = _models(lowp=True)
+        M, _ = _models(lowp=False)          # exact-f32 kernels: two bf16 runs already differ by more than the tolerance (atomic order)
         opt = _optim(M)
         ex = None
         if use:

@@ -178,6 +178,24 @@ def test_conv_fwd_dgrad_wgrad(dtype, N, H, W, Cc, K, R, S, st, pad):
     _close(from_bf16(buf) if dtype == BF16 else buf, want, 8e-3 if dtype == BF16 else 2e-3)
 
 
+@pytest.mark.parametrize("dtype,N,H,W,Cc,K", [(BF16, 2, 8, 8, 64, 64), (BF16, 1, 6, 10, 128, 64), (F32, 2, 4, 6, 64, 128)])
+def test_conv_dgrad_stride2_parity_classes(dtype, N, H, W, Cc, K):
+    """The four input-parity classes of a 3x3 / stride-2 / pad-1 dgrad (clite_conv_dgrad_s2class, each a stride-1 dgrad over the
+    [N][H/2][W/2] sub-grid with its own taps, scattered by RowMap) together equal the full dgrad."""
+    rng = np.random.default_rng(H * 7 + K)
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    cv = Conv(dtype, N, H, W, Cc, K, 3, 3, 2, 1, Ho, Wo)
+    w, _ = _prep(rng.standard_normal((K, 3, 3, Cc), dtype=np.float32) * 0.2, dtype)
+    dy, dyb = _prep(rng.standard_normal((N, Ho, Wo, K), dtype=np.float32), dtype)
+    dx = np.full((N, H, W, Cc), 7.0, np.float32)          # every element must be overwritten by exactly one class
+    for ph in (0, 1):
+        for pw in (0, 1):
+            sub = np.ascontiguousarray(w[:, (ph + 1) & 1::2, (pw + 1) & 1::2, :])
+            _, subb = _prep(sub, dtype)
+            assert lib().clite_conv_dgrad_s2class(ptr(dyb), ptr(subb), C.byref(cv), ph, pw, C.byref(make_ep(dx, Cc, out_f32=True)), None) == 0
+    _close(dx, conv_dgrad_ref(dy, w, (N, H, W, Cc), 2, 1))
+
+
 @pytest.mark.parametrize("dtype", [BF16, F32])
 def test_stem_conv7x7(dtype):
     """7x7/2 pad-3 stem expressed as a 7x1 window over 32 virtual channels of the pre-padded NHWC4 image."""
