@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = wave_uniform(tid >> 6);
   const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
   const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
 
@@ -337,30 +337,44 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
     else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
     else wait_vmcnt<0>();
     barrier_raw();
-#if CLITE_ABLATE != 2
-    if (t + NSTAGE - 1 < t_end) {
-      int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
-      DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
-      DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
-    }
-#endif
     const char* abuf = smem + buf * STAGE;
     const char* bbuf = abuf + LA::BYTES;
 #if CLITE_ABLATE != 1
     if constexpr (sizeof(T) == 2) {
+      // the first k-step's fragment reads go out BEFORE the next tile's DMA is issued: the DMA issue (address selects + 4 DMA
+      // instructions per wave) then overlaps the LDS latency instead of preceding it
+      bf16x8 af0[RM], bf0[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) bf0[j] = LB::frag_at(bbuf + boff[j][0]);
+#if CLITE_ABLATE != 2
+      if (t + NSTAGE - 1 < t_end) {
+        int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+        DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+        DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+      }
+#endif
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
         bf16x8 af[RM], bfr[RN];
 #pragma unroll
-        for (int i = 0; i < RM; ++i) af[i] = LA::frag_at(abuf + aoff[i][ks]);
+        for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
 #pragma unroll
-        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag_at(bbuf + boff[j][ks]);
+        for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
 #pragma unroll
         for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
       }
     } else {
+#if CLITE_ABLATE != 2
+      if (t + NSTAGE - 1 < t_end) {
+        int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+        DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+        DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+      }
+#endif
 #pragma unroll
       for (int kk = 0; kk < BK / 2; ++kk) {
         float af[RM], bfr[RN];
@@ -405,8 +419,8 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogu
 
   const int tid = threadIdx.x & 255;
   const int lane = tid & 63;
-  const int wave = tid >> 6;                                // wave index inside the group
-  const int group = threadIdx.x >> 8;
+  const int wave = wave_uniform(tid >> 6);                  // wave index inside the group
+  const int group = wave_uniform(threadIdx.x >> 8);
   const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
   const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
 
@@ -476,22 +490,31 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogu
     else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
     else wait_vmcnt<0>();
     barrier_raw();
+    const char* abuf = ring + buf * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+    bf16x8 af0[RM], bf0[RN];
+    if constexpr (sizeof(T) == 2) {        // first k-step's fragments before the DMA issue (see igemm_dma_kernel)
+      if (live) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bf0[j] = LB::frag_at(bbuf + boff[j][0]);
+      }
+    }
     if (t + NSTAGE - 1 < t_end) {
       int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
       DmaIssue<LA>::go(la, sa, ring + nb * STAGE, wave, lane, m0);
       DmaIssue<LB>::go(lb, sb, ring + nb * STAGE + LA::BYTES, wave, lane, n0);
     }
     if (live) {
-      const char* abuf = ring + buf * STAGE;
-      const char* bbuf = abuf + LA::BYTES;
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
           bf16x8 af[RM], bfr[RN];
 #pragma unroll
-          for (int i = 0; i < RM; ++i) af[i] = LA::frag_at(abuf + aoff[i][ks]);
+          for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
 #pragma unroll
-          for (int j = 0; j < RN; ++j) bfr[j] = LB::frag_at(bbuf + boff[j][ks]);
+          for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
 #pragma unroll
           for (int i = 0; i < RM; ++i)
 #pragma unroll

@@ -71,6 +71,10 @@ DEV s16x4 lds_read_tr16(const void* p) {
 DEV float bf2f(bf16 x) { return (float)x; }
 DEV bf16 f2bf(float x) { return (bf16)x; }   // round-to-nearest-even (v_cvt_pk_bf16_f32)
 
+// A value that is the same in every lane of the wave (e.g. the wave index): moved to an SGPR so that everything derived from it
+// (LDS-DMA destinations, tile offsets) is scalar arithmetic instead of VALU + v_readfirstlane at every use.
+DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 DEV float wave_shfl_xor(float v, int m) { return __shfl_xor(v, m, WAVE); }
 DEV int wave_shfl_xor_i(int v, int m) { return __shfl_xor(v, m, WAVE); }
 DEV float wave_shfl(float v, int src) { return __shfl(v, src, WAVE); }

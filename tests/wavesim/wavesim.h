@@ -187,6 +187,9 @@ inline bf16 f2bf(float f) {  // round-to-nearest-even, NaN preserved
   return r;
 }
 
+// value known to be identical in every lane of the wave (the device build moves it to a scalar register)
+inline int wave_uniform(int v) { return v; }
+
 // ---------------------------------------------------------------- wave collectives
 inline float wave_shfl(float v, int src) {
   auto& w = wavesim::g_block->waves[wavesim::g_wave];
