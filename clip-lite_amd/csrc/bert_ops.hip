@@ -23,7 +23,7 @@ DEV void apply_dropout8(const Drop& d, size_t idx, float (&v)[8]) {
 }
 
 // one wave per row; out = dropout((x - mean) * rstd * gamma + beta); stats[row] = (mean, rstd)
-template <typename T>
+template <typename T, int NCH>      // NCH = 8-element chunks per lane: C <= 64*NCH*8 (2 covers BERT's 768, 4 the 2048-wide heads)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, float eps, T* out,
                                                             float* stats, int M, int C, Drop drop) {
   seed_resolve(drop.seed, drop.site);
@@ -31,10 +31,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
   const int nchunk = C / 8;
   const float invC = 1.0f / (float)C;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    float v[LN_MAXCH][8];
+    float v[NCH][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       if (c < nchunk) {
         load8(x + (size_t)row * C + c * 8, v[i]);
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
     float mean = wave_sum(s) * invC;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       if (c < nchunk) {
 #pragma unroll
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
     }
     float rstd = rsqrtf(wave_sum(q) * invC + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       if (c < nchunk) {
         float g[8], b[8], o[8];
@@ -73,24 +73,24 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
 
 // dy' = dropout_mask_in(dy); dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy'*gamma; dgamma += sum dy'*xhat; dbeta += sum dy'
 // optional second output dx_masked = dropout_mask_out(dx)
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_masked,
                                                             float* dgamma, float* dbeta, int M, int C, Drop drop_in, Drop drop_out) {
   seed_resolve(drop_in.seed, drop_in.site);
   seed_resolve(drop_out.seed, drop_out.site);
-  __shared__ float red[4][64 * LN_MAXCH * 8];   // [wave][per-lane partials], used once for dgamma and once for dbeta
+  __shared__ float red[4][64 * NCH * 8];   // [wave][per-lane partials], used once for dgamma and once for dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = C / 8;
   const float invC = 1.0f / (float)C;
-  float ag[LN_MAXCH][8], ab[LN_MAXCH][8];
+  float ag[NCH][8], ab[NCH][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) { zero8(ag[i]); zero8(ab[i]); }
+  for (int i = 0; i < NCH; ++i) { zero8(ag[i]); zero8(ab[i]); }
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    float d[LN_MAXCH][8], xh[LN_MAXCH][8], g[LN_MAXCH][8];
+    float d[NCH][8], xh[NCH][8], g[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       if (c < nchunk) {
         size_t idx = (size_t)row * C + c * 8;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
     }
     float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
+    for (int i = 0; i < NCH; ++i) {
       int c = lane + 64 * i;
       if (c < nchunk) {
         size_t idx = (size_t)row * C + c * 8;
@@ -131,13 +131,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
   for (int which = 0; which < 2; ++which) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i)
+    for (int i = 0; i < NCH; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) red[wave][(i * 64 + lane) * 8 + e] = which == 0 ? ag[i][e] : ab[i][e];
     __syncthreads();
     float* dst = which == 0 ? dgamma : dbeta;
     if (dst) {
-      for (int j = threadIdx.x; j < LN_MAXCH * 64 * 8; j += 256) {
+      for (int j = threadIdx.x; j < NCH * 64 * 8; j += 256) {
         int i = j / 512, l = (j / 8) % 64, e = j % 8;
         int c = l + 64 * i;
         if (c < nchunk) atomic_add_f32(dst + c * 8 + e, red[0][j] + red[1][j] + red[2][j] + red[3][j]);
@@ -575,9 +575,17 @@ extern "C" int clite_layernorm_fwd(int dtype, const void* x, const float* gamma,
   if (grid > 2048) grid = 2048;
   Drop d{drop_p, drop_seed, drop_site};
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH(dtype,
-           hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d),
-           hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, eps, (float*)out, stats, M, C, d));
+  if (C <= 1024) {
+    constexpr int NCHV = 2;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d),
+             hipLaunchKernelGGL((layernorm_fwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, eps, (float*)out, stats, M, C, d));
+  } else {
+    constexpr int NCHV = 4;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d),
+             hipLaunchKernelGGL((layernorm_fwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, eps, (float*)out, stats, M, C, d));
+  }
   return (int)hipGetLastError();
 }
 
@@ -589,9 +597,17 @@ extern "C" int clite_layernorm_bwd(int dtype, const void* dy, const void* x, con
   if (grid > 512) grid = 512;
   Drop di{in_p, in_seed, in_site}, dout{out_p, out_seed, out_site};
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH(dtype,
-           hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
-           hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
+  if (C <= 1024) {
+    constexpr int NCHV = 2;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
+             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
+  } else {
+    constexpr int NCHV = 4;
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
+             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
+  }
   return (int)hipGetLastError();
 }
 

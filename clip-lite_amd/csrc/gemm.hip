@@ -382,6 +382,11 @@ int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K, int lda
 }  // namespace
 
 extern "C" int clite_abi_version(void) { return CLITE_ABI_VERSION; }
+#if CLITE_STAMP
+extern "C" int clite_dbg_read(unsigned long long* host, int n) {     // diagnostic builds only
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clite_dbg), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int clite_gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int dtype, const clite_epilogue* ep, void* stream) {
   if (check_gemm(ep, dtype, M, N, K, lda, ldb, M, N) || K % 8 || lda < K || ldb < K) return -1;

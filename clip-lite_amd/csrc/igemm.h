@@ -23,6 +23,10 @@
 #include "vec.h"
 #include "clite.h"
 
+#ifndef EPI_STAMP
+#define EPI_STAMP(i) do {} while (0)
+#endif
+
 namespace clite {
 
 struct FastDiv {  // q = n / d for n < 2^31, d >= 1 (host fills; see fastdiv_make)
@@ -374,7 +378,8 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
             *(float*)(smem + row * CFG::EPI_PITCH + col * 4) = acc[i][j][r];
           }
     }
-    __syncthreads();
+    lds_barrier();
+    if (pass == 0) EPI_STAMP(6);
     float bias[8], bn_mean[8];          // per-column constants (L2-resident; reloaded per pass to keep them out of the staging phase's registers)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bias[e] = (colok && ep.bias) ? ep.bias[gcol + e] : 0.f; bn_mean[e] = 0.f; }
@@ -385,6 +390,9 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
 #pragma unroll
       for (int e = 0; e < 8; ++e) bn_mean[e] *= ep.bn_inv_count;
     }
+    // fully unrolled: the rows of a thread are independent, so their LDS reads, conversions and stores interleave (one wave per SIMD
+    // issues a single row's dependent chain at a fraction of the VALU rate)
+#pragma unroll
     for (int it0 = 0; it0 < ITER; it0 += PF) {
       if (it0 > 0) prefetch(it0);
 #pragma unroll
@@ -455,7 +463,8 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
       }
     }
     }
-    __syncthreads();
+    if (pass == 0) EPI_STAMP(7);
+    lds_barrier();
   }
 
   if (ep.colsum) {
@@ -469,7 +478,7 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
       red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + e] = csum[e];
       red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + 8 + e] = csq[e];
     }
-    __syncthreads();
+    lds_barrier();
     for (int idx = tid; idx < CPRE * 16; idx += 256) {
       float s = 0.f;
       for (int r = 0; r < RPSE; ++r) s += red[r * (CPRE * 16) + idx];
@@ -529,7 +538,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
   };
 #pragma unroll
   for (int q = 0; q < AHEAD && q < ROWS_PT; ++q) request(q);
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int q = 0; q < ROWS_PT; ++q) {
     if (q + AHEAD < ROWS_PT) request(q + AHEAD);
@@ -576,7 +585,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
       for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
     }
   }
-  __syncthreads();
+  lds_barrier();
   if (ep.colsum) {
     float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
     float* red = (float*)smem;                      // [RPSE][CPRE*16]
@@ -585,7 +594,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
       red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + e] = csum[e];
       red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + 8 + e] = csq[e];
     }
-    __syncthreads();
+    lds_barrier();
     for (int idx = tid; idx < CPRE * 16; idx += 256) {
       float sacc = 0.f;
       for (int r = 0; r < RPSE; ++r) sacc += red[r * (CPRE * 16) + idx];

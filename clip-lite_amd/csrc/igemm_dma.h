@@ -19,6 +19,16 @@
 #ifndef CLITE_ABLATE
 #define CLITE_ABLATE 0      // diagnostic builds only (tools/ablate.sh): 1 = main loop without LDS reads / MFMAs, 2 = without the DMA loads
 #endif
+#ifndef CLITE_STAMP
+#define CLITE_STAMP 0       // diagnostic builds only: per-workgroup phase timestamps (s_memrealtime, 100 MHz) into clite_dbg[]
+#endif
+#if CLITE_STAMP
+__device__ unsigned long long clite_dbg[8 * 65536];
+#define EPI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) clite_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) clite_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 #include "igemm.h"
 
 namespace clite {
@@ -268,6 +278,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
   constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
+  STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = wave_uniform(tid >> 6);
@@ -321,6 +332,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
     }
   }
 
+  STAMP(1);
   // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
   for (int pz = 0; pz < NSTAGE - 1; ++pz) {
@@ -329,6 +341,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
       DmaIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
     }
   }
+  STAMP(2);
   int buf = 0;
   for (int t = t_begin; t < t_end; ++t) {
     // tile t has landed once at most min(NSTAGE-2, tiles after t) younger tiles are still outstanding
@@ -337,6 +350,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
     else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
     else wait_vmcnt<0>();
     barrier_raw();
+    if (t == t_begin) STAMP(3);
     const char* abuf = smem + buf * STAGE;
     const char* bbuf = abuf + LA::BYTES;
 #if CLITE_ABLATE != 1
@@ -394,8 +408,10 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
     if (++buf == NSTAGE) buf = 0;
   }
   barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
+  STAMP(4);
   if constexpr (HEAVY) igemm_epilogue_bn<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
   else igemm_epilogue<T, CFG, false>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  STAMP(5);
 }
 
 
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogu
     }
     if (++buf == NSTAGE) buf = 0;
   }
-  __syncthreads();          // (no DMA is outstanding any more) every wave is past its last fragment read: the LDS is free
+  lds_barrier();          // (no DMA is outstanding any more) every wave is past its last fragment read: the LDS is free
   // group 1 -> group 0: element (i, j, r) of thread tid at ((i*RN + j)*16 + r)*256 + tid  (consecutive lanes, consecutive words)
   float* xchg = (float*)smem;
   if (group == 1) {
@@ -548,7 +564,7 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogu
 #pragma unroll
         for (int r = 0; r < 16; ++r) xchg[((i * RN + j) * 16 + r) * 256 + tid] = acc[i][j][r];
   }
-  __syncthreads();
+  lds_barrier();
   if (group == 0) {
 #pragma unroll
     for (int i = 0; i < RM; ++i)
@@ -557,12 +573,12 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogu
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] += xchg[((i * RN + j) * 16 + r) * 256 + tid];
   }
-  __syncthreads();
+  lds_barrier();
   if (group == 0) {
     igemm_epilogue<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
   } else if (!ep.atomic) {   // keep the workgroup barrier count of igemm_epilogue
-    for (int pass = 0; pass < CFG::WAVES_M; ++pass) { __syncthreads(); __syncthreads(); }
-    if (ep.colsum) __syncthreads();
+    for (int pass = 0; pass < CFG::WAVES_M; ++pass) { lds_barrier(); lds_barrier(); }
+    if (ep.colsum) lds_barrier();
   }
 }
 

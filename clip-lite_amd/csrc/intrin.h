@@ -50,6 +50,12 @@ DEV void buf_load16_lds(rsrc_t r, uint32_t off, void* lds_wave_base) {
 }
 template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 DEV void barrier_raw() { __builtin_amdgcn_s_barrier(); }   // no implied vmcnt(0): LDS-DMA may stay in flight across it
+// Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt), NOT for its global loads / stores.
+// __syncthreads() also drains vmcnt, i.e. every epilogue barrier would wait for the stores just issued to reach L2 (~1.5 us each).
+DEV void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
 
 // v_mfma_f32_32x32x16_bf16: lane l holds A[row l&31][k 8*(l>>5)+j], B[k 8*(l>>5)+j][col l&31];
 // D reg i of lane l = D[row (i&3)+8*(i>>2)+4*(l>>5)][col l&31].

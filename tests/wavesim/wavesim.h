@@ -166,6 +166,7 @@ inline void buf_load16_lds(rsrc_t r, uint32_t off, void* lds_wave_base) {
 }
 template <int N> inline void wait_vmcnt() {}
 inline void barrier_raw() { __syncthreads(); }
+inline void lds_barrier() { __syncthreads(); }
 
 // ---------------------------------------------------------------- conversions
 inline float bf2f(bf16 x) {

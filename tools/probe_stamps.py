@@ -1,0 +1,56 @@
+"""Per-workgroup phase timeline of one igemm launch (diagnostic build -DCLITE_STAMP=1, CLITE_HIP_LIB=.../libclite_stamp.so).
+Usage: python tools/probe_stamps.py conv_fwd N H W C K R S stride pad | gemm_nt M N K ..."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from clip_lite_amd import hip
+
+kind = sys.argv[1]
+a = [int(x) for x in sys.argv[2:]]
+if kind.startswith("conv"):
+    N, H, W, Cc, K, R, S, st, pad = a
+    cv = hip.conv_desc(hip.BF16, N, H, W, Cc, K, R, S, st, pad)
+    x = torch.randn(N, H, W, Cc, device="cuda").bfloat16()
+    w = torch.randn(K, R, S, Cc, device="cuda").bfloat16()
+    dy = torch.randn(N, cv.Ho, cv.Wo, K, device="cuda").bfloat16()
+    y = torch.empty(N, cv.Ho, cv.Wo, K, device="cuda", dtype=torch.bfloat16)
+    dx = torch.empty_like(x)
+    cs = hip.Stats(torch.zeros(8 * 3 * K, device="cuda"), 8, K)
+    fn = {"conv_fwd": lambda: hip.conv_fwd(x, w, cv, hip.epilogue(y, K, colsum=cs)),
+          "conv_dgrad": lambda: hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc))}[kind]
+else:
+    M, N, K = a
+    k = kind[-2:]
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    B = torch.randn(N, K, device="cuda").bfloat16() if k == "nt" else torch.randn(K, N, device="cuda").bfloat16()
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    ep = hip.epilogue(out, N)
+    f = getattr(hip, kind)
+    fn = lambda: f(hip.BF16, A, B, M, N, K, ep)
+os.environ.setdefault("CLITE_IGEMM_G2", "0")
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+n = 8 * 8192
+buf = (C.c_ulonglong * n)()
+lib = hip.lib()
+lib.clite_dbg_read.argtypes = [C.c_void_p, C.c_int]
+assert lib.clite_dbg_read(buf, n) == 0
+t = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+t = t[t[:, 0] > 0]
+t0 = t[:, 0].min()
+us = (t[:, :8] - t0) / 100.0
+print(f"{kind} {a}: kernel {e0.elapsed_time(e1) * 1e3:.1f} us, {len(us)} workgroups stamped")
+names = ["start", "init done", "prologue issued", "first tile landed", "main loop done", "epilogue done"]
+d = np.diff(us, axis=1)
+print("phase durations per workgroup (us): median / p90")
+for i, nm in enumerate(["init (addresses, divisions)", "prologue DMA issue", "wait first tile", "main loop", "epilogue"]):
+    print(f"  {nm:30s} {np.median(d[:, i]):7.2f} / {np.percentile(d[:, i], 90):7.2f}")
+print(f"  epilogue: staged+barrier (pass 0)  {np.median(us[:, 6] - us[:, 4]):7.2f}   rows of pass 0 written {np.median(us[:, 7] - us[:, 6]):7.2f}   rest {np.median(us[:, 5] - us[:, 7]):7.2f}")
+print(f"  workgroup lifetime             {np.median(us[:, 5] - us[:, 0]):7.2f} / {np.percentile(us[:, 5] - us[:, 0], 90):7.2f}")
+print(f"  start times: min {us[:, 0].min():.1f} median {np.median(us[:, 0]):.1f} max {us[:, 0].max():.1f};  last end {us[:, 5].max():.1f}")
