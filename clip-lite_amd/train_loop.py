@@ -25,6 +25,9 @@ def build_parser():
     group.add_argument("--checkpoint-every", type=int, default=10000, help="Serialize model to a checkpoint after every these many iterations.")
     group.add_argument("--log-every", type=int, default=500, help="Log training curves after every these many iterations.")
     group.add_argument("--climax-freq", type=int, default=1000, help="Frequency to checkpoint at during climax (last 20%% training)")
+    group = parser.add_argument_group("MI355X launch path (not in the reference)")
+    group.add_argument("--no-hip-graph", action="store_true", help="Launch every kernel of the step from Python instead of replaying the "
+                       "captured hipGraphs of the step (TrainStep graph mode; batches of another shape always take the eager path).")
     return parser
 
 
@@ -227,13 +230,15 @@ class TrainStep:
             raise
         self._g, self._static_out = g, out
 
+    def _same_shapes(self, batch):
+        sb = self._static_batch
+        return all((k in sb and torch.is_tensor(sb[k]) and sb[k].shape == v.shape and sb[k].dtype == v.dtype) for k, v in batch.items() if torch.is_tensor(v))
+
     def _replay(self, batch):
         rt = self.model.runtime
         for k, v in batch.items():
             if torch.is_tensor(v):
                 dst = self._static_batch[k]
-                if dst.shape != v.shape or dst.dtype != v.dtype:
-                    raise RuntimeError(f"graph mode needs fixed batch shapes: {k} was {tuple(dst.shape)}, now {tuple(v.shape)}")
                 dst.copy_(v, non_blocking=True)
         sync = self.optimizer.advance() if hasattr(self.optimizer, "advance") else False
         alpha = getattr(self.optimizer, "alpha", 1.0)
@@ -260,6 +265,8 @@ class TrainStep:
                 self._eager_steps += 1
                 return self._eager(batch)
             self._capture(batch)
+        if not self._same_shapes(batch) or not self.model.training:
+            return self._eager(batch)             # a batch of another shape (e.g. a ragged last one): same kernels, launched from Python
         return self._replay(batch)
 
 
@@ -302,7 +309,7 @@ def main(_A: argparse.Namespace):
     if dist.is_master_process():
         checkpoint_manager = CheckpointManager(_A.checkpoints_dir + _C.RUN_ID, model=model, optimizer=optimizer, scheduler=scheduler, scaler=scaler)
 
-    step = TrainStep(model, optimizer, scheduler, scaler, _C.OPTIM.CLIP_GRAD_NORM, exchange)
+    step = TrainStep(model, optimizer, scheduler, scaler, _C.OPTIM.CLIP_GRAD_NORM, exchange, graph=not _A.no_hip_graph)
     for iteration in range(start_iteration + 1, _C.OPTIM.NUM_ITERATIONS + 1):
         timer.tic()
         batch = next(train_dataloader_iter)
