@@ -60,6 +60,28 @@ __global__ __launch_bounds__(256) void critic_fwd_kernel(const T* f1, const T* f
   }
 }
 
+// out[n] = x[n] / max(|x[n]|_2, 1e-12)  — F.normalize(p=2, dim=-1) of the retrieval path (reference retrieval.py:108,127)
+template <typename T>
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const T* x, T* out, int B, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D / 8;
+  for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
+    float a[CR_MAXCH][8];
+    load_row(x + (size_t)n * D, nchunk, lane, a);
+    float inv = 1.0f / fmaxf(sqrtf(dot_rows(a, a)), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < CR_MAXCH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = a[i][e] * inv;
+        store8(out + (size_t)n * D + c * 8, o);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void critic_bwd_kernel(const T* f1, const T* f2, const float* temperature, const float* work, const float* gout, float scale,
                                                          int B, int D, T* df1, T* df2, float* dtemp) {
@@ -178,6 +200,16 @@ extern "C" int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, c
   DISPATCH(dtype,
            hipLaunchKernelGGL(critic_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, B, D, work, acc),
            hipLaunchKernelGGL(critic_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, B, D, work, acc));
+  return (int)hipGetLastError();
+}
+extern "C" int clite_l2_normalize(int dtype, const void* x, void* out, int B, int D, void* stream) {
+  if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !x || !out) return -1;
+  int grid = (B + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(l2_normalize_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)out, B, D),
+           hipLaunchKernelGGL(l2_normalize_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, B, D));
   return (int)hipGetLastError();
 }
 extern "C" int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, const float* temperature, const float* work, const float* gout, float scale,

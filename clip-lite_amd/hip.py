@@ -82,6 +82,7 @@ _SIGNATURES = {
     "clite_attention_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _F, _U64, _U32, _V],
     "clite_tanh_bwd": [_I, _V, _V, _V, _U64, _V],
     "clite_critic_jsd_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V],
+    "clite_l2_normalize": [_I, _V, _V, _I, _I, _V],
     "clite_critic_jsd_bwd": [_I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V],
     "clite_prior_tail_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V],
     "clite_prior_tail_bwd": [_I, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V],
@@ -340,6 +341,10 @@ def tanh_bwd(dt, dy, y, out, n):
 # ------------------------------------------------------------------------------------------------ loss / update
 def critic_jsd_fwd(dt, f1, f2, temperature, B, D, work, acc):
     check(lib().clite_critic_jsd_fwd(dt, p(f1), p(f2), p(temperature), B, D, p(work), p(acc), stream_ptr(f1)), "critic_jsd_fwd")
+
+
+def l2_normalize(dt, x, out, B, D):
+    check(lib().clite_l2_normalize(dt, p(x), p(out), B, D, stream_ptr(x)), "l2_normalize")
 
 
 def critic_jsd_bwd(dt, f1, f2, temperature, work, gout, scale, B, D, df1, df2, dtemp):

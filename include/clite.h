@@ -187,6 +187,9 @@ int clite_tanh_bwd(int dtype, const void* dy, const void* y, void* out, uint64_t
  * work: f32 [B][8] per-sample scratch kept for backward. acc: f32 [4] accumulators, pre-zeroed:
  *   acc[0] += mean softplus(-o+) (= -Ej), acc[1] += mean softplus(o-) (= Em), acc[2]/acc[3]: image/text prior terms. */
 int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, const float* temperature, int B, int D, float* work, float* acc, void* stream);
+/* out[n] = x[n] / max(||x[n]||_2, 1e-12): F.normalize(p=2, dim=-1) of the embedding-extraction / retrieval path that consumes the trained
+ * projection heads (reference retrieval.py:108,127; zero_shot.py). [B][D], D % 8 == 0, D <= 2048. */
+int clite_l2_normalize(int dtype, const void* x, void* out, int B, int D, void* stream);
 /* gout: device scalar dL/d(total); scale = (1 - prior_weight). df1/df2 in dtype; dtemp (f32 scalar) += . */
 int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, const float* temperature, const float* work, const float* gout, float scale,
                          int B, int D, void* df1, void* df2, float* dtemp, void* stream);

@@ -344,3 +344,19 @@ def test_uniform_and_optimizer():
         assert not g.any()
         from simlib import from_bf16, to_bf16
         assert np.array_equal(cast, to_bf16(p))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_l2_normalize_rows(dtype):
+    """clite_l2_normalize == F.normalize(p=2, dim=-1) (reference retrieval.py:108,127), incl. an all-zero row (eps 1e-12)."""
+    rng = np.random.default_rng(3)
+    B, D = 7, 520
+    x, xb = prep(rng.standard_normal((B, D), dtype=np.float32) * 3, dtype)
+    x[2] = 0
+    _, xb = prep(x, dtype)
+    out = outbuf((B, D), dtype)
+    assert lib().clite_l2_normalize(dtype, ptr(xb), ptr(out), B, D, None) == 0
+    ref = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12)
+    got = val(out, dtype)
+    assert np.abs(got - ref).max() < (6e-3 if dtype == BF16 else 1e-6)
+    assert not got[2].any()
