@@ -215,7 +215,7 @@ def main():
                                    f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "loss": loss, "launch": "hipGraph replay" if step.graph else "eager",
-            "roofline": {"bound": "mfma", "kernel": "clite::igemm_kernel (all conv/linear fwd+dgrad+wgrad launches of one step)",
+            "roofline": {"bound": "mfma", "kernel": "clite::igemm_dma_kernel family (all conv/linear fwd+dgrad+wgrad launches of one step)",
                          "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": pmc_traffic(args),
                          "launches_per_step": n_launch, "kernel_ms_per_step": gemm_ms,

@@ -82,6 +82,83 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const T* x, T* out, i
   }
 }
 
+// ---- InfoNCE all-pairs variant (BASELINE config 4; not in the reference: symmetric cross-entropy over S = t * C with
+// C[i][j] = <a_i, b_j> the cosines of the L2-normalised projections, t = exp(temperature), targets on the diagonal):
+//   L = 1/(2B) * [ sum_i (lse_j S[i][j] - S[i][i]) + sum_j (lse_i S[i][j] - S[j][j]) ].
+// One wave per line (row: sr = ld, se = 1; column: sr = 1, se = ld); lse[line] kept for backward; acc += sum (lse - S_diag) / (2B).
+__global__ __launch_bounds__(256) void infonce_lse_kernel(const float* Cm, int sr, int se, int B, const float* temperature, float* lse, float* acc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float t = expf(temperature[0]);
+  for (int i = blockIdx.x * 4 + wave; i < B; i += gridDim.x * 4) {
+    const float* line = Cm + (size_t)i * sr;
+    float m = -INFINITY;
+    for (int j = lane; j < B; j += 64) m = fmaxf(m, t * line[(size_t)j * se]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < B; j += 64) s += expf(t * line[(size_t)j * se] - m);
+    s = wave_sum(s);
+    float l = m + logf(s);
+    if (lane == 0) {
+      lse[i] = l;
+      atomic_add_f32(acc, (l - t * line[(size_t)i * se]) / (2.0f * (float)B));
+    }
+  }
+}
+// dC[i][j] = g * t * (softmax_row + softmax_col - 2*delta_ij), g = gout*scale/(2B); dtemp += sum_ij g * (...) * S[i][j]  (dS/dtemp = S)
+template <typename T>
+__global__ __launch_bounds__(256) void infonce_bwd_kernel(const float* Cm, int ld, int B, const float* temperature, const float* lse_r, const float* lse_c,
+                                                          const float* gout, float scale, T* dC, int ldd, float* dtemp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float t = expf(temperature[0]);
+  const float g = gout[0] * scale / (2.0f * (float)B);
+  float dt = 0.f;
+  for (int i = blockIdx.x * 4 + wave; i < B; i += gridDim.x * 4) {
+    const float lr = lse_r[i];
+    for (int j0 = lane * 8; j0 < ldd; j0 += 64 * 8) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int j = j0 + e;
+        float v = 0.f;
+        if (j < B) {
+          float sij = t * Cm[(size_t)i * ld + j];
+          float d = g * (expf(sij - lr) + expf(sij - lse_c[j]) - (i == j ? 2.f : 0.f));
+          dt += d * sij;
+          v = d * t;
+        }
+        o[e] = v;
+      }
+      store8(dC + (size_t)i * ldd + j0, o);
+    }
+  }
+  dt = wave_sum(dt);
+  if (lane == 0 && dtemp) atomic_add_f32(dtemp, dt);
+}
+// backward of y = x / max(|x|, eps): dx = (dy - y * <dy, y>) / max(|x|, eps)
+template <typename T>
+__global__ __launch_bounds__(256) void l2_normalize_bwd_kernel(const T* x, const T* y, const T* dy, T* dx, int B, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D / 8;
+  for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
+    float a[CR_MAXCH][8], yv[CR_MAXCH][8], d[CR_MAXCH][8];
+    load_row(x + (size_t)n * D, nchunk, lane, a);
+    load_row(y + (size_t)n * D, nchunk, lane, yv);
+    load_row(dy + (size_t)n * D, nchunk, lane, d);
+    float inv = 1.0f / fmaxf(sqrtf(dot_rows(a, a)), 1e-12f);
+    float p = dot_rows(d, yv);
+#pragma unroll
+    for (int i = 0; i < CR_MAXCH; ++i) {
+      int c = lane + 64 * i;
+      if (c < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (d[i][e] - yv[i][e] * p) * inv;
+        store8(dx + (size_t)n * D + c * 8, o);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void critic_bwd_kernel(const T* f1, const T* f2, const float* temperature, const float* work, const float* gout, float scale,
                                                          int B, int D, T* df1, T* df2, float* dtemp) {
@@ -210,6 +287,34 @@ extern "C" int clite_l2_normalize(int dtype, const void* x, void* out, int B, in
   DISPATCH(dtype,
            hipLaunchKernelGGL(l2_normalize_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, (bf16*)out, B, D),
            hipLaunchKernelGGL(l2_normalize_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)out, B, D));
+  return (int)hipGetLastError();
+}
+extern "C" int clite_infonce_fwd(const float* Cm, int ld, int B, const float* temperature, float* lse_r, float* lse_c, float* acc, void* stream) {
+  if (B <= 0 || ld < B || !Cm || !temperature || !lse_r || !lse_c || !acc) return -1;
+  int grid = (B + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(infonce_lse_kernel, dim3(grid), dim3(256), 0, st, Cm, ld, 1, B, temperature, lse_r, acc);          // rows: image -> text
+  hipLaunchKernelGGL(infonce_lse_kernel, dim3(grid), dim3(256), 0, st, Cm, 1, ld, B, temperature, lse_c, acc + 1);      // columns: text -> image
+  return (int)hipGetLastError();
+}
+extern "C" int clite_infonce_bwd(int dtype, const float* Cm, int ld, int B, const float* temperature, const float* lse_r, const float* lse_c,
+                                 const float* gout, float scale, void* dC, int ldd, float* dtemp, void* stream) {
+  if (B <= 0 || ld < B || ldd < B || ldd % 8 || !Cm || !temperature || !lse_r || !lse_c || !gout || !dC) return -1;
+  int grid = (B + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(infonce_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, Cm, ld, B, temperature, lse_r, lse_c, gout, scale, (bf16*)dC, ldd, dtemp),
+           hipLaunchKernelGGL(infonce_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, Cm, ld, B, temperature, lse_r, lse_c, gout, scale, (float*)dC, ldd, dtemp));
+  return (int)hipGetLastError();
+}
+extern "C" int clite_l2_normalize_bwd(int dtype, const void* x, const void* y, const void* dy, void* dx, int B, int D, void* stream) {
+  if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !x || !y || !dy || !dx) return -1;
+  int grid = (B + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(l2_normalize_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, (const bf16*)y, (const bf16*)dy, (bf16*)dx, B, D),
+           hipLaunchKernelGGL(l2_normalize_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (const float*)y, (const float*)dy, (float*)dx, B, D));
   return (int)hipGetLastError();
 }
 extern "C" int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, const float* temperature, const float* work, const float* gout, float scale,

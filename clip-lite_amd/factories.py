@@ -10,7 +10,7 @@ from torch import nn
 from . import data as vdata
 from .config import Config
 from .encoder import ImageEncoder, TextEncoder
-from .loss import JSDInfoMaxLoss
+from .loss import InfoNCELoss, JSDInfoMaxLoss
 from .model import VLInfoModel
 from .optim import FusedSGD, Lookahead, lr_scheduler
 
@@ -75,7 +75,7 @@ class TextualHeadFactory(Factory):
 
 
 class LossFactory(Factory):
-    PRODUCTS: Dict[str, Callable] = {"jsd": JSDInfoMaxLoss}
+    PRODUCTS: Dict[str, Callable] = {"jsd": JSDInfoMaxLoss, "infonce": InfoNCELoss}     # "infonce": BASELINE config 4 (not in the reference)
 
     @classmethod
     def from_config(cls, config: Config) -> JSDInfoMaxLoss:

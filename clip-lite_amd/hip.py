@@ -83,6 +83,9 @@ _SIGNATURES = {
     "clite_tanh_bwd": [_I, _V, _V, _V, _U64, _V],
     "clite_critic_jsd_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V],
     "clite_l2_normalize": [_I, _V, _V, _I, _I, _V],
+    "clite_l2_normalize_bwd": [_I, _V, _V, _V, _V, _I, _I, _V],
+    "clite_infonce_fwd": [_V, _I, _I, _V, _V, _V, _V, _V],
+    "clite_infonce_bwd": [_I, _V, _I, _I, _V, _V, _V, _V, _F, _V, _I, _V, _V],
     "clite_critic_jsd_bwd": [_I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V],
     "clite_prior_tail_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V],
     "clite_prior_tail_bwd": [_I, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V],
@@ -345,6 +348,18 @@ def critic_jsd_fwd(dt, f1, f2, temperature, B, D, work, acc):
 
 def l2_normalize(dt, x, out, B, D):
     check(lib().clite_l2_normalize(dt, p(x), p(out), B, D, stream_ptr(x)), "l2_normalize")
+
+
+def l2_normalize_bwd(dt, x, y, dy, dx, B, D):
+    check(lib().clite_l2_normalize_bwd(dt, p(x), p(y), p(dy), p(dx), B, D, stream_ptr(x)), "l2_normalize_bwd")
+
+
+def infonce_fwd(Cm, ld, B, temperature, lse_r, lse_c, acc):
+    check(lib().clite_infonce_fwd(p(Cm), ld, B, p(temperature), p(lse_r), p(lse_c), p(acc), stream_ptr(Cm)), "infonce_fwd")
+
+
+def infonce_bwd(dt, Cm, ld, B, temperature, lse_r, lse_c, gout, scale, dC, ldd, dtemp):
+    check(lib().clite_infonce_bwd(dt, p(Cm), ld, B, p(temperature), p(lse_r), p(lse_c), p(gout), scale, p(dC), ldd, p(dtemp), stream_ptr(Cm)), "infonce_bwd")
 
 
 def critic_jsd_bwd(dt, f1, f2, temperature, work, gout, scale, B, D, df1, df2, dtemp):

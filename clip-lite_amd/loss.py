@@ -74,6 +74,7 @@ class JSDInfoMaxLoss(nn.Module):
         if text_prior:
             self.text_prior_d = PriorDiscriminator(sz=text_dim)
         self._noise = None      # test hook: pins the two rand_like draws (image, text)
+        self.estimator = "jsd"  # cross-modal term: "jsd" (reference loss.py:206-222,254) or "infonce" (InfoNCELoss below)
 
     def set_prior_noise(self, image_noise, text_noise):
         """Pin the prior noise (reference loss.py:189,196 draws torch.rand_like(image) then (text)); parity tests only."""
@@ -87,6 +88,17 @@ class JSDInfoMaxLoss(nn.Module):
         total, comps = _JSDLossFn.apply(image_features, text_features, self, rt, rt.next_step(self.training))
         zero = comps[3]
         return {"total_loss": total, "cross_modal_loss": comps[1], "visual_loss": zero, "textual_loss": zero}
+
+
+class InfoNCELoss(JSDInfoMaxLoss):
+    """All-pairs InfoNCE variant (BASELINE config 4; SURVEY §8f N4 — the reference has no such code). Same projection heads, learnable
+    temperature and prior discriminators as JSDInfoMaxLoss (identical parameters / state_dict keys); the cross-modal term is the symmetric
+    cross-entropy, with diagonal targets, over S = exp(tau) * normalize(img_block(I)) @ normalize(text_block(T)).T: the B x B similarity is
+    one MFMA GEMM, its two gradients two more. Negatives are the other captions / images of the local batch."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.estimator = "infonce"
 
 
 def _runtime_of(module):
@@ -221,8 +233,21 @@ def jsd_forward(rt, mod, img, txt, step):
     f2, c2 = mi_block_forward(rt, gd.text_block, txt, training)
     if training:
         rt.bump_counters("loss", 2)
-    work = torch.empty(B, 8, device=rt.device, dtype=torch.float32)
-    hip.critic_jsd_fwd(dt, f1, f2, gd.temperature, B, gd.img_block.units, work, acc)
+    U = gd.img_block.units
+    if getattr(mod, "estimator", "jsd") == "infonce":
+        if B % 8:
+            raise RuntimeError("InfoNCELoss needs a batch that is a multiple of 8 (GEMM column granularity)")
+        a, b = _alloc(rt, B, U), _alloc(rt, B, U)
+        hip.l2_normalize(dt, f1, a, B, U)
+        hip.l2_normalize(dt, f2, b, B, U)
+        Cm = torch.empty(B, B, device=rt.device, dtype=torch.float32)
+        hip.gemm_nt(dt, a, b, B, B, U, hip.epilogue(Cm, B, out_f32=True))          # all-pairs cosines on the MFMA engine
+        lse = torch.empty(2, B, device=rt.device, dtype=torch.float32)
+        hip.infonce_fwd(Cm, B, B, gd.temperature, lse[0], lse[1], acc)
+        work = (a, b, Cm, lse)
+    else:
+        work = torch.empty(B, 8, device=rt.device, dtype=torch.float32)
+        hip.critic_jsd_fwd(dt, f1, f2, gd.temperature, B, U, work, acc)
     out = torch.empty(4, device=rt.device, dtype=torch.float32)
     hip.loss_finalize(acc, mod.prior_weight, out)
     return out, (f1, f2, c1, c2, work, pctx_i, pctx_t, B)
@@ -236,7 +261,17 @@ def jsd_backward(rt, mod, saved, gout):
     gd = mod.global_d
     U = gd.img_block.units
     df1, df2 = _alloc(rt, B, U), _alloc(rt, B, U)
-    hip.critic_jsd_bwd(dt, f1, f2, gd.temperature, work, gout, 1.0 - mod.prior_weight, B, U, df1, df2, A.g(gd.temperature).view(1))
+    if getattr(mod, "estimator", "jsd") == "infonce":
+        a, b, Cm, lse = work
+        dC = _alloc(rt, B, B)
+        hip.infonce_bwd(dt, Cm, B, B, gd.temperature, lse[0], lse[1], gout, 1.0 - mod.prior_weight, dC, B, A.g(gd.temperature).view(1))
+        da, db = _alloc(rt, B, U), _alloc(rt, B, U)
+        hip.gemm_nn(dt, dC, b, B, U, B, hip.epilogue(da, U))                        # da = dC  b
+        hip.gemm_tn(dt, dC, a, B, U, B, hip.epilogue(db, U))                        # db = dC^T a
+        hip.l2_normalize_bwd(dt, f1, a, da, df1, B, U)
+        hip.l2_normalize_bwd(dt, f2, b, db, df2, B, U)
+    else:
+        hip.critic_jsd_bwd(dt, f1, f2, gd.temperature, work, gout, 1.0 - mod.prior_weight, B, U, df1, df2, A.g(gd.temperature).view(1))
     dimg = prior_backward(rt, mod.prior_d, pctx_i, gout, mod.prior_weight, None) if pctx_i is not None else None
     dtxt = prior_backward(rt, mod.text_prior_d, pctx_t, gout, mod.prior_weight, None) if pctx_t is not None else None
     dimg = mi_block_backward(rt, gd.img_block, c1, df1, dimg)

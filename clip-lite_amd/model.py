@@ -73,7 +73,7 @@ class VLInfoModel(nn.Module):
             text_in = {"input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"]}
             if self.overlap_encoders and rt.device.type == "cuda":
                 if rt.side_stream is None:
-                    rt.side_stream = torch.cuda.Stream(device=rt.device)
+                    rt.side_stream = rt.new_side_stream()
                 main = rt.main_stream = torch.cuda.current_stream(rt.device)
                 rt.side_stream.wait_stream(main)
                 with torch.cuda.stream(rt.side_stream):

@@ -301,11 +301,16 @@ class DeviceRuntime:
         self.steps += 1
         return StepState(self.base_seed * 1000003 + self.steps, training)
 
+    def new_side_stream(self):
+        """The text encoder's stream. CLITE_SIDE_PRIORITY (default 0) sets its priority (-1 = high) for experiments."""
+        import os
+        return torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CLITE_SIDE_PRIORITY", "0")))
+
     def begin_capture(self):
         if self.seed_dev is None:
             self.seed_dev = torch.zeros(self.SEED_SLOTS, device=self.device, dtype=torch.int64)
         if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=self.device)
+            self.side_stream = self.new_side_stream()
         self._aux_for(torch.cuda.current_stream(self.device))
         self._capturing, self._slots = True, 0
         self._saved_zpools, self._zpools = self._zpools, {}     # chunks taken during capture live in the graph's memory pool

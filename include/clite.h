@@ -190,6 +190,15 @@ int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, const float*
 /* out[n] = x[n] / max(||x[n]||_2, 1e-12): F.normalize(p=2, dim=-1) of the embedding-extraction / retrieval path that consumes the trained
  * projection heads (reference retrieval.py:108,127; zero_shot.py). [B][D], D % 8 == 0, D <= 2048. */
 int clite_l2_normalize(int dtype, const void* x, void* out, int B, int D, void* stream);
+int clite_l2_normalize_bwd(int dtype, const void* x, const void* y, const void* dy, void* dx, int B, int D, void* stream);
+/* InfoNCE all-pairs variant of the cross-modal term (BASELINE config 4 / SURVEY §8f N4; the reference has no such code): symmetric
+ * cross-entropy with diagonal targets over S = exp(temperature) * C, C f32 [B][ld] the cosines of the L2-normalised projections
+ * (one clite_gemm_nt). lse_r / lse_c: f32 [B] kept for backward; acc[0] += mean_i(lse_r - S_ii)/2, acc[1] += mean_j(lse_c - S_jj)/2
+ * (same slots as the JSD terms, so clite_loss_finalize is shared). */
+int clite_infonce_fwd(const float* C, int ld, int B, const float* temperature, float* lse_r, float* lse_c, float* acc, void* stream);
+/* dC (call dtype, [B][ldd], ldd % 8 == 0, padding columns zeroed) = dL/dC; dtemp (f32 scalar) += ; scale = (1 - prior_weight). */
+int clite_infonce_bwd(int dtype, const float* C, int ld, int B, const float* temperature, const float* lse_r, const float* lse_c,
+                      const float* gout, float scale, void* dC, int ldd, float* dtemp, void* stream);
 /* gout: device scalar dL/d(total); scale = (1 - prior_weight). df1/df2 in dtype; dtemp (f32 scalar) += . */
 int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, const float* temperature, const float* work, const float* gout, float scale,
                          int B, int D, void* df1, void* df2, float* dtemp, void* stream);

@@ -360,3 +360,49 @@ def test_l2_normalize_rows(dtype):
     got = val(out, dtype)
     assert np.abs(got - ref).max() < (6e-3 if dtype == BF16 else 1e-6)
     assert not got[2].any()
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_infonce_terms_and_normalize_backward(dtype):
+    """clite_infonce_fwd/bwd against a float64 numpy evaluation of the symmetric cross-entropy over exp(tau)*C (finite differences for
+    the gradient w.r.t. C and tau), and clite_l2_normalize_bwd against the analytic Jacobian."""
+    rng = np.random.default_rng(5)
+    B, ld = 10, 16
+    Cm = np.zeros((B, ld), np.float32)
+    Cm[:, :B] = rng.uniform(-1, 1, (B, B)).astype(np.float32)
+    temp = np.array([np.log(1 / 0.07)], np.float32)
+
+    def loss(Cv, t):
+        S = np.exp(t) * Cv[:, :B].astype(np.float64)
+        lr = np.log(np.exp(S - S.max(1, keepdims=True)).sum(1)) + S.max(1)
+        lc = np.log(np.exp(S - S.max(0, keepdims=True)).sum(0)) + S.max(0)
+        return ((lr - np.diag(S)).sum() + (lc - np.diag(S)).sum()) / (2 * B), lr, lc
+
+    lse_r, lse_c, acc = np.zeros(B, np.float32), np.zeros(B, np.float32), np.zeros(4, np.float32)
+    assert lib().clite_infonce_fwd(ptr(Cm), ld, B, ptr(temp), ptr(lse_r), ptr(lse_c), ptr(acc), None) == 0
+    L, lr, lc = loss(Cm, float(temp[0]))
+    assert abs(acc[0] + acc[1] - L) < 1e-5 and np.abs(lse_r - lr).max() < 1e-4 and np.abs(lse_c - lc).max() < 1e-4
+    gout = np.array([0.7], np.float32)
+    dC = outbuf((B, ld), dtype)
+    dtemp = np.zeros(1, np.float32)
+    assert lib().clite_infonce_bwd(dtype, ptr(Cm), ld, B, ptr(temp), ptr(lse_r), ptr(lse_c), ptr(gout), C.c_float(0.9), ptr(dC), ld, ptr(dtemp), None) == 0
+    got = val(dC, dtype)
+    eps = 1e-3
+    for (i, j) in [(0, 0), (2, 7), (9, 3), (4, 4)]:
+        Cp, Cq = Cm.copy(), Cm.copy()
+        Cp[i, j] += eps; Cq[i, j] -= eps
+        fd = 0.7 * 0.9 * (loss(Cp, float(temp[0]))[0] - loss(Cq, float(temp[0]))[0]) / (2 * eps)
+        assert abs(got[i, j] - fd) < (2e-2 if dtype == BF16 else 2e-3) * max(1.0, abs(fd))
+    assert not got[:, B:].any()
+    fdt = 0.7 * 0.9 * (loss(Cm, float(temp[0]) + eps)[0] - loss(Cm, float(temp[0]) - eps)[0]) / (2 * eps)
+    assert abs(dtemp[0] - fdt) < 2e-3 * max(1.0, abs(fdt))
+    # normalize backward
+    D = 136
+    x, xb = prep(rng.standard_normal((B, D), dtype=np.float32) * 2, dtype)
+    dy, dyb = prep(rng.standard_normal((B, D), dtype=np.float32), dtype)
+    n = np.linalg.norm(x, axis=1, keepdims=True)
+    y, yb = prep(x / n, dtype)
+    dx = outbuf((B, D), dtype)
+    assert lib().clite_l2_normalize_bwd(dtype, ptr(xb), ptr(yb), ptr(dyb), ptr(dx), B, D, None) == 0
+    ref = (dy - y * (dy * y).sum(1, keepdims=True)) / n
+    assert np.abs(val(dx, dtype) - ref).max() < (2e-2 if dtype == BF16 else 1e-5)
