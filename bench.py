@@ -25,14 +25,15 @@ HBM_PEAK_GBS = 8000.0
 
 def build(args, device):
     from clip_lite_amd.encoder import ImageEncoder, TextEncoder
-    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.loss import InfoNCELoss, JSDInfoMaxLoss
     from clip_lite_amd.model import VLInfoModel
     from clip_lite_amd.optim import FusedSGD, Lookahead
     from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
     torch.manual_seed(1234)
     ie = ImageEncoder(args.visual)
     te = TextEncoder(mode="train_sbert", num_hidden_layers=args.layers)
-    loss = JSDInfoMaxLoss(ie.img_encoder.out_dim, 768, "dot", 0.1, True, True)
+    loss_cls = InfoNCELoss if args.loss == "infonce" else JSDInfoMaxLoss
+    loss = loss_cls(ie.img_encoder.out_dim, 768, "dot", 0.1, True, True)
     model = VLInfoModel(te, ie, loss, "train_sbert", is_amp=not args.f32).to(device).train()
     groups = []
     for name, p in model.named_parameters():      # reference factories.py:464-482
@@ -91,7 +92,7 @@ def pmc_traffic(args):
     """HBM-side bytes of the igemm family per step (all 335 launches), from the committed PMC passes of this configuration
     (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be
     collected inside a timed run, so this is the profiles/ measurement, not a live one. None for other configurations."""
-    if args.visual != "resnet50" or args.layers != 12 or args.batch != 128 or args.f32:
+    if args.visual != "resnet50" or args.layers != 12 or args.batch != 128 or args.f32 or args.loss != "jsd":
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "r1_igemm_hbm_traffic.json")) as f:
@@ -145,6 +146,7 @@ def main():
     ap.add_argument("--visual", default="resnet50")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--f32", action="store_true", help="exact-f32 parity kernels instead of bf16")
+    ap.add_argument("--loss", default="jsd", choices=["jsd", "infonce"], help="cross-modal term: the reference's JSD estimator or the InfoNCE all-pairs variant (BASELINE config 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL over xGMI); gloo is for single-GPU logic tests")
@@ -212,7 +214,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.f32 else "bf16", "data": "synthetic",
             "config": {"workload": f"{args.visual} + BERT-base({args.layers}L) + JSD-MI heads/priors, per-GPU batch {args.batch}, 224x224 images, "
-                                   f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)",
+                                   f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)" + ("" if args.loss == "jsd" else ", InfoNCE all-pairs loss"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "loss": loss, "launch": "hipGraph replay" if step.graph else "eager",
             "roofline": {"bound": "mfma", "kernel": "clite::igemm_dma_kernel family (all conv/linear fwd+dgrad+wgrad launches of one step)",
