@@ -122,10 +122,13 @@ class TrainStep:
         pool_main, pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
         graphs, keep = {}, {}
 
+        # data parallel: RCCL's watchdog / proxy threads keep making HIP calls of their own; only this thread's calls belong to the capture
+        mode = "thread_local" if self.exchange is not None else "global"
+
         def capture(name, pool, fn):
             rt._zpools = {}                   # a segment zeroes the accumulators it uses itself
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
                 fn()
             graphs[name] = g
 
