@@ -267,7 +267,13 @@ class TrainStep:
             if self._eager_steps < self.graph_warmup:
                 self._eager_steps += 1
                 return self._eager(batch)
-            self._capture(batch)
+            try:
+                self._capture(batch)
+            except Exception as e:      # noqa: BLE001 — never lose the run to the launch-path optimisation: same kernels, eager launches
+                logger.warning(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}); continuing with eager launches")
+                self.graph, self._g, self._graphs = False, None, None
+                torch.cuda.synchronize()
+                return self._eager(batch)
         if not self._same_shapes(batch) or not self.model.training:
             return self._eager(batch)             # a batch of another shape (e.g. a ragged last one): same kernels, launched from Python
         return self._replay(batch)
