@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--visual", default="resnet50")
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--f32", action="store_true")
+    ap.add_argument("--loss", default="jsd", choices=["jsd", "infonce"])
     args = ap.parse_args()
     from clip_lite_amd import hip
     from clip_lite_amd.train_loop import TrainStep
