@@ -92,7 +92,7 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
       // it implements exactly: out = [(alpha*acc) (* relu'(aux))] (+ residual) [(* relu'(aux))], colsum; nothing else
       if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || splits != 1) return -1;
       if constexpr (IsDgrad<LA>::value) {
-        hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, true>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+        hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, 1>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
                            M, N, ktiles, per, xsplits);
         return (int)hipGetLastError();
       } else {
@@ -109,6 +109,11 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
     bool deep = 4 * STAGE <= 65536 && (long)tiles * splits <= 2 * 256 && per >= 4 && stages_pref() != 3;
     if (deep || (stages_pref() == 4 && 4 * STAGE <= 65536))
       hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 4>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+                         M, N, ktiles, per, xsplits);
+    else if (sizeof(T) == 2 && !ep.atomic && !ep.out_f32 && !ep.preact && ep.act == CLITE_ACT_NONE && !ep.dact_aux && ep.drop_p <= 0.f && !ep.residual && !ep.bn_y &&
+             !ep.mask_after_residual)
+      // plain bf16 store (+ bias, + column statistics): the branch-free epilogue instantiation
+      hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, 2>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
                          M, N, ktiles, per, xsplits);
     else
       hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,

@@ -489,6 +489,77 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
   }
 }
 
+// Plain form of the epilogue as its own instantiation (EPI = 2): bf16 store of alpha*acc + bias, optionally with the column statistics —
+// every conv forward, the QKV projection, plain dgrads. The generic body tests ~15 wave-uniform flags per row, and at one wave per SIMD
+// those scalar branches — not the stores, not the LDS reads (both ablated with tools/probe_stamps.py) — are what a row costs: this
+// body has none of them (epilogue of the 1x1 64->256 conv: 5.4 -> 3.8 us per workgroup). Same pass structure and barrier count as
+// igemm_epilogue.
+template <typename T, class CFG>
+DEV void igemm_epilogue_plain(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
+                              int tid, int lane, int wave, int wm0, int wn0) {
+  constexpr int BN = CFG::BN;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int CPRE = BN / 8, RPSE = 256 / CPRE, ITER = CFG::WM / RPSE;
+  const int ecol = (tid % CPRE) * 8, erow0 = tid / CPRE;
+  const int gcol = n0 + ecol;
+  const bool colok = gcol < N;
+  const bool stats = ep.colsum != nullptr;
+  float csum[8], csq[8], bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; bias[e] = (colok && ep.bias) ? ep.bias[gcol + e] : 0.f; }
+  for (int pass = 0; pass < CFG::WAVES_M; ++pass) {
+    if (wave / CFG::WAVES_N == pass) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            int col = wn0 + j * 32 + (lane & 31);
+            *(float*)(smem + row * CFG::EPI_PITCH + col * 4) = acc[i][j][r];
+          }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int rr = erow0 + it * RPSE;
+      const int grow = m0 + pass * CFG::WM + rr;
+      if (colok && grow < M) {
+        const float* src = (const float*)(smem + rr * CFG::EPI_PITCH + ecol * 4);
+        f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
+        store8((bf16*)ep.out + (map_row(rm, grow) * ep.ldc + gcol), v);
+        if (stats) {
+          round8_bf16(v);   // statistics of what was stored
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+        }
+      }
+    }
+    lds_barrier();
+  }
+  if (stats) {
+    float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
+    float* red = (float*)smem;                      // [RPSE][CPRE*16]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + e] = csum[e];
+      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + 8 + e] = csq[e];
+    }
+    lds_barrier();
+    for (int idx = tid; idx < CPRE * 16; idx += 256) {
+      float sacc = 0.f;
+      for (int r = 0; r < RPSE; ++r) sacc += red[r * (CPRE * 16) + idx];
+      int chunk = idx / 16, e = idx % 16;
+      int col = n0 + chunk * 8 + (e & 7);
+      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
+    }
+  }
+}
+
 // BatchNorm-backward epilogue (conv dgrad inside the ResNet backward; see HEAVY above) in its own layout: the kernel runs at two
 // workgroups per CU anyway (registers), so the whole BM x BN accumulator tile is staged in LDS at once (one barrier instead of two per
 // wave row) and every thread then walks its BM/RPSE rows with the three extra operands (mask source, BatchNorm input, residual) of the

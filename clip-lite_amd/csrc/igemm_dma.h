@@ -268,13 +268,14 @@ template <typename T, int ROWS, int BK, bool D> struct DmaIssue<DmaKC<T, ROWS, B
   DEV static void go(const L& l, typename L::State& st, char* lds, int wave, int, int) { l.issue(st, lds, wave); }
 };
 
-template <typename T, class CFG, class LA, class LB, int NSTAGE, bool HEAVY = false>
+// EPI: 0 = generic fused epilogue, 1 = BatchNorm-backward epilogue (igemm_epilogue_bn), 2 = plain bf16 store (+ bias, + column statistics)
+template <typename T, class CFG, class LA, class LB, int NSTAGE, int EPI = 0>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split, int xsplits) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
-  constexpr int EPI = HEAVY ? CFG::BM * CFG::EPI_PITCH : CFG::EPI_BYTES;      // the BatchNorm-backward epilogue stages the whole tile
-  constexpr int SMEM = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
+  constexpr int EPIB = EPI == 1 ? CFG::BM * CFG::EPI_PITCH : CFG::EPI_BYTES;      // the BatchNorm-backward epilogue stages the whole tile
+  constexpr int SMEM = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
   constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
@@ -409,7 +410,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
   }
   barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
   STAMP(4);
-  if constexpr (HEAVY) igemm_epilogue_bn<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  if constexpr (EPI == 1) igemm_epilogue_bn<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  else if constexpr (EPI == 2 && sizeof(T) == 2) igemm_epilogue_plain<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
   else igemm_epilogue<T, CFG, false>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
   STAMP(5);
 }
