@@ -245,7 +245,8 @@ def bert_backward(rt, net, ctx, dpooled):
     ds0 = _alloc(rt, M, Hd)
     hip.layernorm_bwd(dt, dh, ctx["s0"], ctx["st0"], emb.LayerNorm.weight, ds0, None, A.g(emb.LayerNorm.weight), A.g(emb.LayerNorm.bias), M, Hd,
                       drop_in=ctx["d0"])
-    hip.embed_bwd(dt, ctx["ids"], ds0, A.g(emb.word_embeddings.weight), A.g(emb.position_embeddings.weight), M, L, Hd, net.vocab)
+    hip.embed_bwd(dt, ctx["ids"], ds0, A.g(emb.word_embeddings.weight), A.g(emb.position_embeddings.weight), M, L, Hd, net.vocab,
+                  padding_idx=0)      # HF BertEmbeddings: nn.Embedding(vocab, hidden, padding_idx=pad_token_id = 0)
     hip.colsum(dt, ds0, A.g(emb.token_type_embeddings.weight)[0], M, Hd)
     rt.join_aux()
     rt.grads_ready(emb)

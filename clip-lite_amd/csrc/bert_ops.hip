@@ -73,21 +73,25 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
 
 // dy' = dropout_mask_in(dy); dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy'*gamma; dgamma += sum dy'*xhat; dbeta += sum dy'
 // optional second output dx_masked = dropout_mask_out(dx)
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_masked,
-                                                            float* dgamma, float* dbeta, int M, int C, Drop drop_in, Drop drop_out) {
+// NW waves per workgroup, one row per wave at a time. The dgamma/dbeta float atomics of ALL workgroups hit the same 2*C addresses, and
+// same-address atomics serialise at the memory side (~25 ns per adder): with 512 four-wave workgroups they were more than half of the
+// kernel's 23 us at M = 3840, C = 768. Hence few, large workgroups (NW = 8 — 16 waves spill at 128 registers — and at most LN_BWD_MAX_WG
+// of them): <= 96 adders per address.
+template <typename T, int NCH, int NW>
+__global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_masked,
+                                                                float* dgamma, float* dbeta, int M, int C, Drop drop_in, Drop drop_out) {
   seed_resolve(drop_in.seed, drop_in.site);
   seed_resolve(drop_out.seed, drop_out.site);
-  __shared__ float red[4][64 * NCH * 8];   // [wave][per-lane partials], used once for dgamma and once for dbeta
+  __shared__ float red[NW][64 * NCH * 8];   // [wave][per-lane partials], used once for dgamma and once for dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = C / 8;
   const float invC = 1.0f / (float)C;
   float ag[NCH][8], ab[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) { zero8(ag[i]); zero8(ab[i]); }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * NW + wave; row < M; row += gridDim.x * NW) {
     float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    float d[NCH][8], xh[NCH][8], g[NCH][8];
+    float d[NCH][8], xh[NCH][8];          // g = d*gamma is re-formed in the second loop (gamma is L1-resident): 8*NCH fewer live registers
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -102,9 +106,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           xh[i][e] = (xv[e] - mean) * rstd;
-          g[i][e] = d[i][e] * gm[e];
-          s1 += g[i][e];
-          s2 += g[i][e] * xh[i][e];
+          const float ge = d[i][e] * gm[e];
+          s1 += ge;
+          s2 += ge * xh[i][e];
           ag[i][e] += d[i][e] * xh[i][e];
           ab[i][e] += d[i][e];
         }
@@ -116,9 +120,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
       int c = lane + 64 * i;
       if (c < nchunk) {
         size_t idx = (size_t)row * C + c * 8;
-        float o[8];
+        float o[8], gm[8];
+        load8(gamma + c * 8, gm);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - m1 - xh[i][e] * m2);
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (d[i][e] * gm[e] - m1 - xh[i][e] * m2);
         store8(dx + idx, o);
         if (dx_masked) {
           if (drop_out.p > 0.f) apply_dropout8(drop_out, idx, o);
@@ -137,10 +142,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* dy, const T
     __syncthreads();
     float* dst = which == 0 ? dgamma : dbeta;
     if (dst) {
-      for (int j = threadIdx.x; j < NCH * 64 * 8; j += 256) {
+      for (int j = threadIdx.x; j < NCH * 64 * 8; j += NW * 64) {
         int i = j / 512, l = (j / 8) % 64, e = j % 8;
         int c = l + 64 * i;
-        if (c < nchunk) atomic_add_f32(dst + c * 8 + e, red[0][j] + red[1][j] + red[2][j] + red[3][j]);
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sacc += red[w][j];
+        if (c < nchunk) atomic_add_f32(dst + c * 8 + e, sacc);
       }
     }
   }
@@ -167,9 +175,10 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* ids, cons
   }
 }
 
-// dword[ids[row]] += d[row] (float atomics)
+// dword[ids[row]] += d[row] (float atomics); rows whose id is padding_idx contribute nothing (nn.Embedding(padding_idx) semantics — and the
+// pad token is the one id thousands of rows share, i.e. the worst same-address atomic contention of the step)
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* d, float* dword, int M, int C, int vocab) {
+__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* d, float* dword, int M, int C, int vocab, int padding_idx) {
   const int nchunk = C / 8;
   size_t total = (size_t)M * nchunk;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -178,6 +187,7 @@ __global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids,
     int64_t id = ids[row];
     if (id < 0) id = 0;
     if (id >= vocab) id = vocab - 1;
+    if (id == padding_idx) continue;
     float v[8];
     load8(d + (size_t)row * C + c * 8, v);
 #pragma unroll
@@ -593,20 +603,23 @@ extern "C" int clite_layernorm_bwd(int dtype, const void* dy, const void* x, con
                                    float* dgamma, float* dbeta, int M, int C, float in_p, uint64_t in_seed, uint32_t in_site,
                                    float out_p, uint64_t out_seed, uint32_t out_site, void* stream) {
   if (!ln_ok(M, C) || !dy || !x || !stats || !dx) return -1;
-  int grid = (M + 3) / 4;
-  if (grid > 512) grid = 512;
+  constexpr int NW = 8, LN_BWD_MAX_WG = 96;
+  int grid = (M + NW - 1) / NW;
+  if (grid > LN_BWD_MAX_WG) grid = LN_BWD_MAX_WG;
   Drop di{in_p, in_seed, in_site}, dout{out_p, out_seed, out_site};
   hipStream_t st = (hipStream_t)stream;
   if (C <= 1024) {
     constexpr int NCHV = 2;
     DISPATCH(dtype,
-             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
-             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
+             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV, NW>), dim3(grid), dim3(NW * 64), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
+             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV, NW>), dim3(grid), dim3(NW * 64), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
   } else {
-    constexpr int NCHV = 4;
+    constexpr int NCHV = 4, NW4 = 8;      // 4 chunks per lane: 8 waves keep the row state in registers
+    grid = (M + NW4 - 1) / NW4;
+    if (grid > LN_BWD_MAX_WG) grid = LN_BWD_MAX_WG;
     DISPATCH(dtype,
-             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
-             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
+             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV, NW4>), dim3(grid), dim3(NW4 * 64), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
+             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV, NW4>), dim3(grid), dim3(NW4 * 64), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
   }
   return (int)hipGetLastError();
 }
@@ -622,14 +635,15 @@ extern "C" int clite_embed_fwd(int dtype, const int64_t* ids, const void* word, 
   return (int)hipGetLastError();
 }
 
-extern "C" int clite_embed_bwd(int dtype, const int64_t* ids, const void* d, float* dword, float* dpos, int M, int L, int C, int vocab, void* stream) {
+extern "C" int clite_embed_bwd(int dtype, const int64_t* ids, const void* d, float* dword, float* dpos, int M, int L, int C, int vocab, int padding_idx,
+                               void* stream) {
   if (M <= 0 || L <= 0 || M % L || C % 8 || !ids || !d) return -1;
   hipStream_t st = (hipStream_t)stream;
   int g1 = ew_grid((size_t)M * (C / 8)), g2 = (L * (C / 8) + 255) / 256;
   if (dword) {
     DISPATCH(dtype,
-             hipLaunchKernelGGL(embed_bwd_word_kernel<bf16>, dim3(g1), dim3(256), 0, st, ids, (const bf16*)d, dword, M, C, vocab),
-             hipLaunchKernelGGL(embed_bwd_word_kernel<float>, dim3(g1), dim3(256), 0, st, ids, (const float*)d, dword, M, C, vocab));
+             hipLaunchKernelGGL(embed_bwd_word_kernel<bf16>, dim3(g1), dim3(256), 0, st, ids, (const bf16*)d, dword, M, C, vocab, padding_idx),
+             hipLaunchKernelGGL(embed_bwd_word_kernel<float>, dim3(g1), dim3(256), 0, st, ids, (const float*)d, dword, M, C, vocab, padding_idx));
   }
   if (dpos) {
     DISPATCH(dtype,

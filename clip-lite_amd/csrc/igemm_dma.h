@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
   for (int t = t_begin; t < t_end; ++t) {
     // tile t has landed once at most min(NSTAGE-2, tiles after t) younger tiles are still outstanding
     const int after = t_end - 1 - t;
-    if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LOADS_PER_TILE>();
+    if (NSTAGE >= 5 && after >= 3) wait_vmcnt<3 * LOADS_PER_TILE>();
+    else if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LOADS_PER_TILE>();
     else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
     else wait_vmcnt<0>();
     barrier_raw();
@@ -504,7 +505,8 @@ __global__ __launch_bounds__(512) void igemm_dma_kernel_g2(LA la, LB lb, Epilogu
     const int t = t_begin + it;
     const bool live = t < t_end;
     const int after = t_end - 1 - t;
-    if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LOADS_PER_TILE>();
+    if (NSTAGE >= 5 && after >= 3) wait_vmcnt<3 * LOADS_PER_TILE>();
+    else if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LOADS_PER_TILE>();
     else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
     else wait_vmcnt<0>();
     barrier_raw();

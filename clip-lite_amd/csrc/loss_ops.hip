@@ -227,6 +227,12 @@ __global__ __launch_bounds__(256) void prior_tail_bwd_kernel(const T* h1, const 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = K / 8;
   const float g = gout[0] * scale / (float)B;
+  // dw2 / db2: every row adds to the same K + 1 addresses, and same-address float atomics serialise at the memory side. Each wave keeps its
+  // rows' contributions in registers (K <= 512: one 8-column chunk per lane) and adds once at the end; the launch uses few workgroups.
+  float aw[8], ab = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) aw[e] = 0.f;
+  const bool one_chunk = nchunk <= 64;
   for (int r = blockIdx.x * 4 + wave; r < 2 * B; r += gridDim.x * 4) {
     float d = sigmoid_f(logit[r]);
     float gl = r < B ? -(1.f - d) * g : d * g;       // d(-log D) = -(1-D), d(-log(1-D)) = D
@@ -237,12 +243,18 @@ __global__ __launch_bounds__(256) void prior_tail_bwd_kernel(const T* h1, const 
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         o[e] = h[e] > 0.f ? gl * w[e] : 0.f;          // through the ReLU that produced h1
-        if (dw2) atomic_add_f32(dw2 + c * 8 + e, gl * h[e]);
+        if (one_chunk) aw[e] += gl * h[e];
+        else if (dw2) atomic_add_f32(dw2 + c * 8 + e, gl * h[e]);
       }
       store8(dh1 + (size_t)r * K + c * 8, o);
     }
-    if (lane == 0 && db2) atomic_add_f32(db2, gl);
+    ab += gl;
   }
+  if (one_chunk && dw2 && lane < nchunk) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomic_add_f32(dw2 + lane * 8 + e, aw[e]);
+  }
+  if (lane == 0 && db2) atomic_add_f32(db2, ab);
 }
 
 // out[0] = total = (1-w)*cross + w*prior, out[1] = cross, out[2] = prior, out[3] = 0  (acc: [-Ej, Em, img prior, text prior])
@@ -340,6 +352,7 @@ extern "C" int clite_prior_tail_bwd(int dtype, const void* h1, const float* w2, 
                                     void* dh1, float* dw2, float* db2, void* stream) {
   if (B <= 0 || K % 8 || !h1 || !w2 || !logit || !gout || !dh1) return -1;
   int grid = (2 * B + 3) / 4;
+  if (grid > 16) grid = 16;          // <= 64 waves add into dw2 / db2 (see the kernel)
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
            hipLaunchKernelGGL(prior_tail_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)h1, w2, logit, gout, scale, B, K, (bf16*)dh1, dw2, db2),

@@ -29,8 +29,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, size_t n, fl
 // hp: [0] lr multiplier (schedule), [1] momentum, [2] max grad norm (<= 0: no clipping), [3] lookahead sync flag,
 //     [4] lookahead alpha, [5] gradient pre-scale (1/world_size after a SUM all-reduce, 1/loss_scale, ...)
 template <typename T, bool CAST>
-__global__ __launch_bounds__(256) void sgd_step_kernel(float* p, float* g, float* v, float* slow, T* cast, const clite_optim_item* items,
-                                                       const float* hp, const float* sumsq) {
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ v, float* __restrict__ slow,
+                                                       T* __restrict__ cast, const clite_optim_item* __restrict__ items,
+                                                       const float* __restrict__ hp, const float* __restrict__ sumsq) {
   const clite_optim_item it = items[blockIdx.x];
   const float lr = it.lr * hp[0], wd = it.wd, mu = hp[1], max_norm = hp[2], alpha = hp[4], gs = hp[5];
   const bool sync = hp[3] != 0.f;
@@ -40,6 +41,8 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* p, float* g, float
     clip = fminf(max_norm / (total + 1e-6f), 1.f);
   }
   const float gmul = gs * clip;
+  // the five flat arrays never overlap (__restrict__), so the unrolled iterations' loads are all issued before the first store
+#pragma unroll 4
   for (uint32_t i = threadIdx.x * 4; i < it.count; i += 1024) {
     size_t o = (size_t)it.start + i;
     f32x4 pv = *(const f32x4*)(p + o), gv = *(const f32x4*)(g + o), vv = *(const f32x4*)(v + o);

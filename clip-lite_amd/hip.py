@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -77,7 +77,7 @@ _SIGNATURES = {
     "clite_layernorm_fwd": [_I, _V, _V, _V, _F, _V, _V, _I, _I, _F, _U64, _U32, _V],
     "clite_layernorm_bwd": [_I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _F, _U64, _U32, _F, _U64, _U32, _V],
     "clite_embed_fwd": [_I, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V],
-    "clite_embed_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _I, _V],
+    "clite_embed_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _I, _I, _V],
     "clite_attention_fwd": [_I, _V, _V, _V, _I, _I, _I, _F, _U64, _U32, _V],
     "clite_attention_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _F, _U64, _U32, _V],
     "clite_tanh_bwd": [_I, _V, _V, _V, _U64, _V],
@@ -325,8 +325,8 @@ def embed_fwd(dt, ids, word, pos, typ, out, M, L, Cc, vocab):
     check(lib().clite_embed_fwd(dt, p(ids), p(word), p(pos), p(typ), p(out), M, L, Cc, vocab, stream_ptr(out)), "embed_fwd")
 
 
-def embed_bwd(dt, ids, d, dword, dpos, M, L, Cc, vocab):
-    check(lib().clite_embed_bwd(dt, p(ids), p(d), p(dword), p(dpos), M, L, Cc, vocab, stream_ptr(d)), "embed_bwd")
+def embed_bwd(dt, ids, d, dword, dpos, M, L, Cc, vocab, padding_idx=-1):
+    check(lib().clite_embed_bwd(dt, p(ids), p(d), p(dword), p(dpos), M, L, Cc, vocab, padding_idx, stream_ptr(d)), "embed_bwd")
 
 
 def attention_fwd(dt, qkv, mask, ctx, B, L, H, drop=NO_DROP):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 2
+#define CLITE_ABI_VERSION 3
 int clite_abi_version(void);
 
 /* storage type of activations / weights handed to a kernel. CLITE_F32 selects the exact-f32 parity mode
@@ -170,8 +170,11 @@ int clite_layernorm_bwd(int dtype, const void* dy, const void* x, const float* s
 /* BertEmbeddings sum: out[row] = word[ids[row]] + pos[row % L] + type[0] (token_type_ids = 0, position_ids = arange(L)) */
 int clite_embed_fwd(int dtype, const int64_t* ids, const void* word, const void* pos, const void* type, void* out,
                     int M, int L, int C, int vocab, void* stream);
-/* dword[ids[row]] += d[row] (float atomics); dpos[l] += sum_b d[b*L+l]. Either may be NULL. */
-int clite_embed_bwd(int dtype, const int64_t* ids, const void* d, float* dword, float* dpos, int M, int L, int C, int vocab, void* stream);
+/* dword[ids[row]] += d[row] (float atomics) for ids[row] != padding_idx; dpos[l] += sum_b d[b*L+l]. Either may be NULL.
+ * padding_idx: the row nn.Embedding(padding_idx=...) never accumulates a gradient into (HF BertEmbeddings.word_embeddings: pad_token_id = 0,
+ * behind reference encoder.py:163-170); -1 = none. */
+int clite_embed_bwd(int dtype, const int64_t* ids, const void* d, float* dword, float* dpos, int M, int L, int C, int vocab, int padding_idx,
+                    void* stream);
 /* BertSelfAttention core for L <= 32, head size 64: qkv [B*L][3*H*64] (q|k|v), mask int64 [B][L] (1 = attend) or NULL,
  * ctx [B*L][H*64] = dropout(softmax(q k^T / 8 + (1-mask)*finfo.min)) v */
 int clite_attention_fwd(int dtype, const void* qkv, const int64_t* mask, void* ctx, int B, int L, int H,

@@ -73,6 +73,7 @@ def run_case(visual, mode, layers, lowp, B, S, Ls, idim, init="det"):
         ids[:, -1] = 102
         mask = torch.ones(B, Ls, dtype=torch.long)
         mask[B - 1, Ls - 2:] = 0
+        ids[mask == 0] = 0          # pad token: nn.Embedding(padding_idx=0) accumulates no gradient for it
         batch["input_ids"], batch["attention_mask"] = ids, mask
     u1, u2 = det_tensor("u1", (B, idim), "uniform"), det_tensor("u2", (B, 768), "uniform")
     M.loss.set_prior_noise(u1.cuda(), u2.cuda())
@@ -130,6 +131,7 @@ def _bf16_case(visual, mode, layers, B, S, Ls, idim):
         ids[:, -1] = 102
         mask = torch.ones(B, Ls, dtype=torch.long)
         mask[B - 1, Ls - 2:] = 0
+        ids[mask == 0] = 0          # pad token: nn.Embedding(padding_idx=0) accumulates no gradient for it
         batch["input_ids"], batch["attention_mask"] = ids, mask
     Me.loss.noise = tuple(t.bfloat16().float() for t in (det_tensor("u1", (B, idim), "uniform"), det_tensor("u2", (B, 768), "uniform")))
     oe = Me(round_batch(batch))

@@ -182,9 +182,19 @@ def test_embedding_fwd_bwd(dtype):
     _close(val(out, dtype), ref, _tol(dtype))
     d, dbuf = prep(rng.standard_normal((B * Ls, Cc), dtype=np.float32), dtype)
     dword = np.zeros((V, Cc), np.float32); dpos = np.zeros((16, Cc), np.float32)
-    assert lib().clite_embed_bwd(dtype, ptr(ids), ptr(dbuf), ptr(dword), ptr(dpos), B * Ls, Ls, Cc, V, None) == 0
+    assert lib().clite_embed_bwd(dtype, ptr(ids), ptr(dbuf), ptr(dword), ptr(dpos), B * Ls, Ls, Cc, V, -1, None) == 0
     rw = np.zeros((V, Cc), np.float32)
     np.add.at(rw, ids.reshape(-1), d)
+    _close(dword, rw, 1e-5)
+    _close(dpos[:Ls], d.reshape(B, Ls, Cc).sum(0), 1e-5)
+    # nn.Embedding(padding_idx=0): rows holding the pad token contribute nothing to the word-embedding gradient (the position sum is unaffected)
+    ids[:, -2:] = 0
+    dword[:] = 0; dpos[:] = 0
+    assert lib().clite_embed_bwd(dtype, ptr(ids), ptr(dbuf), ptr(dword), ptr(dpos), B * Ls, Ls, Cc, V, 0, None) == 0
+    rw = np.zeros((V, Cc), np.float32)
+    np.add.at(rw, ids.reshape(-1), d)
+    rw[0] = 0
+    assert np.count_nonzero(dword[0]) == 0
     _close(dword, rw, 1e-5)
     _close(dpos[:Ls], d.reshape(B, Ls, Cc).sum(0), 1e-5)
 
