@@ -73,10 +73,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
 
 // dy' = dropout_mask_in(dy); dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy'*gamma; dgamma += sum dy'*xhat; dbeta += sum dy'
 // optional second output dx_masked = dropout_mask_out(dx)
-// NW waves per workgroup, one row per wave at a time. The dgamma/dbeta float atomics of ALL workgroups hit the same 2*C addresses, and
-// same-address atomics serialise at the memory side (~25 ns per adder): with 512 four-wave workgroups they were more than half of the
-// kernel's 23 us at M = 3840, C = 768. Hence few, large workgroups (NW = 8 — 16 waves spill at 128 registers — and at most LN_BWD_MAX_WG
-// of them): <= 96 adders per address.
+// NW waves per workgroup, one row per wave at a time; one float atomic per column per workgroup for dgamma / dbeta. What the kernel costs at
+// M = 3840, C = 768 (tools/probe_ln.py): 11 us without the parameter gradients, 13 with them, 20 with the recomputed input dropout mask and
+// 27 with the masked second output as well — the Philox calls, not the atomics, are the expensive part, so the grid keeps one row or two
+// per wave (256 workgroups of 8 waves) rather than trading waves for fewer adders.
 template <typename T, int NCH, int NW>
 __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_masked,
                                                                 float* dgamma, float* dbeta, int M, int C, Drop drop_in, Drop drop_out) {
@@ -603,7 +603,7 @@ extern "C" int clite_layernorm_bwd(int dtype, const void* dy, const void* x, con
                                    float* dgamma, float* dbeta, int M, int C, float in_p, uint64_t in_seed, uint32_t in_site,
                                    float out_p, uint64_t out_seed, uint32_t out_site, void* stream) {
   if (!ln_ok(M, C) || !dy || !x || !stats || !dx) return -1;
-  constexpr int NW = 8, LN_BWD_MAX_WG = 96;
+  constexpr int NW = 8, LN_BWD_MAX_WG = 256;
   int grid = (M + NW - 1) / NW;
   if (grid > LN_BWD_MAX_WG) grid = LN_BWD_MAX_WG;
   Drop di{in_p, in_seed, in_site}, dout{out_p, out_seed, out_site};

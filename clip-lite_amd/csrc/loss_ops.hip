@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void uniform_fill_kernel(T* out, size_t n, uin
   size_t nch = n / 8;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nch; i += (size_t)gridDim.x * 256) {
     float u[8];
-    dropout_uniform8(seed, site, i * 8, u);
+    rng_uniform8(seed, site, i * 8, u);
     store8(out + i * 8, u);
   }
 }
