@@ -151,7 +151,15 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL over xGMI); gloo is for single-GPU logic tests")
     ap.add_argument("--single-device", action="store_true", help="logic test only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--force-exchange", action="store_true", help="run the gradient exchange (process group, RCCL all-reduces between the graphs) even with "
+                    "one rank: exercises the data-parallel launch path on a one-GPU box (launch under torch.distributed.run)")
     args = ap.parse_args()
+
+    # stdout carries exactly one line, the JSON result: RCCL prints a version banner to fd 1 when the process group comes up (and the encoders
+    # print construction banners), so fd 1 is pointed at stderr for the whole run and the result goes to the original stdout
+    sys.stdout.flush()
+    result_stream = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -162,7 +170,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_exchange
+    if dist_on:
         tdist.init_process_group(backend=args.backend, init_method="env://")
 
     from clip_lite_amd.train_loop import TrainStep
@@ -173,7 +182,7 @@ def main():
         model, opt, sched = build(args, device)
     cdist.broadcast_parameters(model)
     exchange = None
-    if world > 1:
+    if dist_on:
         exchange = cdist.GradientExchange(model.runtime.arena)
         model.runtime.exchange = exchange
     step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange, graph=not args.no_graph)
@@ -183,18 +192,18 @@ def main():
     for i in range(max(args.warmup, 3 if step.graph else 0)):      # graph mode: 2 eager steps, then the capture + first replay
         step(batches[i % len(batches)])
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(batches[i % len(batches)])
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         tdist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = t.item()
@@ -226,8 +235,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(res))
-    if world > 1:
+        print(json.dumps(res), file=result_stream, flush=True)
+    if dist_on:
         tdist.barrier()
         tdist.destroy_process_group()
 
