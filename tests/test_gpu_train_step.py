@@ -278,3 +278,24 @@ def test_graph_two_segment_step_with_exchange_single_rank():
     assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
     rel = ((d0 - d1).norm() / d0.norm()).item()
     assert d0.norm().item() > 1e-3 and rel < 2e-2, (d0.norm().item(), rel)
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_with_rccl_exchange_one_rank():
+    """bench.py launched the way the driver launches it (torch.distributed.run, backend nccl = RCCL), with the gradient exchange forced on for
+    the single rank: the process group comes up, the RCCL all-reduces run between the captured graphs of the step, and stdout is exactly
+    one JSON line (RCCL writes a version banner to fd 1 at init)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "3", "--batch", "16", "--visual", "resnet18", "--layers", "2",
+           "--force-exchange", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["launch"] == "hipGraph replay" and res["n_gpus"] == 1 and res["value"] > 0 and np.isfinite(res["loss"])
