@@ -318,23 +318,55 @@ class GlobalDiscriminatorDot(nn.Module):
         return (f1 * f2).sum(-1) * self.temperature.exp()
 
 
-class OracleJSDInfoMaxLoss(nn.Module):
-    """loss.py:110-314 for type="dot", no cluster negatives, no SSL branches (what every shipped YAML uses); device-agnostic
-    (the reference's `.cuda()` literals at loss.py:186,257,280 are dropped). `noise` optionally pins the two
-    torch.rand_like draws (loss.py:189,196) in their draw order (image, text)."""
+class GlobalDiscriminator(nn.Module):
+    """loss.py:56-68 — the `concat` critic: an MLP on cat(features1, features2)."""
 
-    def __init__(self, image_dim=2048, text_dim=768, type="dot", prior_weight=0.1, image_prior=True, text_prior=False, **_):
+    def __init__(self, sz):
         super().__init__()
-        assert type == "dot"
+        self.l0 = nn.Linear(sz, 512)
+        self.l1 = nn.Linear(512, 512)
+        self.l2 = nn.Linear(512, 1)
+
+    def forward(self, features1=None, features2=None):
+        x = torch.cat((features1, features2), dim=1)
+        return self.l2(F.relu(self.l1(F.relu(self.l0(x)))))
+
+
+def _roll1(t):
+    return torch.cat((t[1:], t[0].unsqueeze(0)), dim=0)
+
+
+class OracleJSDInfoMaxLoss(nn.Module):
+    """loss.py:110-314: critic types dot / concat / condot / dotcon (:129-169), the cluster hard-negative branch (:225-252) and the
+    visual / textual self-supervised terms (:256-300); device-agnostic (the reference's `.cuda()` literals at loss.py:186,257,280 are
+    dropped). `noise` optionally pins the two torch.rand_like draws (loss.py:189,196) in their draw order (image, text)."""
+
+    def __init__(self, image_dim=2048, text_dim=768, type="dot", prior_weight=0.1, image_prior=True, text_prior=False,
+                 visual_self_supervised=False, textual_self_supervised=False, **_):
+        super().__init__()
+        assert type in ("dot", "concat", "condot", "dotcon")
         self.prior_weight, self.image_prior, self.text_prior = prior_weight, image_prior, text_prior
-        self.global_d = GlobalDiscriminatorDot(image_dim, text_dim)
+        cross_dot = type in ("dot", "dotcon")
+        ssl_dot = type in ("dot", "condot")
+        self.global_d = GlobalDiscriminatorDot(image_dim, text_dim) if cross_dot else GlobalDiscriminator(image_dim + text_dim)
+        if visual_self_supervised:
+            self.visual_d = GlobalDiscriminatorDot(image_dim, image_dim) if ssl_dot else GlobalDiscriminator(2 * image_dim)
+        if textual_self_supervised:
+            self.textual_d = GlobalDiscriminatorDot(text_dim, text_dim) if ssl_dot else GlobalDiscriminator(2 * text_dim)
         if image_prior:
             self.prior_d = PriorDiscriminator(image_dim)
         if text_prior:
             self.text_prior_d = PriorDiscriminator(text_dim)
         self.noise = None
 
-    def forward(self, image_features, text_features):
+    @staticmethod
+    def _pair_terms(critic, f1, f2_pos, f2_neg):
+        ej = -F.softplus(-critic(features1=f1, features2=f2_pos)).mean()
+        em = F.softplus(critic(features1=f1, features2=f2_neg)).mean()
+        return em - ej
+
+    def forward(self, image_features, text_features, neg_image_features=None, neg_text_features=None,
+                aug_image_features=None, aug_text_features=None):
         prior = image_features.new_zeros(())
         if self.image_prior:
             u = torch.rand_like(image_features) if self.noise is None else self.noise[0]
@@ -342,13 +374,23 @@ class OracleJSDInfoMaxLoss(nn.Module):
         if self.text_prior:
             u = torch.rand_like(text_features) if self.noise is None else self.noise[1]
             prior = prior - (torch.log(self.text_prior_d(u)).mean() + torch.log(1.0 - self.text_prior_d(text_features)).mean())
-        ej = -F.softplus(-self.global_d(image_features, text_features)).mean()
-        tprime = torch.cat((text_features[1:], text_features[0].unsqueeze(0)), dim=0)
-        em = F.softplus(self.global_d(image_features, tprime)).mean()
-        cross = em - ej
+        if neg_text_features is None:
+            cross = self._pair_terms(self.global_d, image_features, text_features, _roll1(text_features))
+        else:
+            # cluster mode (loss.py:225-252): hard negatives for the first half, rolled in-batch negatives for the second; note that the
+            # reference re-binds text_features to the rolled batch here, so the textual SSL term below sees the rolled captions
+            img_all = torch.cat((image_features, neg_image_features), dim=0)
+            txt_all = torch.cat((text_features, neg_text_features), dim=0)
+            text_features = _roll1(text_features)
+            cross = self._pair_terms(self.global_d, img_all, txt_all, torch.cat((neg_text_features, text_features), dim=0))
         zero = image_features.new_zeros(())
-        total = (1.0 - self.prior_weight) * cross + self.prior_weight * prior
-        return {"total_loss": total, "cross_modal_loss": cross, "visual_loss": zero, "textual_loss": zero}
+        visual = textual = zero
+        if aug_image_features is not None:
+            visual = self._pair_terms(self.visual_d, image_features, aug_image_features, _roll1(aug_image_features))
+        if aug_text_features is not None:
+            textual = self._pair_terms(self.textual_d, text_features, aug_text_features, _roll1(aug_text_features))
+        total = (1.0 - self.prior_weight) * (cross + visual + textual) + self.prior_weight * prior
+        return {"total_loss": total, "cross_modal_loss": cross, "visual_loss": visual, "textual_loss": textual}
 
 
 class OracleVLInfoModel(nn.Module):

@@ -93,6 +93,42 @@ def g_loss(tag, B, idim, tdim):
          eval_proj_img=p_img, eval_proj_txt=p_txt)
 
 
+# ---------------------------------------------------------------- G1b: loss.py variants (critic types, cluster negatives, SSL terms)
+VARIANTS = {   # tag -> (type, cluster, visual_ssl, textual_ssl)
+    "lossvar_dot_cluster": ("dot", True, False, False),
+    "lossvar_concat": ("concat", False, False, False),
+    "lossvar_dot_ssl": ("dot", False, True, True),
+    "lossvar_condot_cluster_ssl": ("condot", True, True, True),
+    "lossvar_dotcon_ssl": ("dotcon", False, True, True),
+}
+
+
+def g_loss_variant(tag, B=8, idim=512, tdim=768):
+    ctype, cluster, vssl, tssl = VARIANTS[tag]
+    L = det_fill(ref_loss.JSDInfoMaxLoss(image_dim=idim, text_dim=tdim, type=ctype, prior_weight=0.1, image_prior=True, text_prior=True,
+                                         visual_self_supervised=vssl, textual_self_supervised=tssl))
+    L.train()
+    feats = {"img": det_tensor(tag + "img", (B, idim), "normal").abs(), "txt": torch.tanh(det_tensor(tag + "txt", (B, tdim), "normal"))}
+    if cluster:
+        feats["nimg"] = det_tensor(tag + "nimg", (B, idim), "normal").abs()
+        feats["ntxt"] = torch.tanh(det_tensor(tag + "ntxt", (B, tdim), "normal"))
+    if vssl:
+        feats["aimg"] = det_tensor(tag + "aimg", (B, idim), "normal").abs()
+    if tssl:
+        feats["atxt"] = torch.tanh(det_tensor(tag + "atxt", (B, tdim), "normal"))
+    for v in feats.values():
+        v.requires_grad_(True)
+    u_img, u_txt = det_tensor(tag + "u_img", (B, idim), "uniform"), det_tensor(tag + "u_txt", (B, tdim), "uniform")
+    d = pin_noise(lambda: L(feats["img"], feats["txt"], neg_image_features=feats.get("nimg"), neg_text_features=feats.get("ntxt"),
+                            aug_image_features=feats.get("aimg"), aug_text_features=feats.get("atxt")), [u_img, u_txt])
+    d["total_loss"].backward()
+    g = grads(L)
+    out = {k: v for k, v in feats.items()}
+    out.update({"d_" + k: v.grad for k, v in feats.items()})
+    save(tag, u_img=u_img, u_txt=u_txt, total=d["total_loss"], cross=d["cross_modal_loss"], visual=d["visual_loss"], textual=d["textual_loss"],
+         gnames=np.array(sorted(g)), gnorms=np.array([g[k].norm().item() for k in sorted(g)]), **out)
+
+
 # ---------------------------------------------------------------- G2: encoder.TextEncoder (HF BertModel), dropout pinned to 0
 def g_text(tag, B, Ls, layers, ragged):
     te = ref_encoder.TextEncoder(word_dict={}, mode="train_sbert", num_hidden_layers=layers)
@@ -186,6 +222,8 @@ def g_optim():
 if __name__ == "__main__":
     g_loss("loss_b8_rn18", 8, 512, 768)
     g_loss("loss_b6_rn50", 6, 2048, 768)
+    for tag in VARIANTS:
+        g_loss_variant(tag)
     g_text("text_l2_b4_len7_ragged", 4, 7, 2, True)
     g_text("text_l1_b3_len30", 3, 30, 1, False)
     g_model("model_rn18_sbert_b4", "resnet18", "sbert", 4, 64, 0, 0)
