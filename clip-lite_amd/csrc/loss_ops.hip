@@ -33,14 +33,17 @@ DEV float dot_rows(const float (&a)[CR_MAXCH][8], const float (&b)[CR_MAXCH][8])
   return wave_sum(s);
 }
 
-// work[n] = { |a_n|, |b_n|, |b_{n+1}|, cos+, cos-, o+, o-, 0 } ; acc[0] += softplus(-o+)/B ; acc[1] += softplus(o-)/B
+// work[n] = { |a_n|, |b_n|, |b_neg(n)|, cos+, cos-, o+, o-, 0 } ; acc[0] += softplus(-o+)/B ; acc[1] += softplus(o-)/B
+// neg: the row of f2 paired with row n as its negative; NULL = roll by one (n + 1 mod B, reference loss.py:214-216). The cluster
+// hard-negative branch (loss.py:225-252) passes the permutation [B/2 + i | (i + 1) mod B/2].
 template <typename T>
-__global__ __launch_bounds__(256) void critic_fwd_kernel(const T* f1, const T* f2, const float* temperature, int B, int D, float* work, float* acc) {
+__global__ __launch_bounds__(256) void critic_fwd_kernel(const T* f1, const T* f2, const float* temperature, int B, int D, const int32_t* neg, float* work,
+                                                         float* acc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D / 8;
   const float tscale = expf(temperature[0]);
   for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
-    int n1 = n + 1 == B ? 0 : n + 1;
+    int n1 = neg ? neg[n] : (n + 1 == B ? 0 : n + 1);
     float a[CR_MAXCH][8], b[CR_MAXCH][8], c[CR_MAXCH][8];
     load_row(f1 + (size_t)n * D, nchunk, lane, a);
     load_row(f2 + (size_t)n * D, nchunk, lane, b);
@@ -161,13 +164,14 @@ __global__ __launch_bounds__(256) void l2_normalize_bwd_kernel(const T* x, const
 
 template <typename T>
 __global__ __launch_bounds__(256) void critic_bwd_kernel(const T* f1, const T* f2, const float* temperature, const float* work, const float* gout, float scale,
-                                                         int B, int D, T* df1, T* df2, float* dtemp) {
+                                                         int B, int D, const int32_t* neg, const int32_t* neg_inv, T* df1, T* df2, float* dtemp) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D / 8;
   const float tscale = expf(temperature[0]);
   const float g = gout[0] * scale / (float)B;
   for (int m = blockIdx.x * 4 + wave; m < B; m += gridDim.x * 4) {
-    int m1 = m + 1 == B ? 0 : m + 1, mp = m == 0 ? B - 1 : m - 1;
+    // m1: the negative partner of row m; mp: the row whose negative partner is m (inverse permutation)
+    int m1 = neg ? neg[m] : (m + 1 == B ? 0 : m + 1), mp = neg_inv ? neg_inv[m] : (m == 0 ? B - 1 : m - 1);
     const float* w = work + (size_t)m * 8;
     const float* wp = work + (size_t)mp * 8;
     float na = w[0], nb = w[1], nc = w[2], cp = w[3], cn = w[4];
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) void critic_bwd_kernel(const T* f1, const T* f
 // PriorDiscriminator tail on stacked rows [noise u (B rows); features f (B rows)]: logit = h1 . w2 + b2, D = sigmoid(logit)
 // acc += -( mean log D(u) + mean log(1 - D(f)) )
 template <typename T>
-__global__ __launch_bounds__(256) void prior_tail_fwd_kernel(const T* h1, const float* w2, const float* b2, int B, int K, float* logit, float* acc) {
+__global__ __launch_bounds__(256) void prior_tail_fwd_kernel(const T* h1, const float* w2, const float* b2, int B, int K, int softplus, float* logit, float* acc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = K / 8;
   for (int r = blockIdx.x * 4 + wave; r < 2 * B; r += gridDim.x * 4) {
@@ -215,9 +219,17 @@ __global__ __launch_bounds__(256) void prior_tail_fwd_kernel(const T* h1, const 
     s = wave_sum(s) + b2[0];
     if (lane == 0) {
       logit[r] = s;
-      float d = sigmoid_f(s);
-      float term = r < B ? logf(d) : logf(1.f - d);
-      atomic_add_f32(acc, -term / (float)B);
+      // -log D = softplus(-s) and -log(1 - D) = softplus(s) mathematically, but not in f32: the reference's prior takes log(sigmoid(s)) and
+      // log(1 - sigmoid(s)) (loss.py:190-192), which lose digits for |s| >~ 10, and parity means reproducing that; the `concat` critic's two
+      // JSD terms are F.softplus in the reference (loss.py:206-222), selected by `softplus`
+      float term;
+      if (softplus) {
+        term = r < B ? softplus_f(-s) : softplus_f(s);
+      } else {
+        float d = sigmoid_f(s);
+        term = -(r < B ? logf(d) : logf(1.f - d));
+      }
+      atomic_add_f32(acc, term / (float)B);
     }
   }
 }
@@ -257,12 +269,26 @@ __global__ __launch_bounds__(256) void prior_tail_bwd_kernel(const T* h1, const 
   if (lane == 0 && db2) atomic_add_f32(db2, ab);
 }
 
-// out[0] = total = (1-w)*cross + w*prior, out[1] = cross, out[2] = prior, out[3] = 0  (acc: [-Ej, Em, img prior, text prior])
+// acc: [-Ej, Em | image prior, text prior | visual -Ej, Em | textual -Ej, Em]
+// out[0] = total = (1-w)*(cross + visual + textual) + w*prior (loss.py:302-305), out[1] = cross, out[2] = prior, out[3] = visual, out[4] = textual
 __global__ void loss_finalize_kernel(const float* acc, float prior_weight, float* out) {
   if (threadIdx.x == 0) {
-    float cross = acc[0] + acc[1], prior = acc[2] + acc[3];
-    out[0] = (1.f - prior_weight) * cross + prior_weight * prior;
-    out[1] = cross; out[2] = prior; out[3] = 0.f;
+    float cross = acc[0] + acc[1], prior = acc[2] + acc[3], visual = acc[4] + acc[5], textual = acc[6] + acc[7];
+    out[0] = (1.f - prior_weight) * (cross + visual + textual) + prior_weight * prior;
+    out[1] = cross; out[2] = prior; out[3] = visual; out[4] = textual; out[5] = out[6] = out[7] = 0.f;
+  }
+}
+
+// out = a + b (sums of feature gradients arriving from several loss terms)
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* out, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float x[8], y[8];
+    load8(a + i * 8, x);
+    load8(b + i * 8, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += y[e];
+    store8(out + i * 8, x);
   }
 }
 
@@ -282,13 +308,14 @@ __global__ __launch_bounds__(256) void uniform_fill_kernel(T* out, size_t n, uin
 #define DISPATCH(dtype, CALL_BF16, CALL_F32) \
   if ((dtype) == CLITE_BF16) { CALL_BF16; } else if ((dtype) == CLITE_F32) { CALL_F32; } else return -1;
 
-extern "C" int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, const float* temperature, int B, int D, float* work, float* acc, void* stream) {
+extern "C" int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, const float* temperature, int B, int D, const int32_t* neg, float* work,
+                                    float* acc, void* stream) {
   if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !f1 || !f2 || !work || !acc) return -1;
   int grid = (B + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(critic_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, B, D, work, acc),
-           hipLaunchKernelGGL(critic_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, B, D, work, acc));
+           hipLaunchKernelGGL(critic_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, B, D, neg, work, acc),
+           hipLaunchKernelGGL(critic_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, B, D, neg, work, acc));
   return (int)hipGetLastError();
 }
 extern "C" int clite_l2_normalize(int dtype, const void* x, void* out, int B, int D, void* stream) {
@@ -330,22 +357,23 @@ extern "C" int clite_l2_normalize_bwd(int dtype, const void* x, const void* y, c
   return (int)hipGetLastError();
 }
 extern "C" int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, const float* temperature, const float* work, const float* gout, float scale,
-                                    int B, int D, void* df1, void* df2, float* dtemp, void* stream) {
-  if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !f1 || !f2 || !work || !gout || !df1 || !df2) return -1;
+                                    int B, int D, const int32_t* neg, const int32_t* neg_inv, void* df1, void* df2, float* dtemp, void* stream) {
+  if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !f1 || !f2 || !work || !gout || !df1 || !df2 || (!neg) != (!neg_inv)) return -1;
   int grid = (B + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(critic_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, work, gout, scale, B, D, (bf16*)df1, (bf16*)df2, dtemp),
-           hipLaunchKernelGGL(critic_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, work, gout, scale, B, D, (float*)df1, (float*)df2, dtemp));
+           hipLaunchKernelGGL(critic_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, work, gout, scale, B, D, neg, neg_inv, (bf16*)df1, (bf16*)df2, dtemp),
+           hipLaunchKernelGGL(critic_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, work, gout, scale, B, D, neg, neg_inv, (float*)df1, (float*)df2, dtemp));
   return (int)hipGetLastError();
 }
-extern "C" int clite_prior_tail_fwd(int dtype, const void* h1, const float* w2, const float* b2, int B, int K, float* logit, float* acc, void* stream) {
+extern "C" int clite_prior_tail_fwd(int dtype, const void* h1, const float* w2, const float* b2, int B, int K, int softplus, float* logit, float* acc,
+                                    void* stream) {
   if (B <= 0 || K % 8 || !h1 || !w2 || !b2 || !logit || !acc) return -1;
   int grid = (2 * B + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(prior_tail_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)h1, w2, b2, B, K, logit, acc),
-           hipLaunchKernelGGL(prior_tail_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)h1, w2, b2, B, K, logit, acc));
+           hipLaunchKernelGGL(prior_tail_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)h1, w2, b2, B, K, softplus, logit, acc),
+           hipLaunchKernelGGL(prior_tail_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)h1, w2, b2, B, K, softplus, logit, acc));
   return (int)hipGetLastError();
 }
 extern "C" int clite_prior_tail_bwd(int dtype, const void* h1, const float* w2, const float* logit, const float* gout, float scale, int B, int K,
@@ -362,6 +390,16 @@ extern "C" int clite_prior_tail_bwd(int dtype, const void* h1, const float* w2, 
 extern "C" int clite_loss_finalize(const float* acc, float prior_weight, float* out, void* stream) {
   if (!acc || !out) return -1;
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, prior_weight, out);
+  return (int)hipGetLastError();
+}
+extern "C" int clite_add(int dtype, const void* a, const void* b, void* out, uint64_t n, void* stream) {
+  if (!a || !b || !out || n % 8) return -1;
+  size_t g = (n / 8 + 255) / 256;
+  int grid = (int)(g < 2048 ? (g ? g : 1) : 2048);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(add_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)out, (size_t)(n / 8)),
+           hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, (size_t)(n / 8)));
   return (int)hipGetLastError();
 }
 extern "C" int clite_uniform_fill(int dtype, void* out, uint64_t n, uint64_t seed, uint32_t site, void* stream) {

@@ -81,15 +81,16 @@ _SIGNATURES = {
     "clite_attention_fwd": [_I, _V, _V, _V, _I, _I, _I, _F, _U64, _U32, _V],
     "clite_attention_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _F, _U64, _U32, _V],
     "clite_tanh_bwd": [_I, _V, _V, _V, _U64, _V],
-    "clite_critic_jsd_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V],
+    "clite_critic_jsd_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V, _V],
     "clite_l2_normalize": [_I, _V, _V, _I, _I, _V],
     "clite_l2_normalize_bwd": [_I, _V, _V, _V, _V, _I, _I, _V],
     "clite_infonce_fwd": [_V, _I, _I, _V, _V, _V, _V, _V],
     "clite_infonce_bwd": [_I, _V, _I, _I, _V, _V, _V, _V, _F, _V, _I, _V, _V],
-    "clite_critic_jsd_bwd": [_I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V],
-    "clite_prior_tail_fwd": [_I, _V, _V, _V, _I, _I, _V, _V, _V],
+    "clite_critic_jsd_bwd": [_I, _V, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V, _V, _V],
+    "clite_prior_tail_fwd": [_I, _V, _V, _V, _I, _I, _I, _V, _V, _V],
     "clite_prior_tail_bwd": [_I, _V, _V, _V, _V, _F, _I, _I, _V, _V, _V, _V],
     "clite_loss_finalize": [_V, _F, _V, _V],
+    "clite_add": [_I, _V, _V, _V, _U64, _V],
     "clite_uniform_fill": [_I, _V, _U64, _U64, _U32, _V],
     "clite_sumsq": [_V, _U64, _V, _V],
     "clite_sgd_step": [_V, _V, _V, _V, _V, _V, _I, _V, _V, _V],
@@ -342,8 +343,8 @@ def tanh_bwd(dt, dy, y, out, n):
 
 
 # ------------------------------------------------------------------------------------------------ loss / update
-def critic_jsd_fwd(dt, f1, f2, temperature, B, D, work, acc):
-    check(lib().clite_critic_jsd_fwd(dt, p(f1), p(f2), p(temperature), B, D, p(work), p(acc), stream_ptr(f1)), "critic_jsd_fwd")
+def critic_jsd_fwd(dt, f1, f2, temperature, B, D, work, acc, neg=None):
+    check(lib().clite_critic_jsd_fwd(dt, p(f1), p(f2), p(temperature), B, D, p(neg), p(work), p(acc), stream_ptr(f1)), "critic_jsd_fwd")
 
 
 def l2_normalize(dt, x, out, B, D):
@@ -362,17 +363,22 @@ def infonce_bwd(dt, Cm, ld, B, temperature, lse_r, lse_c, gout, scale, dC, ldd, 
     check(lib().clite_infonce_bwd(dt, p(Cm), ld, B, p(temperature), p(lse_r), p(lse_c), p(gout), scale, p(dC), ldd, p(dtemp), stream_ptr(Cm)), "infonce_bwd")
 
 
-def critic_jsd_bwd(dt, f1, f2, temperature, work, gout, scale, B, D, df1, df2, dtemp):
-    check(lib().clite_critic_jsd_bwd(dt, p(f1), p(f2), p(temperature), p(work), p(gout), scale, B, D, p(df1), p(df2), p(dtemp), stream_ptr(f1)),
+def critic_jsd_bwd(dt, f1, f2, temperature, work, gout, scale, B, D, df1, df2, dtemp, neg=None, neg_inv=None):
+    check(lib().clite_critic_jsd_bwd(dt, p(f1), p(f2), p(temperature), p(work), p(gout), scale, B, D, p(neg), p(neg_inv), p(df1), p(df2), p(dtemp),
+                                     stream_ptr(f1)),
           "critic_jsd_bwd")
 
 
-def prior_tail_fwd(dt, h1, w2, b2, B, K, logit, acc):
-    check(lib().clite_prior_tail_fwd(dt, p(h1), p(w2), p(b2), B, K, p(logit), p(acc), stream_ptr(h1)), "prior_tail_fwd")
+def prior_tail_fwd(dt, h1, w2, b2, B, K, logit, acc, softplus=False):
+    check(lib().clite_prior_tail_fwd(dt, p(h1), p(w2), p(b2), B, K, int(softplus), p(logit), p(acc), stream_ptr(h1)), "prior_tail_fwd")
 
 
 def prior_tail_bwd(dt, h1, w2, logit, gout, scale, B, K, dh1, dw2, db2):
     check(lib().clite_prior_tail_bwd(dt, p(h1), p(w2), p(logit), p(gout), scale, B, K, p(dh1), p(dw2), p(db2), stream_ptr(h1)), "prior_tail_bwd")
+
+
+def add(dt, a, b, out):
+    check(lib().clite_add(dt, p(a), p(b), p(out), a.numel(), stream_ptr(a)), "add")
 
 
 def loss_finalize(acc, prior_weight, out):

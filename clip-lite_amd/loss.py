@@ -50,6 +50,17 @@ class PriorDiscriminator(nn.Module):
         self.sz = sz
 
 
+class GlobalDiscriminator(nn.Module):
+    """The `concat` critic (reference loss.py:56-68): l2(relu(l1(relu(l0(cat(features1, features2)))))), sz -> 512 -> 512 -> 1."""
+
+    def __init__(self, sz):
+        super().__init__()
+        self.l0 = LinearParams(sz, 512)
+        self.l1 = LinearParams(512, 512)
+        self.l2 = LinearParams(512, 1)
+        self.sz = sz
+
+
 class GlobalDiscriminatorDot(nn.Module):
     def __init__(self, image_sz, text_sz, units=2048, bln=True):
         super().__init__()
@@ -62,13 +73,18 @@ class JSDInfoMaxLoss(nn.Module):
     def __init__(self, image_dim=2048, text_dim=768, type="dot", prior_weight=0.1, image_prior=True, text_prior=False,
                  visual_self_supervised=False, textual_self_supervised=False):
         super().__init__()
-        if type != "dot":
-            raise NotImplementedError(f"critic type {type!r}: only the 'dot' critic (every shipped YAML) is built on the HIP path")
-        if visual_self_supervised or textual_self_supervised:
-            raise NotImplementedError("visual/textual self-supervised terms are outside the accelerated hot path")
+        if type not in ("dot", "concat", "condot", "dotcon"):
+            raise ValueError(f"critic type {type!r} (reference loss.py:129-169 knows dot, concat, condot, dotcon)")
         self.prior_weight, self.image_prior, self.text_prior = prior_weight, image_prior, text_prior
-        self.image_dim, self.text_dim = image_dim, text_dim
-        self.global_d = GlobalDiscriminatorDot(image_sz=image_dim, text_sz=text_dim)
+        self.image_dim, self.text_dim, self.type = image_dim, text_dim, type
+        # reference loss.py:129-169: `dot`/`dotcon` use the projection-head critic for the cross-modal term, `concat`/`condot` the MLP on the
+        # concatenated features; the self-supervised critics are of the dot kind for `dot`/`condot`, of the concat kind otherwise
+        cross_dot, ssl_dot = type in ("dot", "dotcon"), type in ("dot", "condot")
+        self.global_d = GlobalDiscriminatorDot(image_sz=image_dim, text_sz=text_dim) if cross_dot else GlobalDiscriminator(image_dim + text_dim)
+        if visual_self_supervised:
+            self.visual_d = GlobalDiscriminatorDot(image_sz=image_dim, text_sz=image_dim) if ssl_dot else GlobalDiscriminator(2 * image_dim)
+        if textual_self_supervised:
+            self.textual_d = GlobalDiscriminatorDot(image_sz=text_dim, text_sz=text_dim) if ssl_dot else GlobalDiscriminator(2 * text_dim)
         if image_prior:
             self.prior_d = PriorDiscriminator(sz=image_dim)
         if text_prior:
@@ -82,12 +98,20 @@ class JSDInfoMaxLoss(nn.Module):
 
     def forward(self, image_features, text_features, neg_image_features=None, neg_text_features=None,
                 aug_image_features=None, aug_text_features=None):
-        if any(t is not None for t in (neg_image_features, neg_text_features, aug_image_features, aug_text_features)):
-            raise NotImplementedError("cluster negatives / augmented views are outside the accelerated hot path")
         rt = _runtime_of(self)
-        total, comps = _JSDLossFn.apply(image_features, text_features, self, rt, rt.next_step(self.training))
-        zero = comps[3]
-        return {"total_loss": total, "cross_modal_loss": comps[1], "visual_loss": zero, "textual_loss": zero}
+        extras = (neg_image_features, neg_text_features, aug_image_features, aug_text_features)
+        if all(t is None for t in extras) and isinstance(self.global_d, GlobalDiscriminatorDot):
+            # every shipped YAML: dot critic, in-batch negatives, no augmented views — the path the captured train step replays
+            total, comps = _JSDLossFn.apply(image_features, text_features, self, rt, rt.next_step(self.training))
+        else:
+            if getattr(self, "estimator", "jsd") != "jsd":
+                raise NotImplementedError("InfoNCELoss is defined for the dot critic with in-batch negatives only")
+            if (neg_image_features is None) != (neg_text_features is None):
+                raise ValueError("cluster mode needs both neg_image_features and neg_text_features (reference loss.py:225-252)")
+            present = [t is not None for t in extras]
+            args = [t if t is not None else image_features.new_zeros(()) for t in extras]
+            total, comps = _JSDGeneralFn.apply(image_features, text_features, *args, present, self, rt, rt.next_step(self.training))
+        return {"total_loss": total, "cross_modal_loss": comps[1], "visual_loss": comps[3], "textual_loss": comps[4]}
 
 
 class InfoNCELoss(JSDInfoMaxLoss):
@@ -185,31 +209,50 @@ def prior_forward(rt, pd, feat, noise, acc_slot, step, site):
     else:
         hip.uniform_fill(dt, x2, B * sz, step.seed, site)
     x2[B:].copy_(feat)
-    h0 = _alloc(rt, 2 * B, 1000)
-    hip.gemm_nt(dt, x2, A.w(pd.l0.weight), 2 * B, 1000, sz, hip.epilogue(h0, 1000, bias=pd.l0.bias, act=hip.ACT_RELU))
-    h1 = _alloc(rt, 2 * B, 200)
-    hip.gemm_nt(dt, h0, A.w(pd.l1.weight), 2 * B, 200, 1000, hip.epilogue(h1, 200, bias=pd.l1.bias, act=hip.ACT_RELU))
-    logit = torch.empty(2 * B, device=rt.device, dtype=torch.float32)
-    hip.prior_tail_fwd(dt, h1, pd.l2.weight, pd.l2.bias, B, 200, logit, acc_slot)
+    return _mlp_tail_forward(rt, pd, x2, B, acc_slot, softplus=False)
+
+
+def _mlp_tail_forward(rt, net, x2, half, acc_slot, softplus):
+    """x2 [2*half][sz] -> relu(l0) -> relu(l1) -> l2 logits; acc_slot += mean softplus(-logit[:half]) + mean softplus(logit[half:]).
+    Shared by PriorDiscriminator (sz -> 1000 -> 200 -> 1; rows = [noise; features]) and the concat critic GlobalDiscriminator
+    (sz -> 512 -> 512 -> 1; rows = [positive pairs; negative pairs])."""
+    dt, A = rt.dt, rt.arena
+    R, sz = x2.shape
+    n0, n1 = net.l0.weight.shape[0], net.l1.weight.shape[0]
+    h0 = _alloc(rt, R, n0)
+    hip.gemm_nt(dt, x2, A.w(net.l0.weight), R, n0, sz, hip.epilogue(h0, n0, bias=net.l0.bias, act=hip.ACT_RELU))
+    h1 = _alloc(rt, R, n1)
+    hip.gemm_nt(dt, h0, A.w(net.l1.weight), R, n1, n0, hip.epilogue(h1, n1, bias=net.l1.bias, act=hip.ACT_RELU))
+    logit = torch.empty(R, device=rt.device, dtype=torch.float32)
+    hip.prior_tail_fwd(dt, h1, net.l2.weight, net.l2.bias, half, n1, logit, acc_slot, softplus=softplus)
     return (x2, h0, h1, logit)
+
+
+def _mlp_tail_backward(rt, net, ctx, gout, scale):
+    """Parameter gradients of the three layers into the arena; returns dh0 [2*half][n0] (gradient at l0's pre-activation)."""
+    from .bert import _linear_grads
+    dt, A = rt.dt, rt.arena
+    x2, h0, h1, logit = ctx
+    R = x2.shape[0]
+    n0, n1 = net.l0.weight.shape[0], net.l1.weight.shape[0]
+    dh1 = _alloc(rt, R, n1)
+    hip.prior_tail_bwd(dt, h1, net.l2.weight, logit, gout, scale, R // 2, n1, dh1, A.g(net.l2.weight), A.g(net.l2.bias))
+    _linear_grads(rt, net.l1, dh1, h0, R)
+    dh0 = _alloc(rt, R, n0)
+    hip.gemm_nn(dt, dh1, A.w(net.l1.weight), R, n0, n1, hip.epilogue(dh0, n0, dact_aux=h0, dact=hip.DACT_RELU))
+    _linear_grads(rt, net.l0, dh0, x2, R)
+    return dh0
 
 
 def prior_backward(rt, pd, ctx, gout, scale, dfeat_residual):
     """Returns d(feat) [B][sz] + dfeat_residual."""
-    from .bert import _linear_grads
     dt, A = rt.dt, rt.arena
-    x2, h0, h1, logit = ctx
-    B2, sz = x2.shape
+    B2, sz = ctx[0].shape
     B = B2 // 2
-    dh1 = _alloc(rt, B2, 200)
-    hip.prior_tail_bwd(dt, h1, pd.l2.weight, logit, gout, scale, B, 200, dh1, A.g(pd.l2.weight), A.g(pd.l2.bias))
-    _linear_grads(rt, pd.l1, dh1, h0, B2)
-    dh0 = _alloc(rt, B2, 1000)
-    hip.gemm_nn(dt, dh1, A.w(pd.l1.weight), B2, 1000, 200, hip.epilogue(dh0, 1000, dact_aux=h0, dact=hip.DACT_RELU))
-    _linear_grads(rt, pd.l0, dh0, x2, B2)
+    dh0 = _mlp_tail_backward(rt, pd, ctx, gout, scale)
     dfeat = _alloc(rt, B, sz)
     # only the feature rows (B..2B) need an input gradient; the noise rows have none
-    hip.gemm_nn(dt, dh0[B:], A.w(pd.l0.weight), B, sz, 1000, hip.epilogue(dfeat, sz, residual=dfeat_residual))
+    hip.gemm_nn(dt, dh0[B:], A.w(pd.l0.weight), B, sz, dh0.shape[1], hip.epilogue(dfeat, sz, residual=dfeat_residual))
     return dfeat
 
 
@@ -221,7 +264,7 @@ def jsd_forward(rt, mod, img, txt, step):
     img = img.to(rt.tdtype).contiguous()
     txt = txt.to(rt.tdtype).contiguous()
     B = img.shape[0]
-    acc = torch.zeros(4, device=rt.device, dtype=torch.float32)
+    acc = torch.zeros(8, device=rt.device, dtype=torch.float32)
     noise = mod._noise or (None, None)
     pctx_i = pctx_t = None
     if mod.image_prior:
@@ -248,7 +291,7 @@ def jsd_forward(rt, mod, img, txt, step):
     else:
         work = torch.empty(B, 8, device=rt.device, dtype=torch.float32)
         hip.critic_jsd_fwd(dt, f1, f2, gd.temperature, B, U, work, acc)
-    out = torch.empty(4, device=rt.device, dtype=torch.float32)
+    out = torch.empty(8, device=rt.device, dtype=torch.float32)
     hip.loss_finalize(acc, mod.prior_weight, out)
     return out, (f1, f2, c1, c2, work, pctx_i, pctx_t, B)
 
@@ -297,3 +340,158 @@ class _JSDLossFn(torch.autograd.Function):
         gout = gtotal.to(torch.float32).contiguous().view(1)
         dimg, dtxt = jsd_backward(ctx.rt, ctx.mod, ctx.saved, gout)
         return dimg.to(ctx.in_dtypes[0]), dtxt.to(ctx.in_dtypes[1]), None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------- general form
+# Critic types concat / condot / dotcon (reference loss.py:129-169), the cluster hard-negative branch (:225-252) and the visual / textual
+# self-supervised terms (:256-300). Eager launches only: these forms call the encoders several times per step, which the captured
+# train step does not model.
+def _neg_perm(rt, rows, cluster):
+    """(neg, neg_inv) int32 device tensors for the critic kernels, or (None, None) for roll-by-one. Cluster mode stacks
+    [batch (B rows); hard negatives (B rows)]: row i < B is paired with its hard negative B + i, row B + i with caption (i + 1) mod B
+    (reference loss.py:236-246)."""
+    if not cluster:
+        return None, None
+    cache = rt.__dict__.setdefault("_neg_perm_cache", {})
+    if rows not in cache:
+        half = rows // 2
+        i = torch.arange(half)
+        neg = torch.cat((i + half, (i + 1) % half)).to(torch.int32)
+        inv = torch.empty(rows, dtype=torch.int32)
+        inv[neg.long()] = torch.arange(rows, dtype=torch.int32)
+        cache[rows] = (neg.to(rt.device), inv.to(rt.device))
+    return cache[rows]
+
+
+def _take_rows(t, index):
+    """t[index] (a row gather = data movement only); index None = roll by one: out[i] = t[(i + 1) mod n]."""
+    if index is None:
+        return torch.cat((t[1:], t[:1]), dim=0)
+    return t.index_select(0, index.long())
+
+
+def _put_rows_back(t, index_inv):
+    """Inverse of _take_rows: out[j] = t[i] where j = index[i]."""
+    if index_inv is None:
+        return torch.cat((t[-1:], t[:-1]), dim=0)
+    return t.index_select(0, index_inv.long())
+
+
+def _pair_forward(rt, critic, f1, f2, perm, acc2, training):
+    """One (positive, negative) critic evaluation: acc2[0] += mean softplus(-critic(f1, f2)), acc2[1] += mean softplus(critic(f1, f2[neg]))."""
+    dt = rt.dt
+    neg, _ = perm
+    R = f1.shape[0]
+    if isinstance(critic, GlobalDiscriminatorDot):
+        p1, c1 = mi_block_forward(rt, critic.img_block, f1, training)
+        p2, c2 = mi_block_forward(rt, critic.text_block, f2, training)
+        if training:      # the reference runs each block twice per step (positives, negatives): running stats and counters advance twice
+            for blk in (critic.img_block, critic.text_block):
+                blk.feature_nonlinear[1]._buffers["num_batches_tracked"] += 2
+        work = torch.empty(R, 8, device=rt.device, dtype=torch.float32)
+        hip.critic_jsd_fwd(dt, p1, p2, critic.temperature, R, critic.img_block.units, work, acc2, neg=neg)
+        return ("dot", p1, p2, c1, c2, work)
+    x2 = torch.cat((torch.cat((f1, f2), dim=1), torch.cat((f1, _take_rows(f2, neg)), dim=1)), dim=0).contiguous()
+    return ("concat", _mlp_tail_forward(rt, critic, x2, R, acc2, softplus=True), f1.shape[1])
+
+
+def _pair_backward(rt, critic, saved, perm, gout, scale):
+    """-> (d f1, d f2); parameter gradients accumulate into the arena."""
+    dt, A = rt.dt, rt.arena
+    neg, neg_inv = perm
+    if saved[0] == "dot":
+        _, p1, p2, c1, c2, work = saved
+        R, U = p1.shape
+        dp1, dp2 = _alloc(rt, R, U), _alloc(rt, R, U)
+        hip.critic_jsd_bwd(dt, p1, p2, critic.temperature, work, gout, scale, R, U, dp1, dp2, A.g(critic.temperature).view(1), neg=neg, neg_inv=neg_inv)
+        return mi_block_backward(rt, critic.img_block, c1, dp1), mi_block_backward(rt, critic.text_block, c2, dp2)
+    _, ctx, d1 = saved
+    R2, sz = ctx[0].shape
+    R, d2 = R2 // 2, sz - d1
+    dh0 = _mlp_tail_backward(rt, critic, ctx, gout, scale)
+    n0 = dh0.shape[1]
+    w0 = A.w(critic.l0.weight)                       # [n0][d1 + d2]: column blocks address the two concatenated inputs
+    df1a, df1 = _alloc(rt, R, d1), _alloc(rt, R, d1)
+    hip.gemm_nn(dt, dh0[:R], w0, R, d1, n0, hip.epilogue(df1a, d1), ldb=sz)
+    hip.gemm_nn(dt, dh0[R:], w0, R, d1, n0, hip.epilogue(df1, d1, residual=df1a), ldb=sz)
+    w0b = w0[:, d1:]
+    dneg = _alloc(rt, R, d2)
+    hip.gemm_nn(dt, dh0[R:], w0b, R, d2, n0, hip.epilogue(dneg, d2), ldb=sz)
+    df2 = _alloc(rt, R, d2)
+    hip.gemm_nn(dt, dh0[:R], w0b, R, d2, n0, hip.epilogue(df2, d2, residual=_put_rows_back(dneg, neg_inv).contiguous()), ldb=sz)
+    return df1, df2
+
+
+def _sum(rt, a, b):
+    if a is None:
+        return b
+    if b is None:
+        return a
+    out = torch.empty_like(a)
+    hip.add(rt.dt, a.contiguous(), b.contiguous(), out)
+    return out
+
+
+def jsd_general_forward(rt, mod, img, txt, nimg, ntxt, aimg, atxt, step):
+    training = step.training
+    cast = lambda t: None if t is None else t.to(rt.tdtype).contiguous()
+    img, txt, nimg, ntxt, aimg, atxt = (cast(t) for t in (img, txt, nimg, ntxt, aimg, atxt))
+    B = img.shape[0]
+    acc = torch.zeros(8, device=rt.device, dtype=torch.float32)
+    noise = mod._noise or (None, None)
+    pctx_i = prior_forward(rt, mod.prior_d, img, noise[0], acc[2:3], step, step.site()) if mod.image_prior else None
+    pctx_t = prior_forward(rt, mod.text_prior_d, txt, noise[1], acc[3:4], step, step.site()) if mod.text_prior else None
+    cluster = ntxt is not None
+    if cluster:
+        f1, f2 = torch.cat((img, nimg), dim=0).contiguous(), torch.cat((txt, ntxt), dim=0).contiguous()
+    else:
+        f1, f2 = img, txt
+    perm = _neg_perm(rt, f1.shape[0], cluster)
+    cross = _pair_forward(rt, mod.global_d, f1, f2, perm, acc[0:2], training)
+    # reference loss.py:236-238 re-binds text_features to the rolled captions in cluster mode; the textual SSL term then pairs those
+    txt_ssl = _take_rows(txt, None).contiguous() if cluster else txt
+    vis = _pair_forward(rt, mod.visual_d, img, aimg, (None, None), acc[4:6], training) if aimg is not None else None
+    tex = _pair_forward(rt, mod.textual_d, txt_ssl, atxt, (None, None), acc[6:8], training) if atxt is not None else None
+    out = torch.empty(8, device=rt.device, dtype=torch.float32)
+    hip.loss_finalize(acc, mod.prior_weight, out)
+    return out, (cross, vis, tex, perm, pctx_i, pctx_t, B, cluster)
+
+
+def jsd_general_backward(rt, mod, saved, gout):
+    """-> gradients w.r.t. (img, txt, nimg, ntxt, aimg, atxt), None where the input was absent."""
+    cross, vis, tex, perm, pctx_i, pctx_t, B, cluster = saved
+    s = 1.0 - mod.prior_weight
+    d1, d2 = _pair_backward(rt, mod.global_d, cross, perm, gout, s)
+    dimg, dtxt, dnimg, dntxt = (d1[:B], d2[:B], d1[B:], d2[B:]) if cluster else (d1, d2, None, None)
+    daimg = datxt = None
+    if vis is not None:
+        dv1, daimg = _pair_backward(rt, mod.visual_d, vis, (None, None), gout, s)
+        dimg = _sum(rt, dimg, dv1)
+    if tex is not None:
+        dt1, datxt = _pair_backward(rt, mod.textual_d, tex, (None, None), gout, s)
+        dtxt = _sum(rt, dtxt, _put_rows_back(dt1, None) if cluster else dt1)
+    if pctx_i is not None:
+        dimg = prior_backward(rt, mod.prior_d, pctx_i, gout, mod.prior_weight, dimg.contiguous())
+    if pctx_t is not None:
+        dtxt = prior_backward(rt, mod.text_prior_d, pctx_t, gout, mod.prior_weight, dtxt.contiguous())
+    rt.join_aux()
+    rt.grads_ready(mod)
+    return dimg, dtxt, dnimg, dntxt, daimg, datxt
+
+
+class _JSDGeneralFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, txt, nimg, ntxt, aimg, atxt, present, mod, rt, step):
+        ins = [img, txt] + [t if ok else None for t, ok in zip((nimg, ntxt, aimg, atxt), present)]
+        out, saved = jsd_general_forward(rt, mod, *ins, step)
+        ctx.mod, ctx.rt, ctx.saved = mod, rt, saved
+        ctx.in_dtypes = [None if t is None else t.dtype for t in ins]
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, gtotal, _gcomps):
+        gout = gtotal.to(torch.float32).contiguous().view(1)
+        grads = jsd_general_backward(ctx.rt, ctx.mod, ctx.saved, gout)
+        outs = tuple(None if (g is None or d is None) else g.to(d) for g, d in zip(grads, ctx.in_dtypes))
+        return outs + (None, None, None, None)

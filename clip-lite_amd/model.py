@@ -64,8 +64,14 @@ class VLInfoModel(nn.Module):
             image_features = self.image_encoder(batch["image"])
             text_features = self.text_encoder(batch["caption_encodings"])
         elif self.mode == "train_sbert":
-            if any(k in batch for k in ("neg_input_ids", "aug_image", "aug_input_ids")):
-                raise NotImplementedError("negative / augmented branches (reference model.py:61-92) are outside the accelerated hot path")
+            extra = any(k in batch for k in ("neg_input_ids", "aug_image", "aug_input_ids"))
+            ex = getattr(rt, "exchange", None)
+            if ex is not None:
+                # with hard negatives / augmented views each encoder runs several times per step, so "this module's gradients are final"
+                # only holds after the last backward: the exchange then reduces the whole arena at the end of the step instead
+                ex.defer = extra
+            if extra:
+                return self._forward_with_extras(batch)
             # The two encoders are independent until the loss: the text encoder is enqueued on a second HIP stream so its
             # (small-grid, latency-bound) BERT kernels share the chip with the ResNet's. Autograd replays each backward on the
             # stream its forward ran on, so the two backward passes overlap the same way; under graph capture the fork/join
@@ -86,6 +92,29 @@ class VLInfoModel(nn.Module):
         else:
             raise NotImplementedError(f"mode {self.mode!r}")
         loss_dict = self.loss(image_features=image_features, text_features=text_features)
+        return self._output(loss_dict)
+
+    def _forward_with_extras(self, batch):
+        """reference model.py:61-92: hard negatives from the clustered dataset (`neg_image`, `neg_input_ids`, `neg_attention_mask`) and
+        augmented views (`aug_image`; `aug_input_ids`, `aug_attention_mask`) go through the same encoders — separate calls, so separate
+        BatchNorm batch statistics and running-stat updates per call, as in the reference — and on into the loss."""
+        enc_t = lambda ids, mask: self.text_encoder({"input_ids": batch[ids], "attention_mask": batch[mask]})
+        image_features = self.image_encoder(batch["image"])
+        text_features = enc_t("input_ids", "attention_mask")
+        neg_image = neg_text = aug_image = aug_text = None
+        if "neg_input_ids" in batch:
+            neg_image = self.image_encoder(batch["neg_image"])
+            neg_text = enc_t("neg_input_ids", "neg_attention_mask")
+        if "aug_image" in batch:
+            aug_image = self.image_encoder(batch["aug_image"])
+        if "aug_input_ids" in batch:
+            aug_text = enc_t("aug_input_ids", "aug_attention_mask")
+        loss_dict = self.loss(image_features=image_features, text_features=text_features, neg_image_features=neg_image, neg_text_features=neg_text,
+                              aug_image_features=aug_image, aug_text_features=aug_text)
+        return self._output(loss_dict)
+
+    @staticmethod
+    def _output(loss_dict):
         return {
             "loss": loss_dict["total_loss"],
             "loss_components": {

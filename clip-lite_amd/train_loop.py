@@ -104,12 +104,14 @@ class TrainStep:
     # and every tensor that crosses a stream (features, their gradients) is kept referenced for the lifetime of the graphs.
     def _direct_ok(self):
         m = self.model
+        from .loss import GlobalDiscriminatorDot
         return (getattr(m, "mode", None) == "train_sbert" and not m.text_encoder.transform_embedding and m.training
+                and isinstance(m.loss.global_d, GlobalDiscriminatorDot)
                 and not getattr(m.image_encoder, "frozen", False)
                 and all(p.requires_grad for p in m.parameters()))
 
     def _capture(self, batch):
-        if not self._direct_ok():
+        if not self._direct_ok() or any(k in batch for k in ("neg_input_ids", "aug_image", "aug_input_ids")):
             return self._capture_single(batch)
         from .bert import bert_backward, bert_forward
         from .loss import jsd_backward, jsd_forward
@@ -146,7 +148,7 @@ class TrainStep:
             keep["dimg"], keep["dtxt"] = jsd_backward(rt, m.loss, saved, keep["gout"])
             keep["loss_saved"] = saved
             keep["result"] = {"loss": out[0].clone(), "loss_components": {"total_loss": out[0].clone(), "cross_modal_loss": out[1].clone(),
-                                                                          "visual_loss": out[3].clone(), "textual_loss": out[3].clone()}}
+                                                                          "visual_loss": out[3].clone(), "textual_loss": out[4].clone()}}
 
         def image_bwd():
             resnet_backward(rt, m.image_encoder.img_encoder, keep["ctx_i"], keep["dimg"].contiguous())

@@ -113,6 +113,7 @@ class GradientExchange:
         self._pending = []      # [lo, hi) regions not yet sent
         self._works = []
         self._covered = []     # [lo, hi) regions already handed to RCCL this step
+        self.defer = False     # True: ignore region_ready (modules run several times per step); finish() reduces the whole arena
 
     def _send(self, lo, hi):
         buf = self.arena.flat_g[lo:hi]
@@ -125,7 +126,7 @@ class GradientExchange:
         self._covered.append((lo, hi))
 
     def region_ready(self, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if self.world == 1 or hi <= lo or self.defer:
             return
         # merge with an adjacent pending region when possible
         if self._pending and self._pending[-1][0] == hi:

@@ -186,10 +186,13 @@ int clite_attention_bwd(int dtype, const void* qkv, const int64_t* mask, const v
 int clite_tanh_bwd(int dtype, const void* dy, const void* y, void* out, uint64_t n, void* stream);
 
 /* ---- JSD mutual-information loss (reference loss.py). f1 = img_block(image_features), f2 = text_block(text_features),
- * both [B][D], D % 8 == 0, D <= 2048. Negatives are roll-by-one inside the batch: pair (n, n+1 mod B) (loss.py:214-216).
- * work: f32 [B][8] per-sample scratch kept for backward. acc: f32 [4] accumulators, pre-zeroed:
- *   acc[0] += mean softplus(-o+) (= -Ej), acc[1] += mean softplus(o-) (= Em), acc[2]/acc[3]: image/text prior terms. */
-int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, const float* temperature, int B, int D, float* work, float* acc, void* stream);
+ * both [B][D], D % 8 == 0, D <= 2048. neg = NULL: negatives are roll-by-one inside the batch, pair (n, n+1 mod B) (loss.py:214-216);
+ * otherwise neg[n] (int32, a permutation of 0..B-1) is the row of f2 paired with row n — the cluster hard-negative branch (loss.py:225-252)
+ * stacks [batch; hard negatives] and pairs [B/2 + i | (i+1) mod B/2].
+ * work: f32 [B][8] per-sample scratch kept for backward. acc: f32 [2] of the step's 8 pre-zeroed accumulators
+ * (clite_loss_finalize): acc[0] += mean softplus(-o+) (= -Ej), acc[1] += mean softplus(o-) (= Em). */
+int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, const float* temperature, int B, int D, const int32_t* neg, float* work,
+                         float* acc, void* stream);
 /* out[n] = x[n] / max(||x[n]||_2, 1e-12): F.normalize(p=2, dim=-1) of the embedding-extraction / retrieval path that consumes the trained
  * projection heads (reference retrieval.py:108,127; zero_shot.py). [B][D], D % 8 == 0, D <= 2048. */
 int clite_l2_normalize(int dtype, const void* x, void* out, int B, int D, void* stream);
@@ -202,17 +205,26 @@ int clite_infonce_fwd(const float* C, int ld, int B, const float* temperature, f
 /* dC (call dtype, [B][ldd], ldd % 8 == 0, padding columns zeroed) = dL/dC; dtemp (f32 scalar) += ; scale = (1 - prior_weight). */
 int clite_infonce_bwd(int dtype, const float* C, int ld, int B, const float* temperature, const float* lse_r, const float* lse_c,
                       const float* gout, float scale, void* dC, int ldd, float* dtemp, void* stream);
-/* gout: device scalar dL/d(total); scale = (1 - prior_weight). df1/df2 in dtype; dtemp (f32 scalar) += . */
+/* gout: device scalar dL/d(total); scale = (1 - prior_weight). df1/df2 in dtype; dtemp (f32 scalar) += . neg as in the forward call,
+ * neg_inv its inverse permutation (both NULL = roll by one). */
 int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, const float* temperature, const float* work, const float* gout, float scale,
-                         int B, int D, void* df1, void* df2, float* dtemp, void* stream);
+                         int B, int D, const int32_t* neg, const int32_t* neg_inv, void* df1, void* df2, float* dtemp, void* stream);
 /* PriorDiscriminator.l2 + sigmoid + log terms (loss.py:49-53,189-193) on h1 = relu(l1(relu(l0([u; f])))) stacked [2B][K]:
- * acc += -(mean log D(u) + mean log(1 - D(f))). K % 8 == 0. logit: f32 [2B] kept for backward. */
-int clite_prior_tail_fwd(int dtype, const void* h1, const float* w2, const float* b2, int B, int K, float* logit, float* acc, void* stream);
+ * acc += -(mean log D(u) + mean log(1 - D(f))), evaluated as the reference does (log of the f32 sigmoid) when softplus = 0. K % 8 == 0.
+ * logit: f32 [2B] kept for backward. With softplus = 1 the same pair of calls is the tail of the `concat` critic GlobalDiscriminator
+ * (loss.py:56-68,206-222): rows [0,B) = logits of the positive pairs, acc += mean softplus(-o) (= -Ej); rows [B,2B) = negative pairs,
+ * acc += mean softplus(o) (= Em); K = 512. The two forms have the same derivative (clite_prior_tail_bwd). */
+int clite_prior_tail_fwd(int dtype, const void* h1, const float* w2, const float* b2, int B, int K, int softplus, float* logit, float* acc,
+                         void* stream);
 /* dh1 = gradient w.r.t. l1's pre-activation (ReLU mask applied); dw2/db2 (f32) += ; scale = prior_weight. */
 int clite_prior_tail_bwd(int dtype, const void* h1, const float* w2, const float* logit, const float* gout, float scale, int B, int K,
                          void* dh1, float* dw2, float* db2, void* stream);
-/* out[0] = (1-w)*cross + w*prior (loss.py:302-305), out[1] = cross = Em - Ej, out[2] = prior, out[3] = 0 */
+/* acc: f32 [8] = [-Ej, Em | image prior, text prior | visual SSL -Ej, Em | textual SSL -Ej, Em] (loss.py:256-300 for the SSL terms).
+ * out: f32 [8]: out[0] = (1-w)*(cross + visual + textual) + w*prior (loss.py:302-305), out[1] = cross = Em - Ej, out[2] = prior,
+ * out[3] = visual, out[4] = textual, rest 0. */
 int clite_loss_finalize(const float* acc, float prior_weight, float* out, void* stream);
+/* out = a + b, n % 8 == 0 elements of `dtype`: feature gradients that arrive from several loss terms (cross-modal + SSL + prior). */
+int clite_add(int dtype, const void* a, const void* b, void* out, uint64_t n, void* stream);
 /* torch.rand_like replacement for the prior noise (loss.py:189,196): U[0,1) from Philox(seed, site, index). n % 8 == 0. */
 int clite_uniform_fill(int dtype, void* out, uint64_t n, uint64_t seed, uint32_t site, void* stream);
 

@@ -394,7 +394,7 @@ class OracleJSDInfoMaxLoss(nn.Module):
 
 
 class OracleVLInfoModel(nn.Module):
-    """model.py:15-113 (modes "sbert" and "train_sbert", no negative/augmented branches)"""
+    """model.py:15-113 (modes "sbert" and "train_sbert"; hard-negative and augmented-view branches :61-92)"""
 
     def __init__(self, text_encoder, image_encoder, loss, mode="sbert", is_amp=False):
         super().__init__()
@@ -406,20 +406,31 @@ class OracleVLInfoModel(nn.Module):
             text_features = self.text_encoder(batch["caption_encodings"])
         else:
             text_features = self.text_encoder({"input_ids": batch["input_ids"], "attention_mask": batch["attention_mask"]})
-        d = self.loss(image_features, text_features)
+        extra = {}
+        if self.mode != "sbert":
+            enc_t = lambda i, m: self.text_encoder({"input_ids": batch[i], "attention_mask": batch[m]})
+            if "neg_input_ids" in batch:
+                extra["neg_image_features"] = self.image_encoder(batch["neg_image"])
+                extra["neg_text_features"] = enc_t("neg_input_ids", "neg_attention_mask")
+            if "aug_image" in batch:
+                extra["aug_image_features"] = self.image_encoder(batch["aug_image"])
+            if "aug_input_ids" in batch:
+                extra["aug_text_features"] = enc_t("aug_input_ids", "aug_attention_mask")
+        d = self.loss(image_features, text_features, **extra)
         return {"loss": d["total_loss"], "loss_components": {k: v.clone().detach() for k, v in d.items()},
                 "image_features": image_features, "text_features": text_features}
 
 
 def build_oracle_model(visual="resnet50", textual="train_sbert", num_hidden_layers=12, image_dim=None, text_dim=768,
-                       image_prior=True, text_prior=True, prior_weight=0.1, dropout=0.1):
+                       image_prior=True, text_prior=True, prior_weight=0.1, dropout=0.1, critic="dot", visual_ssl=False, textual_ssl=False):
     ie = OracleImageEncoder(visual)
     te = OracleTextEncoder(mode=textual, num_hidden_layers=num_hidden_layers)
     if textual == "train_sbert" and dropout != 0.1:
         for m in te.modules():
             if isinstance(m, nn.Dropout):
                 m.p = dropout
-    loss = OracleJSDInfoMaxLoss(image_dim or ie.img_encoder.out_dim, text_dim, "dot", prior_weight, image_prior, text_prior)
+    loss = OracleJSDInfoMaxLoss(image_dim or ie.img_encoder.out_dim, text_dim, critic, prior_weight, image_prior, text_prior,
+                                visual_self_supervised=visual_ssl, textual_self_supervised=textual_ssl)
     return OracleVLInfoModel(te, ie, loss, textual)
 
 

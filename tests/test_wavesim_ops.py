@@ -244,12 +244,20 @@ def _softplus(x):
     return np.where(x > 20, x, np.log1p(np.exp(np.minimum(x, 20))))
 
 
+@pytest.mark.parametrize("cluster", [False, True])
 @pytest.mark.parametrize("dtype", [BF16, F32])
-def test_critic_jsd_fwd_bwd(dtype):
+def test_critic_jsd_fwd_bwd(dtype, cluster):
     """Against a numpy restatement of GlobalDiscriminatorDot + the JSD estimator (reference loss.py:84-107,206-222,254)
-    with central finite differences for the gradient."""
+    with central finite differences for the gradient. cluster: the negative pairing of the hard-negative branch (loss.py:225-252)
+    passed as an index permutation instead of roll-by-one."""
     rng = np.random.default_rng(11)
     B, D = 6, 128
+    half = B // 2
+    negidx = np.concatenate([np.arange(half) + half, (np.arange(half) + 1) % half]).astype(np.int32) if cluster else None
+    neginv = None
+    if cluster:
+        neginv = np.empty(B, np.int32)
+        neginv[negidx] = np.arange(B, dtype=np.int32)
     f1, f1b = prep(rng.standard_normal((B, D), dtype=np.float32), dtype)
     f2, f2b = prep(rng.standard_normal((B, D), dtype=np.float32), dtype)
     temp = np.array([np.log(1 / 0.07)], np.float32)
@@ -257,18 +265,21 @@ def test_critic_jsd_fwd_bwd(dtype):
     def loss(a, b, t):
         a = a.astype(np.float64); b = b.astype(np.float64)
         an = a / np.linalg.norm(a, axis=1, keepdims=True); bn = b / np.linalg.norm(b, axis=1, keepdims=True)
-        op = (an * bn).sum(1) * np.exp(t); on = (an * np.roll(bn, -1, 0)).sum(1) * np.exp(t)
+        op = (an * bn).sum(1) * np.exp(t); on = (an * (bn[negidx] if cluster else np.roll(bn, -1, 0))).sum(1) * np.exp(t)
         return _softplus(-op).mean(), _softplus(on).mean()
 
     L = lib()
-    L.clite_critic_jsd_bwd.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4
-    work = np.zeros((B, 8), np.float32); acc = np.zeros(4, np.float32)
-    assert L.clite_critic_jsd_fwd(dtype, ptr(f1b), ptr(f2b), ptr(temp), B, D, ptr(work), ptr(acc), None) == 0
+    L.clite_critic_jsd_fwd.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4
+    L.clite_critic_jsd_bwd.argtypes = [C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 6
+    work = np.zeros((B, 8), np.float32); acc = np.zeros(8, np.float32)
+    optr = lambda a: None if a is None else ptr(a)
+    assert L.clite_critic_jsd_fwd(dtype, ptr(f1b), ptr(f2b), ptr(temp), B, D, optr(negidx), ptr(work), ptr(acc), None) == 0
     l0, l1 = loss(f1, f2, float(temp[0]))
     assert abs(acc[0] - l0) < 1e-5 and abs(acc[1] - l1) < 1e-5
     gout = np.array([1.7], np.float32)
     df1 = outbuf((B, D), dtype); df2 = outbuf((B, D), dtype); dt = np.zeros(1, np.float32)
-    assert L.clite_critic_jsd_bwd(dtype, ptr(f1b), ptr(f2b), ptr(temp), ptr(work), ptr(gout), 0.9, B, D, ptr(df1), ptr(df2), ptr(dt), None) == 0
+    assert L.clite_critic_jsd_bwd(dtype, ptr(f1b), ptr(f2b), ptr(temp), ptr(work), ptr(gout), 0.9, B, D, optr(negidx), optr(neginv), ptr(df1), ptr(df2),
+                                  ptr(dt), None) == 0
     tot = lambda a, b, t: 1.7 * 0.9 * sum(loss(a, b, t))
     eps = 1e-3
     for (i, j) in [(0, 0), (2, 5), (5, 127), (3, 64)]:
@@ -289,14 +300,17 @@ def test_prior_tail_and_finalize(dtype):
     B, K = 5, 200
     h1, hb = prep(np.maximum(rng.standard_normal((2 * B, K), dtype=np.float32), 0), dtype)
     w2 = (rng.standard_normal(K) * 0.1).astype(np.float32); b2 = np.array([0.05], np.float32)
-    logit = np.zeros(2 * B, np.float32); acc = np.zeros(4, np.float32)
+    logit = np.zeros(2 * B, np.float32); acc = np.zeros(8, np.float32)
     L = lib()
     L.clite_prior_tail_bwd.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_int, C.c_int] + [C.c_void_p] * 4
     L.clite_loss_finalize.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
-    assert L.clite_prior_tail_fwd(dtype, ptr(hb), ptr(w2), ptr(b2), B, K, ptr(logit), ptr(acc[2:]), None) == 0
+    L.clite_prior_tail_fwd.argtypes = [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 3
     z = h1 @ w2 + b2[0]
     d = 1 / (1 + np.exp(-z))
     ref = -(np.log(d[:B]).mean() + np.log(1 - d[B:]).mean())
+    assert L.clite_prior_tail_fwd(dtype, ptr(hb), ptr(w2), ptr(b2), B, K, 1, ptr(logit), ptr(acc[4:]), None) == 0      # softplus form (concat critic)
+    assert abs(acc[4] - (_softplus(-z[:B]).mean() + _softplus(z[B:]).mean())) < 1e-5
+    assert L.clite_prior_tail_fwd(dtype, ptr(hb), ptr(w2), ptr(b2), B, K, 0, ptr(logit), ptr(acc[2:]), None) == 0      # the prior's log(sigmoid) form
     assert abs(acc[2] - ref) < 1e-5
     gout = np.array([2.0], np.float32)
     dh = outbuf((2 * B, K), dtype); dw = np.zeros(K, np.float32); db = np.zeros(1, np.float32)
@@ -305,10 +319,17 @@ def test_prior_tail_and_finalize(dtype):
     _close(val(dh, dtype), gl[:, None] * w2[None, :] * (h1 > 0), _tol(dtype))
     _close(dw, (gl[:, None] * h1).sum(0), 1e-4)
     assert abs(db[0] - gl.sum()) < 1e-6
-    acc[:] = [0.3, 0.4, 1.0, 2.0]
-    out = np.zeros(4, np.float32)
+    acc[:] = [0.3, 0.4, 1.0, 2.0, 0.05, 0.15, 0.25, 0.35]
+    out = np.zeros(8, np.float32)
     assert L.clite_loss_finalize(ptr(acc), 0.1, ptr(out), None) == 0
-    assert np.allclose(out, [0.9 * 0.7 + 0.1 * 3.0, 0.7, 3.0, 0.0], atol=1e-6)
+    assert np.allclose(out, [0.9 * (0.7 + 0.2 + 0.6) + 0.1 * 3.0, 0.7, 3.0, 0.2, 0.6, 0, 0, 0], atol=1e-6)
+    # clite_add: sums of feature gradients from several loss terms
+    a, ab = prep(rng.standard_normal((4, 64), dtype=np.float32), dtype)
+    b, bb = prep(rng.standard_normal((4, 64), dtype=np.float32), dtype)
+    o = outbuf((4, 64), dtype)
+    L.clite_add.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    assert L.clite_add(dtype, ptr(ab), ptr(bb), ptr(o), 256, None) == 0
+    _close(val(o, dtype), a + b, _tol(dtype))
 
 
 def test_uniform_and_optimizer():
