@@ -77,6 +77,24 @@ def test_state_dict_keys_match_reference_layout():
     assert "stem.conv1.weight" in d2 and "res2.0.conv1.norm.weight" in d2 and "res3.0.shortcut.weight" in d2
 
 
+def test_loss_variant_parameter_names_match_reference():
+    """Parameter names / shapes of every critic type and of the SSL critics against the names recorded from the reference's own
+    JSDInfoMaxLoss (tests/golden/lossvar_*.npz, reference loss.py:56-68,129-169) and against the oracle's modules."""
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from oracle import ref_model as O
+    for name, (ctype, vssl, tssl) in {"lossvar_dot_cluster": ("dot", False, False), "lossvar_concat": ("concat", False, False),
+                                      "lossvar_dot_ssl": ("dot", True, True), "lossvar_condot_cluster_ssl": ("condot", True, True),
+                                      "lossvar_dotcon_ssl": ("dotcon", True, True)}.items():
+        fx = np.load(os.path.join(G, name + ".npz"))
+        L = JSDInfoMaxLoss(512, 768, ctype, 0.1, True, True, visual_self_supervised=vssl, textual_self_supervised=tssl)
+        Lo = O.OracleJSDInfoMaxLoss(512, 768, ctype, 0.1, True, True, visual_self_supervised=vssl, textual_self_supervised=tssl)
+        assert sorted(n for n, _ in L.named_parameters()) == [str(x) for x in fx["gnames"]], name
+        sd, so = L.state_dict(), Lo.state_dict()
+        assert sorted(sd) == sorted(so) and all(tuple(sd[k].shape) == tuple(so[k].shape) for k in sd), name
+    with pytest.raises(ValueError):
+        JSDInfoMaxLoss(512, 768, "bilinear")
+
+
 def test_config_defaults_yaml_overrides_and_freeze(tmp_path):
     from clip_lite_amd.config import Config
     c = Config()
