@@ -130,3 +130,67 @@ def test_stem_7x7(dt):
     dw = torch.zeros(64, 7, 7, 3, device="cuda")
     hip.stem_unpack_grad(dwv, dw)
     assert _rel(dw, wr.grad.permute(0, 2, 3, 1)) < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 104), (3840, 2304, 768), (1000, 64, 72)])
+def test_plain_epilogue_bf16_store_bias_and_column_statistics(M, N, K):
+    """The branch-free plain epilogue instantiation (bf16 store of alpha*acc + bias, column sums of what was stored): every conv forward
+    and the QKV projection take it. Statistics are of the ROUNDED stored values (what the following BatchNorm normalises)."""
+    hip = _hip()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A, B = _t((M, K), g, BF16), _t((N, K), g, BF16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    stats = hip.Stats(torch.zeros(8 * 3 * N, device="cuda"), 8, N)
+    hip.gemm_nt(BF16, A, B, M, N, K, hip.epilogue(out, N, bias=bias, alpha=0.5, colsum=stats))
+    ref = 0.5 * (A.float() @ B.float().t()) + bias
+    assert _rel(out, ref) < 6e-3
+    cs = stats.t.view(8, 3, N).sum(0)
+    of = out.float()
+    assert _rel(cs[0], of.sum(0)) < 1e-3 and _rel(cs[1], (of ** 2).sum(0)) < 1e-3
+
+
+FULL_SIZE_CONVS = [   # ResNet-50 layers at the benchmark's per-GPU batch of 128
+    (128, 56, 56, 64, 256, 1, 1, 1, 0), (128, 14, 14, 256, 256, 3, 3, 1, 1), (128, 56, 56, 128, 128, 3, 3, 2, 1), (128, 28, 28, 256, 512, 1, 1, 2, 0),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cc,K,R,S,st,pad", FULL_SIZE_CONVS)
+def test_full_size_conv_adjoint_identities(N, H, W, Cc, K, R, S, st, pad):
+    """Size-independent property at BASELINE.json's sizes (no reference convolution is run): forward, dgrad and wgrad are the three
+    faces of one trilinear form, <conv(x, w), dy> = <x, dgrad(dy, w)> = <w, wgrad(dy, x)>. bf16 operands, f32 outputs: the three values
+    agree to summation order."""
+    hip = _hip()
+    cv = hip.conv_desc(BF16, N, H, W, Cc, K, R, S, st, pad)
+    g = torch.Generator(device="cuda").manual_seed(H + Cc + K)
+    x, w, dy = _t((N, H, W, Cc), g, BF16), _t((K, R, S, Cc), g, BF16, 0.05), _t((N, cv.Ho, cv.Wo, K), g, BF16)
+    y = torch.empty(N, cv.Ho, cv.Wo, K, device="cuda", dtype=torch.float32)
+    hip.conv_fwd(x, w, cv, hip.epilogue(y, K))
+    dx = torch.empty(N, H, W, Cc, device="cuda", dtype=torch.float32)
+    hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc))
+    dw = torch.zeros(K, R, S, Cc, device="cuda", dtype=torch.float32)
+    hip.conv_wgrad(dy, x, cv, dw)
+    a = (y.double() * dy.double()).sum().item()
+    b = (dx.double() * x.double()).sum().item()
+    c = (dw.double() * w.double()).sum().item()
+    scale = (y.double().abs() * dy.double().abs()).sum().item()
+    assert abs(a - b) < 1e-5 * scale and abs(a - c) < 1e-5 * scale, (a, b, c, scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(3840, 3072, 768), (3840, 768, 3072)])
+def test_full_size_gemm_adjoint_identities(M, N, K):
+    """<A B^T, dC> = <A, dC B> = <B, dC^T A> at the BERT FFN sizes of the benchmark (nt forward, nn input gradient, tn weight gradient)."""
+    hip = _hip()
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A, B, dC = _t((M, K), g, BF16), _t((N, K), g, BF16, 0.05), _t((M, N), g, BF16)
+    Cm = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    hip.gemm_nt(BF16, A, B, M, N, K, hip.epilogue(Cm, N))
+    dA = torch.empty(M, K, device="cuda", dtype=torch.float32)
+    hip.gemm_nn(BF16, dC, B, M, K, N, hip.epilogue(dA, K))
+    dB = torch.zeros(N, K, device="cuda", dtype=torch.float32)
+    hip.gemm_tn(BF16, dC, A, N, K, M, hip.epilogue(dB, K, atomic=True))
+    a = (Cm.double() * dC.double()).sum().item()
+    b = (dA.double() * A.double()).sum().item()
+    c = (dB.double() * B.double()).sum().item()
+    scale = (Cm.double().abs() * dC.double().abs()).sum().item()
+    assert abs(a - b) < 1e-5 * scale and abs(a - c) < 1e-5 * scale, (a, b, c, scale)
