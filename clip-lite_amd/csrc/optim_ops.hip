@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, size_t n, fl
   float s = 0.f;
   size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-    f32x4 v = *(const f32x4*)(x + i * 4);
+    f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
     s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, fl
 #pragma unroll 4
   for (uint32_t i = threadIdx.x * 4; i < it.count; i += 1024) {
     size_t o = (size_t)it.start + i;
+    // (nontemporal loads / stores measured here: 698 -> 734 us inside the step; plain accesses kept)
     f32x4 pv = *(const f32x4*)(p + o), gv = *(const f32x4*)(g + o), vv = *(const f32x4*)(v + o);
     f32x4 sv = {0.f, 0.f, 0.f, 0.f};
     if (sync) sv = *(const f32x4*)(slow + o);

@@ -81,7 +81,15 @@ DEV void bn_coef(const float* stats, int R, int RS, const float* gamma, const fl
 }
 
 // out = relu?( y*a + b  [+ res | + res*a' + b'] ).  Workgroup = 256 threads = (256/CPR) rows x CPR 8-channel chunks.
-template <typename T>
+// NT: streaming (nontemporal) loads and stores for tensors too large to be cache-resident between their producer and consumer
+// (>= BN_NT_BYTES per tensor). Stand-alone (tools/probe_bn.py, 205 MB tensors): apply 131 -> 96 us = 6.4 TB/s, backward apply 179 -> 131,
+// reduce 108 -> 88, while at <= 51 MB the cached forms are faster (the data still sits in L2 / Infinity Cache). Inside the step, where
+// the neighbouring GEMMs compete for the same HBM, the gain shrinks to 1-2 % for the apply kernels and 10 % for the reduce (rocprofv3).
+template <bool NT, typename T> DEV void ld8(const T* p, float (&v)[8]) { if constexpr (NT) load8_nt(p, v); else load8(p, v); }
+template <bool NT, typename T> DEV void st8(T* p, const float (&v)[8]) { if constexpr (NT) store8_nt(p, v); else store8(p, v); }
+constexpr size_t BN_NT_BYTES = (size_t)64 << 20;
+
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
   for (int r = row_begin + r0; r < row_end; r += RPS) {
     size_t idx = (size_t)r * p.C + c0;
     float v[8];
-    load8(y + idx, v);
+    ld8<NT>(y + idx, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[e]) * k.a[e] + k.b[e];
     if (res) {
@@ -128,13 +136,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    store8(out + idx, v);
+    st8<NT>(out + idx, v);
   }
 }
 
 // dstats[0][c] += sum dz, dstats[1][c] += sum dz*(y - mean_c), with dz = dout * (mask > 0) and mean_c = stats[0][c]/M.
 // Centering y here (instead of forming sum dz*y - mean*sum dz afterwards) avoids cancellation on channels with |mean| >> std.
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ mask, const T* __restrict__ y, const float* stats, float* dstats, int R, int RS, int M, int C, int rows_per_block) {
   __shared__ float red[256 * 16];
   const int CPR = C / 8, RPS = 256 / CPR;
@@ -150,8 +158,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (int r = row_begin + r0; r < row_end; r += RPS) {
     size_t idx = (size_t)r * C + c0;
     float d[8], yv[8];
-    load8(dout + idx, d);
-    load8(y + idx, yv);
+    ld8<NT>(dout + idx, d);
+    ld8<NT>(y + idx, yv);
     if (mask) {
       float m[8];
       load8(mask + idx, m);
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* __restric
 }
 
 // dy = gamma*rstd*(dz - S1/M - xhat*G/M), G = sum dz*xhat = rstd*S2 (S2 = sum dz*(y-mean) from the reduce kernel); dgamma += G, dbeta += S1
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* __restrict__ dout, const T* __restrict__ mask, const T* __restrict__ y, const float* dstats,
                                                            T* __restrict__ dy, T* __restrict__ dz_out, float* dgamma, float* dbeta, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
@@ -238,8 +246,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
   for (int r = row_begin + r0; r < row_end; r += RPS) {
     size_t idx = (size_t)r * p.C + c0;
     float d[8], yv[8];
-    load8(dout + idx, d);
-    load8(y + idx, yv);
+    ld8<NT>(dout + idx, d);
+    ld8<NT>(y + idx, yv);
     if (mask) {
       float m[8];
       load8(mask + idx, m);
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
     if (dz_out) store8(dz_out + idx, d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) d[e] = ka[e] * d[e] + kb[e] + kc[e] * (yv[e] - mean[e]);
-    store8(dy + idx, d);
+    st8<NT>(dy + idx, d);
   }
 }
 
@@ -450,9 +458,16 @@ extern "C" int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const
   int rpb;
   int grid = bn_grid(p->M, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH(dtype,
-           hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb),
-           hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *p, (const float*)y, (const float*)res, (float*)out, rpb));
+  const bool nt = (size_t)p->M * p->C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
+  if (nt) {
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((bn_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb),
+             hipLaunchKernelGGL((bn_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, *p, (const float*)y, (const float*)res, (float*)out, rpb));
+  } else {
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((bn_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb),
+             hipLaunchKernelGGL((bn_apply_kernel<float, false>), dim3(grid), dim3(256), 0, st, *p, (const float*)y, (const float*)res, (float*)out, rpb));
+  }
   return (int)hipGetLastError();
 }
 
@@ -473,9 +488,16 @@ extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask
   int rpb;
   int grid = bn_grid(M, C, &rpb);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH(dtype,
-           hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, stats, dstats, replicas, rstride, M, C, rpb),
-           hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, stats, dstats, replicas, rstride, M, C, rpb));
+  const bool nt = (size_t)M * C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
+  if (nt) {
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, stats, dstats, replicas, rstride, M, C, rpb),
+             hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, stats, dstats, replicas, rstride, M, C, rpb));
+  } else {
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, stats, dstats, replicas, rstride, M, C, rpb),
+             hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, stats, dstats, replicas, rstride, M, C, rpb));
+  }
   return (int)hipGetLastError();
 }
 
@@ -485,9 +507,16 @@ extern "C" int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout
   int rpb;
   int grid = bn_grid(p->M, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH(dtype,
-           hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),
-           hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, *p, (const float*)dout, (const float*)mask, (const float*)y, dstats, (float*)dy, (float*)dz, dgamma, dbeta, rpb));
+  const bool nt = (size_t)p->M * p->C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
+  if (nt) {
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),
+             hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, *p, (const float*)dout, (const float*)mask, (const float*)y, dstats, (float*)dy, (float*)dz, dgamma, dbeta, rpb));
+  } else {
+    DISPATCH(dtype,
+             hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),
+             hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(grid), dim3(256), 0, st, *p, (const float*)dout, (const float*)mask, (const float*)y, dstats, (float*)dy, (float*)dz, dgamma, dbeta, rpb));
+  }
   return (int)hipGetLastError();
 }
 

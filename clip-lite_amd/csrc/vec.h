@@ -17,6 +17,27 @@ DEV void load8(const float* p, float (&v)[8]) {
   f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
   v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
+// streaming forms: the tensor is not read again soon (last use of an activation in backward) / not re-read by this kernel
+DEV void load8_nt(const bf16* p, float (&v)[8]) {
+  Chunk16 c;
+  c.u = __builtin_nontemporal_load((const u32x4*)p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = bf2f(c.e[e]);
+}
+DEV void load8_nt(const float* p, float (&v)[8]) {
+  f32x4 a = __builtin_nontemporal_load((const f32x4*)p), b = __builtin_nontemporal_load((const f32x4*)(p + 4));
+  v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+DEV void store8_nt(bf16* p, const float (&v)[8]) {
+  Chunk16 c;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) c.e[e] = f2bf(v[e]);
+  __builtin_nontemporal_store(c.u, (u32x4*)p);
+}
+DEV void store8_nt(float* p, const float (&v)[8]) {
+  __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4*)p);
+  __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, (f32x4*)(p + 4));
+}
 DEV void store8(bf16* p, const float (&v)[8]) {
   Chunk16 c;
 #pragma unroll
