@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL over xGMI); gloo is for single-GPU logic tests")
     ap.add_argument("--single-device", action="store_true", help="logic test only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--host-input", action="store_true", help="batches start in pinned host memory and cross PCIe every step through the train loop's "
+                    "copy-stream prefetcher (utils/common.cycle): the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--force-exchange", action="store_true", help="run the gradient exchange (process group, RCCL all-reduces between the graphs) even with "
                     "one rank: exercises the data-parallel launch path on a one-GPU box (launch under torch.distributed.run)")
     args = ap.parse_args()
@@ -188,16 +190,29 @@ def main():
     step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange, graph=not args.no_graph)
     eager_step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange)      # per-launch timing needs eager launches
     batches = synthetic_batches(args, device, rank)
+    if args.host_input:
+        from clip_lite_amd.utils.common import cycle
+
+        class _HostLoader:          # what a DataLoader(pin_memory=True) hands out
+            sampler = None
+            data = [{k: v.cpu().pin_memory() for k, v in b.items()} for b in batches]
+
+            def __iter__(self):
+                return iter(self.data)
+        feed = cycle(_HostLoader(), device)
+        next_batch = lambda i: next(feed)
+    else:
+        next_batch = lambda i: batches[i % len(batches)]
 
     for i in range(max(args.warmup, 3 if step.graph else 0)):      # graph mode: 2 eager steps, then the capture + first replay
-        step(batches[i % len(batches)])
+        step(next_batch(i))
     torch.cuda.synchronize()
     if dist_on:
         tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        out = step(batches[i % len(batches)])
+        out = step(next_batch(i))
     torch.cuda.synchronize()
     if dist_on:
         tdist.barrier()
@@ -221,7 +236,7 @@ def main():
             "metric": "image-caption pairs/sec (global batch) — ResNet-50+BERT bs1024, 1/2/4/8 MI355X",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.f32 else "bf16", "data": "synthetic",
+            "dtype": "f32" if args.f32 else "bf16", "data": "synthetic" + (", fed from pinned host memory every step" if args.host_input else ""),
             "config": {"workload": f"{args.visual} + BERT-base({args.layers}L) + JSD-MI heads/priors, per-GPU batch {args.batch}, 224x224 images, "
                                    f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)" + ("" if args.loss == "jsd" else ", InfoNCE all-pairs loss"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},

@@ -299,3 +299,27 @@ def test_bench_under_torchrun_with_rccl_exchange_one_rank():
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
     assert res["launch"] == "hipGraph replay" and res["n_gpus"] == 1 and res["value"] > 0 and np.isfinite(res["loss"])
+
+
+@pytest.mark.gpu
+def test_prefetching_batch_iterator_hands_over_intact_batches():
+    """utils/common.cycle on the GPU: batches staged on the copy stream from pinned host memory arrive bit-identical and in order on the
+    compute stream, also when the consumer overwrites / frees them while later batches are still in flight."""
+    from clip_lite_amd.utils.common import cycle
+    g = torch.Generator().manual_seed(0)
+    host = [{"image": torch.randn(8, 3, 64, 64, generator=g).pin_memory(), "input_ids": torch.randint(0, 30522, (8, 30), generator=g).pin_memory()}
+            for _ in range(5)]
+
+    class Loader:
+        sampler = None
+
+        def __iter__(self):
+            return iter(host)
+
+    it = cycle(Loader(), torch.device("cuda", 0))
+    for i in range(12):
+        b = next(it)
+        ref = host[i % 5]
+        assert b["image"].is_cuda and torch.equal(b["image"].cpu(), ref["image"]) and torch.equal(b["input_ids"].cpu(), ref["input_ids"])
+        b["image"].mul_(0.0)        # consumer scribbles over its batch; the next ones must be unaffected
+        del b

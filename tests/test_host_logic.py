@@ -152,6 +152,31 @@ def test_batch_contract_and_factories():
         assert len(j) == 41 and j.collate_fn([j[0], j[1]])["input_ids"].shape[0] == 2
 
 
+def test_cycle_keeps_the_reference_batch_order_and_shuffle_seeds():
+    """utils/common.cycle (reference utils/common.py:14-37) with the copy-stream prefetcher: same batches in the same order, and the
+    DistributedSampler is re-seeded with the number of batches drawn so far at each pass, exactly as the reference's `iteration`."""
+    from torch.utils.data import DataLoader, DistributedSampler, TensorDataset
+    from clip_lite_amd.utils.common import cycle
+    ds = TensorDataset(torch.arange(12))
+    seeds = []
+
+    class Sampler(DistributedSampler):
+        def set_epoch(self, e):
+            seeds.append(e)
+            super().set_epoch(e)
+
+    def run(prefetch):
+        seeds.clear()
+        dl = DataLoader(ds, batch_size=4, sampler=Sampler(ds, num_replicas=1, rank=0, shuffle=True, seed=3), collate_fn=lambda it: {"x": torch.stack([i[0] for i in it])})
+        it = cycle(dl, "cpu", start_iteration=5, prefetch=prefetch)
+        return [next(it)["x"].tolist() for _ in range(7)], list(seeds)
+
+    b0, s0 = run(0)          # the reference's order: copy, yield, copy, yield, ...
+    b2, s2 = run(2)
+    assert b0 == b2
+    assert s0[:2] == [5, 8] and s2[:len(s0)] == s0      # 3 batches per pass; the prefetching iterator may already have begun the next pass
+
+
 def test_checkpoint_manager_layout(tmp_path):
     from clip_lite_amd.utils.checkpointing import CheckpointManager
     model = torch.nn.Linear(4, 2)
