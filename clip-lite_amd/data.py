@@ -13,6 +13,7 @@ synthetic.
 import hashlib
 import json
 import re
+import unicodedata
 
 import torch
 from torch.utils.data import Dataset
@@ -21,10 +22,27 @@ CAPTIONS = ["a photo of a cat sitting on a couch", "two people riding bikes down
             "a plate of food with vegetables on a table", "a large airplane flying through a cloudy sky"]
 
 
+_DROPPED = str.maketrans("", "", ",.'!?\"()*#:;~")
+
+
+def normalize_caption(caption: str, max_caption_length: int = 30) -> str:
+    """The reference's caption normalisation (data/transforms.py:46-90, NormalizeCaption): lower-case; delete , . ' ! ? " ( ) * # : ; ~;
+    '-' and '/' become spaces; the COCO placeholder "<person>" becomes "person"; runs of two or more whitespace characters collapse
+    to one space; trailing newlines and surrounding spaces go; at most `max_caption_length` space-separated words are kept; finally NFKD
+    decomposition with the combining marks removed (accents stripped)."""
+    c = caption.lower().translate(_DROPPED).replace("-", " ").replace("/", " ").replace("<person>", "person")
+    c = re.sub(r"\s{2,}", " ", c).rstrip("\n").strip(" ")
+    words = c.split(" ")
+    if len(words) > max_caption_length:
+        c = " ".join(words[:max_caption_length])
+    c = unicodedata.normalize("NFKD", c.lower())
+    return "".join(ch for ch in c if not unicodedata.combining(ch))
+
+
 def hash_tokenize(caption: str, max_len: int, vocab: int = 30522):
-    """lower-case / strip punctuation like the reference's caption normalisation (data/transforms.py:46-90), then map every word to
-    a stable id in [1000, vocab); [CLS]=101 ... [SEP]=102."""
-    words = re.sub(r"[^a-z0-9 ]", " ", caption.lower()).split()
+    """normalize_caption, then map every word to a stable id in [1000, vocab); [CLS]=101 ... [SEP]=102 (the HF tokenizer files the
+    reference loads, data/tokenizers.py, are not available offline)."""
+    words = re.sub(r"[^a-z0-9 ]", " ", normalize_caption(caption, max_len)).split()
     ids = [101] + [1000 + int.from_bytes(hashlib.md5(w.encode()).digest()[:4], "little") % (vocab - 1000) for w in words][: max_len - 2] + [102]
     return ids
 

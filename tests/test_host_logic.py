@@ -152,6 +152,19 @@ def test_batch_contract_and_factories():
         assert len(j) == 41 and j.collate_fn([j[0], j[1]])["input_ids"].shape[0] == 2
 
 
+def test_caption_normalisation_known_answers():
+    """reference data/transforms.py:46-90 (NormalizeCaption.pre_caption + apply_to_caption), worked by hand from its rules: the listed
+    punctuation is deleted (not spaced), '-' and '/' become spaces, "<person>" -> "person" (after lower-casing, so "<PERSON>" too), runs of
+    >= 2 whitespace characters collapse to one space but a single tab survives, truncation counts space-separated words, accents go."""
+    from clip_lite_amd.data import normalize_caption as n
+    assert n("  A man, riding a skate-board!  ") == "a man riding a skate board"
+    assert n('<person> and/or <PERSON> at the Caf\u00e9;  it\'s  "great"\n') == "person and or person at the cafe its great"
+    assert n("tab\there  two\t\tTabs") == "tab\there two tabs"
+    assert n(" ".join(str(i) for i in range(40)), 30) == " ".join(str(i) for i in range(30))
+    assert n("a (very) *small* #1 dog: ~nice~") == "a very small 1 dog nice"
+    assert n("") == ""
+
+
 def test_cycle_keeps_the_reference_batch_order_and_shuffle_seeds():
     """utils/common.cycle (reference utils/common.py:14-37) with the copy-stream prefetcher: same batches in the same order, and the
     DistributedSampler is re-seeded with the number of batches drawn so far at each pass, exactly as the reference's `iteration`."""
