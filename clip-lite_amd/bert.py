@@ -191,7 +191,7 @@ def bert_forward(rt, net, input_ids, attention_mask, step):
         ctx["layers"].append((layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2))
         h = h2
     pooled = _alloc(rt, B, Hd)
-    hip.gemm_nt(dt, h, A.w(net.pooler.dense.weight), B, Hd, Hd, hip.epilogue(pooled, Hd, bias=net.pooler.dense.bias, act=hip.ACT_TANH), lda=L * Hd)
+    hip.gemm_nt(dt, h, A.w(net.pooler.dense.weight), B, Hd, Hd, hip.epilogue(pooled, Hd, bias=net.pooler.dense.bias, act=hip.ACT_TANH, ws=rt.gemm_ws(B, Hd)), lda=L * Hd)
     ctx["h_last"], ctx["pooled"] = h, pooled
     return pooled, ctx
 
@@ -210,7 +210,7 @@ def bert_backward(rt, net, ctx, dpooled):
         hip.colsum(dt, dpre, A.g(pw.bias), B, Hd)
     rt.grads_ready(net.pooler)
     dh = torch.zeros(M, Hd, device=rt.device, dtype=rt.tdtype)
-    hip.gemm_nn(dt, dpre, A.w(pw.weight), B, Hd, Hd, hip.epilogue(dh, L * Hd))
+    hip.gemm_nn(dt, dpre, A.w(pw.weight), B, Hd, Hd, hip.epilogue(dh, L * Hd, ws=rt.gemm_ws(B, Hd)))
     for (layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2) in reversed(ctx["layers"]):
         sa, so, out = layer.attention.self, layer.attention.output, layer.output
         # LayerNorm 2 -> (dropout) -> FFN

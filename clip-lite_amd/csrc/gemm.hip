@@ -161,11 +161,112 @@ int check_ep(const clite_epilogue* ep, int N) {
 
 uint32_t span_bytes(int rows, int cols, int ld, size_t es) { return (uint32_t)(((size_t)(rows - 1) * ld + cols) * es); }
 
+// ---- split-K for GEMMs of few output tiles (clite_epilogue.splitk_ws) ------------------------------------------------------------
+// The heads' GEMMs have M = 128 or 256 rows: 16-32 output tiles, i.e. 16-32 CUs pulling an 8 MB weight matrix out of HBM at ~25 GB/s each
+// (37 us in the step for 128 x 2048 x 2048). Split over K every CU fetches a slice: the partial tiles meet in an f32 workspace through
+// float atomics and splitk_finish_kernel applies the epilogue. bf16 only (the exact-f32 mode keeps one k-ordered chain per output).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, clite_epilogue ep, int M, int N) {
+  // workgroup = 8 column chunks (64 columns) x 32 row lanes; all M rows of its columns, so the column statistics need no cross-workgroup step
+  __shared__ float red[32][8][16];
+  const int tid = threadIdx.x, cl = tid & 7, rl = tid >> 3;
+  const int col = (blockIdx.x * 8 + cl) * 8;
+  const bool colok = col < N;
+  float bias[8], csum[8], csq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { bias[e] = (colok && ep.bias) ? ep.bias[col + e] : 0.f; csum[e] = 0.f; csq[e] = 0.f; }
+  if (colok) {
+    for (int r = rl; r < M; r += 32) {
+      float v[8];
+      load8(ws + (size_t)r * N + col, v);
+      const size_t o = (size_t)r * ep.ldc + col;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
+      if (ep.preact) store8((T*)ep.preact + o, v);
+      if (ep.act == CLITE_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      } else if (ep.act == CLITE_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      } else if (ep.act == CLITE_ACT_TANH) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+      }
+      if (ep.dact_aux) {
+        float a[8];
+        load8((const T*)ep.dact_aux + o, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= ep.dact == 1 ? (a[e] > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_f(a[e]) : (1.f - a[e] * a[e]);
+      }
+      if (ep.residual) {
+        float rv[8];
+        load8((const T*)ep.residual + o, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (ep.out_f32) {
+        store8((float*)ep.out + o, v);
+      } else {
+        store8((T*)ep.out + o, v);
+        round8_bf16(v);       // statistics of what was stored
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+    }
+  }
+  if (!ep.colsum) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[rl][cl][e] = csum[e]; red[rl][cl][8 + e] = csq[e]; }
+  __syncthreads();
+  if (tid < 128) {
+    const int c = tid >> 4, e = tid & 15;
+    float s = 0.f;
+    for (int r = 0; r < 32; ++r) s += red[r][c][e];
+    const int cc = (blockIdx.x * 8 + c) * 8 + (e & 7);
+    float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
+    if (cc < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + cc, s);
+  }
+}
+
+// number of K splits for the workspace form, or 0 when the launch does not qualify
+template <typename T>
+int splitk_plan(const clite_epilogue& ep, int M, int N, int ktiles) {
+  if (sizeof(T) != 2 || !ep.splitk_ws || ep.atomic || ep.drop_p > 0.f || ep.bn_y || ep.mask_after_residual || N % 8) return 0;
+  static int pref = -1;      // CLITE_SPLITK_WS=0 disables (A/B timing)
+  if (pref < 0) { const char* e = getenv("CLITE_SPLITK_WS"); pref = e ? atoi(e) : 1; }
+  if (!pref) return 0;
+  long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles > 48 || ktiles < 8) return 0;
+  long want = (256 + tiles - 1) / tiles, cap = ktiles / 2;
+  if (want > cap) want = cap;
+  return want >= 2 ? (int)want : 0;
+}
+
+template <typename T>
+int splitk_finish(const clite_epilogue& ep, int M, int N, hipStream_t st) {
+  hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((N / 8 + 7) / 8), dim3(256), 0, st, (const float*)ep.splitk_ws, ep, M, N);
+  return (int)hipGetLastError();
+}
+
+clite_epilogue splitk_partial(const clite_epilogue& ep, int N) {
+  clite_epilogue e{};
+  e.out = ep.splitk_ws; e.ldc = N; e.out_f32 = 1; e.atomic = 1; e.alpha = 1.f;
+  return e;
+}
+
 template <typename T>
 int gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
   constexpr int BK = Cfg<T>::BK;
   uint32_t ab = span_bytes(M, K, lda, sizeof(T)), bb = span_bytes(N, K, ldb, sizeof(T));
   int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
+  if (int sk = splitk_plan<T>(*ep, M, N, (K + BK - 1) / BK)) {
+    clite_epilogue e1 = splitk_partial(*ep, N);
+    GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K, lda)};
+    GatherKC<T, 128, BK, false> lb{B, bb, geom_dense(N, K, ldb)};
+    int rc = launch<T, typename Cfg<T>::C128>(la, lb, e1, M, N, K, sk, st);
+    return rc ? rc : splitk_finish<T>(*ep, M, N, st);
+  }
   if (N <= 64) {
     GatherKC<T, 256, BK, false> la{A, ab, geom_dense(M, K, lda)};
     GatherKC<T, 64, BK, false> lb{B, bb, geom_dense(N, K, ldb)};
@@ -181,6 +282,13 @@ int gemm_nn(const void* A, int lda, const void* B, int ldb, int M, int N, int K,
   constexpr int BK = Cfg<T>::BK;
   uint32_t ab = span_bytes(M, K, lda, sizeof(T)), bb = span_bytes(K, N, ldb, sizeof(T));
   int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
+  if (int sk = splitk_plan<T>(*ep, M, N, (K + BK - 1) / BK)) {
+    clite_epilogue e1 = splitk_partial(*ep, N);
+    GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K, lda)};
+    StridedXC<T, 128, BK> lb{B, bb, ldb, N, K, 1};
+    int rc = launch<T, typename Cfg<T>::C128>(la, lb, e1, M, N, K, sk, st);
+    return rc ? rc : splitk_finish<T>(*ep, M, N, st);
+  }
   if (N <= 64) {
     GatherKC<T, 256, BK, false> la{A, ab, geom_dense(M, K, lda)};
     StridedXC<T, 64, BK> lb{B, bb, ldb, N, K, 1};

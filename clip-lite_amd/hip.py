@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -28,7 +28,7 @@ class Epilogue(C.Structure):
         ("drop_site", C.c_uint32), ("residual", C.c_void_p), ("colsum", C.c_void_p),
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
-        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32),
+        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("splitk_ws", C.c_void_p),
     ]
 
 
@@ -161,7 +161,7 @@ class Stats:
 
 
 def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
-             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False):
+             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False, ws=None):
     """bn = (y, stats: Stats, rows): accumulate the BatchNorm-backward reductions (sum v, sum v*(y - mean)) into `colsum`."""
     ep = Epilogue()
     ep.out = p(out)
@@ -185,6 +185,7 @@ def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, pr
         y, st, rows = bn
         ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = p(y), p(st.t), st.R, st.rstride, 1.0 / rows
     ep.mask_after_residual = int(mask_after_residual)
+    ep.splitk_ws = p(ws)        # zeroed f32 [M][N] workspace: allows split-K for GEMMs of few output tiles (clite_epilogue.splitk_ws)
     return ep
 
 

@@ -145,7 +145,7 @@ def mi_block_forward(rt, blk, x, training, updates=2):
     l1, bn, _, l2 = blk.feature_nonlinear
     z = _alloc(rt, B, U)
     stats = rt.new_stats(U) if training else None
-    hip.gemm_nt(dt, x, A.w(l1.weight), B, U, Fin, hip.epilogue(z, U, colsum=stats))
+    hip.gemm_nt(dt, x, A.w(l1.weight), B, U, Fin, hip.epilogue(z, U, colsum=stats, ws=rt.gemm_ws(B, U)))
     if training and rt.precise_bn:
         hip.bn_centered_var(dt, z, stats, B, U)
     a = _alloc(rt, B, U)
@@ -155,9 +155,9 @@ def mi_block_forward(rt, blk, x, training, updates=2):
         desc2 = hip.bn_desc(B, U, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, True, bn.momentum, bn.eps, True, centered=rt.precise_bn)
         hip.bn_apply(dt, desc2, z, None, a)
     f = _alloc(rt, B, U)
-    hip.gemm_nt(dt, a, A.w(l2.weight), B, U, U, hip.epilogue(f, U, bias=l2.bias))
+    hip.gemm_nt(dt, a, A.w(l2.weight), B, U, U, hip.epilogue(f, U, bias=l2.bias, ws=rt.gemm_ws(B, U)))
     t = _alloc(rt, B, U)
-    hip.gemm_nt(dt, x, A.w(blk.feature_shortcut.weight), B, U, Fin, hip.epilogue(t, U, bias=blk.feature_shortcut.bias, residual=f))
+    hip.gemm_nt(dt, x, A.w(blk.feature_shortcut.weight), B, U, Fin, hip.epilogue(t, U, bias=blk.feature_shortcut.bias, residual=f, ws=rt.gemm_ws(B, U)))
     if not blk.bln:
         return t, (x, z, stats, a, t, None)
     out = _alloc(rt, B, U)
@@ -183,11 +183,11 @@ def mi_block_backward(rt, blk, ctx, dout, dx_residual=None):
     sc = blk.feature_shortcut
     _linear_grads(rt, sc, dtt, x, B)
     dx = _alloc(rt, B, Fin)
-    hip.gemm_nn(dt, dtt, A.w(sc.weight), B, Fin, U, hip.epilogue(dx, Fin, residual=dx_residual))
+    hip.gemm_nn(dt, dtt, A.w(sc.weight), B, Fin, U, hip.epilogue(dx, Fin, residual=dx_residual, ws=rt.gemm_ws(B, Fin)))
     hip.gemm_tn(dt, dtt, a, U, U, B, hip.epilogue(A.g(l2.weight), U, atomic=True, out_f32=True))
     hip.colsum(dt, dtt, A.g(l2.bias), B, U)
     da = _alloc(rt, B, U)
-    hip.gemm_nn(dt, dtt, A.w(l2.weight), B, U, U, hip.epilogue(da, U))
+    hip.gemm_nn(dt, dtt, A.w(l2.weight), B, U, U, hip.epilogue(da, U, ws=rt.gemm_ws(B, U)))
     dstats = rt.new_stats(U)
     hip.bn_bwd_reduce(dt, da, a, z, stats, dstats, B, U)
     dz = _alloc(rt, B, U)
@@ -195,7 +195,7 @@ def mi_block_backward(rt, blk, ctx, dout, dx_residual=None):
     hip.bn_bwd_apply(dt, desc, da, a, z, dstats, dz, None, A.g(bn.weight), A.g(bn.bias))
     hip.gemm_tn(dt, dz, x, U, Fin, B, hip.epilogue(A.g(l1.weight), Fin, atomic=True, out_f32=True))
     dx2 = _alloc(rt, B, Fin)
-    hip.gemm_nn(dt, dz, A.w(l1.weight), B, Fin, U, hip.epilogue(dx2, Fin, residual=dx))
+    hip.gemm_nn(dt, dz, A.w(l1.weight), B, Fin, U, hip.epilogue(dx2, Fin, residual=dx, ws=rt.gemm_ws(B, Fin)))
     return dx2
 
 
@@ -220,9 +220,9 @@ def _mlp_tail_forward(rt, net, x2, half, acc_slot, softplus):
     R, sz = x2.shape
     n0, n1 = net.l0.weight.shape[0], net.l1.weight.shape[0]
     h0 = _alloc(rt, R, n0)
-    hip.gemm_nt(dt, x2, A.w(net.l0.weight), R, n0, sz, hip.epilogue(h0, n0, bias=net.l0.bias, act=hip.ACT_RELU))
+    hip.gemm_nt(dt, x2, A.w(net.l0.weight), R, n0, sz, hip.epilogue(h0, n0, bias=net.l0.bias, act=hip.ACT_RELU, ws=rt.gemm_ws(R, n0)))
     h1 = _alloc(rt, R, n1)
-    hip.gemm_nt(dt, h0, A.w(net.l1.weight), R, n1, n0, hip.epilogue(h1, n1, bias=net.l1.bias, act=hip.ACT_RELU))
+    hip.gemm_nt(dt, h0, A.w(net.l1.weight), R, n1, n0, hip.epilogue(h1, n1, bias=net.l1.bias, act=hip.ACT_RELU, ws=rt.gemm_ws(R, n1)))
     logit = torch.empty(R, device=rt.device, dtype=torch.float32)
     hip.prior_tail_fwd(dt, h1, net.l2.weight, net.l2.bias, half, n1, logit, acc_slot, softplus=softplus)
     return (x2, h0, h1, logit)
@@ -239,7 +239,7 @@ def _mlp_tail_backward(rt, net, ctx, gout, scale):
     hip.prior_tail_bwd(dt, h1, net.l2.weight, logit, gout, scale, R // 2, n1, dh1, A.g(net.l2.weight), A.g(net.l2.bias))
     _linear_grads(rt, net.l1, dh1, h0, R)
     dh0 = _alloc(rt, R, n0)
-    hip.gemm_nn(dt, dh1, A.w(net.l1.weight), R, n0, n1, hip.epilogue(dh0, n0, dact_aux=h0, dact=hip.DACT_RELU))
+    hip.gemm_nn(dt, dh1, A.w(net.l1.weight), R, n0, n1, hip.epilogue(dh0, n0, dact_aux=h0, dact=hip.DACT_RELU, ws=rt.gemm_ws(R, n0)))
     _linear_grads(rt, net.l0, dh0, x2, R)
     return dh0
 
@@ -252,7 +252,7 @@ def prior_backward(rt, pd, ctx, gout, scale, dfeat_residual):
     dh0 = _mlp_tail_backward(rt, pd, ctx, gout, scale)
     dfeat = _alloc(rt, B, sz)
     # only the feature rows (B..2B) need an input gradient; the noise rows have none
-    hip.gemm_nn(dt, dh0[B:], A.w(pd.l0.weight), B, sz, dh0.shape[1], hip.epilogue(dfeat, sz, residual=dfeat_residual))
+    hip.gemm_nn(dt, dh0[B:], A.w(pd.l0.weight), B, sz, dh0.shape[1], hip.epilogue(dfeat, sz, residual=dfeat_residual, ws=rt.gemm_ws(B, sz)))
     return dfeat
 
 

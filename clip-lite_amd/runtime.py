@@ -222,6 +222,13 @@ class DeviceRuntime:
             pool = self._zpools[key] = ZeroPool(self.device)
         return pool
 
+    def gemm_ws(self, M, N):
+        """Zeroed f32 [M][N] split-K workspace for a GEMM of few output tiles (clite_epilogue.splitk_ws), or None where the library would
+        not split anyway (many tiles, exact-f32 mode)."""
+        if not self.lowp or ((M + 127) // 128) * ((N + 127) // 128) > 48 or N % 8:
+            return None
+        return self.zpool.take(M * N)
+
     def new_stats(self, Cc):
         """Zeroed replicated accumulator for per-channel statistics of a [rows][Cc] tensor."""
         return hip.Stats(self.zpool.take(STAT_REPLICAS * 3 * Cc), STAT_REPLICAS, Cc)

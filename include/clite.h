@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 3
+#define CLITE_ABI_VERSION 4
 int clite_abi_version(void);
 
 /* storage type of activations / weights handed to a kernel. CLITE_F32 selects the exact-f32 parity mode
@@ -67,6 +67,9 @@ typedef struct clite_epilogue {
   int32_t bn_rstride;
   float bn_inv_count;       /* 1 / rows of the BatchNorm */
   int32_t mask_after_residual;
+  float* splitk_ws;         /* optional f32 [M][N] workspace, ZERO on entry (left dirty): lets clite_gemm_nt / _nn run a GEMM of few output tiles
+                             * (the M = 128/256-row GEMMs of the projection heads and prior discriminators) as split-K over all CUs — partial
+                             * sums accumulate here with float atomics and a second small kernel applies this epilogue. NULL: never split. */
 } clite_epilogue;
 
 /* NHWC convolution problem. x: [N][H][W][C], w: [K][R][S][C], y: [N][Ho][Wo][K], all of `dtype`. */

@@ -22,7 +22,7 @@ class Epilogue(C.Structure):
         ("drop_site", C.c_uint32), ("residual", C.c_void_p), ("colsum", C.c_void_p),
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
-        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32),
+        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("splitk_ws", C.c_void_p),
     ]
 
 

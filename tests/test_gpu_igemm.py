@@ -194,3 +194,30 @@ def test_full_size_gemm_adjoint_identities(M, N, K):
     c = (dB.double() * B.double()).sum().item()
     scale = (Cm.double().abs() * dC.double().abs()).sum().item()
     assert abs(a - b) < 1e-5 * scale and abs(a - c) < 1e-5 * scale, (a, b, c, scale)
+
+
+@pytest.mark.parametrize("kind,M,N,K", [("nt", 128, 2048, 2048), ("nn", 128, 768, 2048), ("nt", 256, 200, 1000), ("nn", 256, 1000, 200), ("nt", 128, 768, 768)])
+def test_splitk_workspace_form_matches_fused_path(kind, M, N, K):
+    """The heads' tiny-M GEMMs through clite_epilogue.splitk_ws (split-K into a zeroed f32 workspace + finishing kernel) against the
+    fused single-pass path on the same operands and against torch: bias + ReLU + pre-activation / residual / column statistics."""
+    hip = _hip()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = _t((M, K), g, BF16)
+    B = _t((N, K) if kind == "nt" else (K, N), g, BF16, 0.05)
+    res, bias = _t((M, N), g, BF16), torch.randn(N, device="cuda", generator=g)
+    f = hip.gemm_nt if kind == "nt" else hip.gemm_nn
+    outs = []
+    for use_ws in (False, True):
+        out, pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        stats = hip.Stats(torch.zeros(8 * 3 * N, device="cuda"), 8, N)
+        ws = torch.zeros(M, N, device="cuda") if use_ws else None
+        f(BF16, A, B, M, N, K, hip.epilogue(out, N, bias=bias, act=hip.ACT_RELU, preact=pre, residual=res, colsum=stats, ws=ws))
+        if use_ws:
+            assert (ws.abs().max() > 0) == (K >= 256)      # the split-K form ran (K < 8 tiles does not qualify: the fused path is taken)
+        outs.append((out.float(), pre.float(), stats.t.view(8, 3, N).sum(0)))
+    z = A.float() @ (B.float().t() if kind == "nt" else B.float()) + bias
+    ref = z.relu() + res.float()
+    for out, pre, cs in outs:
+        assert _rel(out, ref) < 6e-3 and _rel(pre, z) < 6e-3
+        assert _rel(cs[0], out.sum(0)) < 1e-3 and _rel(cs[1], (out ** 2).sum(0)) < 1e-3
+    assert _rel(outs[1][0], outs[0][0]) < 8e-3

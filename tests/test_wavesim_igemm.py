@@ -54,6 +54,42 @@ def test_gemm_nn_dact(dtype, M, N, K):
     _close(out, (A @ B) * (aux > 0))
 
 
+@pytest.mark.parametrize("kind,M,N,K", [("nt", 40, 136, 256), ("nn", 128, 200, 320), ("nt", 130, 64, 288)])
+def test_gemm_splitk_workspace_form(kind, M, N, K):
+    """clite_epilogue.splitk_ws: a GEMM of few output tiles runs as split-K into a zeroed f32 workspace plus splitk_finish_kernel. Same
+    epilogue semantics as the fused path: bias, ReLU with pre-activation store / activation-derivative factor, residual, bf16 store,
+    column statistics of the stored values, strided output rows."""
+    rng = np.random.default_rng(M + N + K)
+    A, Ab = _prep(rng.standard_normal((M, K), dtype=np.float32), BF16)
+    Bm, Bb = _prep(rng.standard_normal((N, K) if kind == "nt" else (K, N), dtype=np.float32), BF16)
+    R, Rb = _prep(rng.standard_normal((M, 2 * N), dtype=np.float32), BF16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ldc = 2 * N                                   # output rows scattered through ldc, as the BERT pooler's input gradient is
+    out = np.zeros((M, ldc), np.uint16); pre = np.zeros((M, ldc), np.uint16)
+    colsum = np.zeros((2, N), np.float32)
+    ws = np.zeros((M, N), np.float32)
+    z = A @ (Bm.T if kind == "nt" else Bm)
+    if kind == "nt":
+        ep = make_ep(out, ldc, bias=bias, act=1, preact=pre, residual=Rb, colsum=colsum, alpha=0.5)
+        ep.splitk_ws = ptr(ws)
+        assert lib().clite_gemm_nt(ptr(Ab), K, ptr(Bb), K, M, N, K, BF16, C.byref(ep), None) == 0
+        zz = 0.5 * z + bias
+        ref = np.maximum(zz, 0) + R[:, :N]
+        _close(from_bf16(pre)[:, :N], zz, 6e-3)
+    else:
+        aux, auxb = _prep(rng.standard_normal((M, 2 * N), dtype=np.float32), BF16)
+        ep = make_ep(out, ldc, dact_aux=auxb, dact=1, residual=Rb, colsum=colsum)
+        ep.splitk_ws = ptr(ws)
+        assert lib().clite_gemm_nn(ptr(Ab), K, ptr(Bb), N, M, N, K, BF16, C.byref(ep), None) == 0
+        ref = z * (aux[:, :N] > 0) + R[:, :N]
+    assert np.abs(ws).max() > 0                   # the split-K form ran (the fused path never touches the workspace)
+    got = from_bf16(out)
+    _close(got[:, :N], ref, 6e-3)
+    assert not got[:, N:].any()
+    _close(colsum[0], got[:, :N].sum(0), 1e-4)
+    _close(colsum[1], (got[:, :N] ** 2).sum(0), 1e-4)
+
+
 @pytest.mark.parametrize("dtype,N,H,W,Cc,K,R,S,st,pad", [(BF16, 2, 8, 8, 32, 64, 3, 3, 1, 1), (BF16, 3, 6, 6, 136, 64, 1, 1, 1, 0), (F32, 2, 9, 7, 64, 32, 3, 3, 2, 1)])
 def test_conv_dgrad_bn_backward_reductions(dtype, N, H, W, Cc, K, R, S, st, pad):
     """Epilogue form used by the ResNet backward (conv dgrad only): v = (acc + residual) * (aux > 0) stored, and
