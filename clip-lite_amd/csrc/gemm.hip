@@ -233,12 +233,15 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 template <typename T>
 int splitk_plan(const clite_epilogue& ep, int M, int N, int ktiles) {
   if (sizeof(T) != 2 || !ep.splitk_ws || ep.atomic || ep.drop_p > 0.f || ep.bn_y || ep.mask_after_residual || N % 8) return 0;
-  static int pref = -1;      // CLITE_SPLITK_WS=0 disables (A/B timing)
+  static int pref = -1;      // CLITE_SPLITK_WS=0 disables, =n aims for n workgroups (A/B timing)
   if (pref < 0) { const char* e = getenv("CLITE_SPLITK_WS"); pref = e ? atoi(e) : 1; }
   if (!pref) return 0;
+  // every split adds a full f32 tile of atomic traffic (64 KB; chip-wide ~1.3 TB/s): ~64 workgroups balance that against the number of
+  // CUs fetching the weights (tools/probe_heads.py, sum over the heads' shapes: no split 482 us, 32 -> 371, 64 -> 339, 128 -> 357, 256 -> 425)
+  const long target = pref > 1 ? pref : 64;
   long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
   if (tiles > 48 || ktiles < 8) return 0;
-  long want = (256 + tiles - 1) / tiles, cap = ktiles / 2;
+  long want = (target + tiles - 1) / tiles, cap = ktiles / 2;
   if (want > cap) want = cap;
   return want >= 2 ? (int)want : 0;
 }
