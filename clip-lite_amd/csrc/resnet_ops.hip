@@ -280,13 +280,13 @@ int bn_ok(int M, int C) { return M > 0 && C >= 8 && C % 8 == 0 && C / 8 <= 256 &
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, uint8_t* idx, int N, int H, int W, int C, int Ho, int Wo) {
   const int CPR = C / 8;
-  size_t total = (size_t)N * Ho * Wo * CPR;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    int cc = (int)(i % CPR);
-    size_t pix = i / CPR;
-    int wo = (int)(pix % Wo);
-    int ho = (int)((pix / Wo) % Ho);
-    int n = (int)(pix / ((size_t)Wo * Ho));
+  const uint32_t total = (uint32_t)N * Ho * Wo * CPR;          // 32-bit index arithmetic (the entry point checks the range): 64-bit div/mod
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {          // is emulated and dominated this kernel
+    int cc = (int)(i % (uint32_t)CPR);
+    uint32_t pix = i / (uint32_t)CPR;
+    int wo = (int)(pix % (uint32_t)Wo);
+    int ho = (int)((pix / (uint32_t)Wo) % (uint32_t)Ho);
+    int n = (int)(pix / ((uint32_t)Wo * Ho));
     float best[8];
     int bi[8];
 #pragma unroll
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, ui
         for (int e = 0; e < 8; ++e)
           if (v[e] > best[e] || bi[e] < 0) { best[e] = v[e]; bi[e] = r * 3 + s; }   // first maximum in scan order wins
       }
-    store8(out + pix * C + cc * 8, best);
-    uint8_t* ip = idx + pix * C + cc * 8;
+    store8(out + (size_t)pix * C + cc * 8, best);
+    uint8_t* ip = idx + (size_t)pix * C + cc * 8;
     uint32_t lo = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     uint32_t hi4 = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
     *(u32x2*)ip = u32x2{lo, hi4};
@@ -312,13 +312,13 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, ui
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const uint8_t* idx, T* dx, int N, int H, int W, int C, int Ho, int Wo) {
   const int CPR = C / 8;
-  size_t total = (size_t)N * H * W * CPR;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    int cc = (int)(i % CPR);
-    size_t pix = i / CPR;
-    int wi = (int)(pix % W);
-    int hi = (int)((pix / W) % H);
-    int n = (int)(pix / ((size_t)W * H));
+  const uint32_t total = (uint32_t)N * H * W * CPR;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int cc = (int)(i % (uint32_t)CPR);
+    uint32_t pix = i / (uint32_t)CPR;
+    int wi = (int)(pix % (uint32_t)W);
+    int hi = (int)((pix / (uint32_t)W) % (uint32_t)H);
+    int n = (int)(pix / ((uint32_t)W * H));
     float acc[8];
     zero8(acc);
     for (int r = 0; r < 3; ++r) {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* dout, const u
         }
       }
     }
-    store8(dx + pix * C + cc * 8, acc);
+    store8(dx + (size_t)pix * C + cc * 8, acc);
   }
 }
 
@@ -521,7 +521,7 @@ extern "C" int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout
 }
 
 extern "C" int clite_maxpool3x3s2_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream) {
-  if (C % 8 || N <= 0) return -1;
+  if (C % 8 || N <= 0 || (size_t)N * H * W * (C / 8) >= ((size_t)1 << 31)) return -1;
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   int grid = ew_grid((size_t)N * Ho * Wo * (C / 8));
   hipStream_t st = (hipStream_t)stream;
@@ -532,7 +532,7 @@ extern "C" int clite_maxpool3x3s2_fwd(int dtype, const void* x, void* out, uint8
 }
 
 extern "C" int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream) {
-  if (C % 8 || N <= 0) return -1;
+  if (C % 8 || N <= 0 || (size_t)N * H * W * (C / 8) >= ((size_t)1 << 31)) return -1;
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   int grid = ew_grid((size_t)N * H * W * (C / 8));
   hipStream_t st = (hipStream_t)stream;
