@@ -125,12 +125,13 @@ def _alloc(rt, *shape):
     return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
 
 
-def _linear_grads(rt, lin, dy, x, M, dw=None, db=None):
-    """dW[N][K] += dy^T x ; db += colsum(dy) for a LinearParams (or explicit arena views for fused q/k/v)."""
+def _linear_grads(rt, lin, dy, x, M, dw=None, db=None, bias_done=False):
+    """dW[N][K] += dy^T x ; db += colsum(dy) for a LinearParams (or explicit arena views for fused q/k/v). bias_done: the kernel that
+    produced dy already accumulated its column sums into the bias gradient (clite_layernorm_bwd's dcolsum)."""
     N, K = dy.shape[1], x.shape[1]
     if dw is None:
         dw = rt.arena.g(lin.weight) if lin.weight.requires_grad else None
-        db = rt.arena.g(lin.bias) if (lin.bias is not None and lin.bias.requires_grad) else None
+        db = rt.arena.g(lin.bias) if (lin.bias is not None and lin.bias.requires_grad and not bias_done) else None
 
     def launch():
         if dw is not None:
@@ -216,9 +217,10 @@ def bert_backward(rt, net, ctx, dpooled):
         # LayerNorm 2 -> (dropout) -> FFN
         ds2 = _alloc(rt, M, Hd)
         ds2m = _alloc(rt, M, Hd) if d2[0] > 0 else None
-        hip.layernorm_bwd(dt, dh, s2, st2, out.LayerNorm.weight, ds2, ds2m, A.g(out.LayerNorm.weight), A.g(out.LayerNorm.bias), M, Hd, drop_out=d2)
+        hip.layernorm_bwd(dt, dh, s2, st2, out.LayerNorm.weight, ds2, ds2m, A.g(out.LayerNorm.weight), A.g(out.LayerNorm.bias), M, Hd, drop_out=d2,
+                          dcolsum=A.g(out.dense.bias))
         dz2 = ds2m if ds2m is not None else ds2
-        _linear_grads(rt, out.dense, dz2, g, M)
+        _linear_grads(rt, out.dense, dz2, g, M, bias_done=True)
         df = _alloc(rt, M, inner)
         hip.gemm_nn(dt, dz2, A.w(out.dense.weight), M, inner, Hd, hip.epilogue(df, inner, dact_aux=f, dact=hip.DACT_GELU))
         _linear_grads(rt, layer.intermediate.dense, df, h1, M)
@@ -227,9 +229,10 @@ def bert_backward(rt, net, ctx, dpooled):
         # LayerNorm 1 -> (dropout) -> attention output projection
         ds1 = _alloc(rt, M, Hd)
         ds1m = _alloc(rt, M, Hd) if d1[0] > 0 else None
-        hip.layernorm_bwd(dt, dh1, s1, st1, so.LayerNorm.weight, ds1, ds1m, A.g(so.LayerNorm.weight), A.g(so.LayerNorm.bias), M, Hd, drop_out=d1)
+        hip.layernorm_bwd(dt, dh1, s1, st1, so.LayerNorm.weight, ds1, ds1m, A.g(so.LayerNorm.weight), A.g(so.LayerNorm.bias), M, Hd, drop_out=d1,
+                          dcolsum=A.g(so.dense.bias))
         dz1 = ds1m if ds1m is not None else ds1
-        _linear_grads(rt, so.dense, dz1, ctxt, M)
+        _linear_grads(rt, so.dense, dz1, ctxt, M, bias_done=True)
         dctx = _alloc(rt, M, Hd)
         hip.gemm_nn(dt, dz1, A.w(so.dense.weight), M, Hd, Hd, hip.epilogue(dctx, Hd))
         dqkv = _alloc(rt, M, 3 * Hd)
@@ -244,9 +247,8 @@ def bert_backward(rt, net, ctx, dpooled):
     emb = net.embeddings
     ds0 = _alloc(rt, M, Hd)
     hip.layernorm_bwd(dt, dh, ctx["s0"], ctx["st0"], emb.LayerNorm.weight, ds0, None, A.g(emb.LayerNorm.weight), A.g(emb.LayerNorm.bias), M, Hd,
-                      drop_in=ctx["d0"])
+                      drop_in=ctx["d0"], dcolsum=A.g(emb.token_type_embeddings.weight)[0])      # token_type_ids = 0: every row adds to row 0
     hip.embed_bwd(dt, ctx["ids"], ds0, A.g(emb.word_embeddings.weight), A.g(emb.position_embeddings.weight), M, L, Hd, net.vocab,
                   padding_idx=0)      # HF BertEmbeddings: nn.Embedding(vocab, hidden, padding_idx=pad_token_id = 0)
-    hip.colsum(dt, ds0, A.g(emb.token_type_embeddings.weight)[0], M, Hd)
     rt.join_aux()
     rt.grads_ready(emb)

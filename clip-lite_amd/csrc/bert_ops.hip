@@ -79,16 +79,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
 // per wave (256 workgroups of 8 waves) rather than trading waves for fewer adders.
 template <typename T, int NCH, int NW>
 __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const T* dy, const T* x, const float* stats, const float* gamma, T* dx, T* dx_masked,
-                                                                float* dgamma, float* dbeta, int M, int C, Drop drop_in, Drop drop_out) {
+                                                                float* dgamma, float* dbeta, float* dcolsum, int M, int C, Drop drop_in, Drop drop_out) {
   seed_resolve(drop_in.seed, drop_in.site);
   seed_resolve(drop_out.seed, drop_out.site);
   __shared__ float red[NW][64 * NCH * 8];   // [wave][per-lane partials], used once for dgamma and once for dbeta
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = C / 8;
   const float invC = 1.0f / (float)C;
-  float ag[NCH][8], ab[NCH][8];
+  float ag[NCH][8], ab[NCH][8], ax[NCH][8];      // ax: column sums of the stored gradient = bias gradient of the Linear that fed this LayerNorm
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) { zero8(ag[i]); zero8(ab[i]); }
+  for (int i = 0; i < NCH; ++i) { zero8(ag[i]); zero8(ab[i]); zero8(ax[i]); }
   for (int row = blockIdx.x * NW + wave; row < M; row += gridDim.x * NW) {
     float mean = stats[row * 2], rstd = stats[row * 2 + 1];
     float d[NCH][8], xh[NCH][8];          // g = d*gamma is re-formed in the second loop (gamma is L1-resident): 8*NCH fewer live registers
@@ -129,18 +129,24 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const T* dy, con
           if (drop_out.p > 0.f) apply_dropout8(drop_out, idx, o);
           store8(dx_masked + idx, o);
         }
+        if (dcolsum) {      // sums of what the consumer reads: the masked tensor when there is one, rounded to the storage type
+          if (sizeof(T) == 2) round8_bf16(o);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ax[i][e] += o[e];
+        }
       }
     }
   }
   // fold the 4 waves' partial dgamma/dbeta through LDS (two passes to bound LDS), one atomic per column per block
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < 3; ++which) {
+    if (which == 2 && !dcolsum) break;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) red[wave][(i * 64 + lane) * 8 + e] = which == 0 ? ag[i][e] : ab[i][e];
+      for (int e = 0; e < 8; ++e) red[wave][(i * 64 + lane) * 8 + e] = which == 0 ? ag[i][e] : which == 1 ? ab[i][e] : ax[i][e];
     __syncthreads();
-    float* dst = which == 0 ? dgamma : dbeta;
+    float* dst = which == 0 ? dgamma : which == 1 ? dbeta : dcolsum;
     if (dst) {
       for (int j = threadIdx.x; j < NCH * 64 * 8; j += NW * 64) {
         int i = j / 512, l = (j / 8) % 64, e = j % 8;
@@ -600,7 +606,7 @@ extern "C" int clite_layernorm_fwd(int dtype, const void* x, const float* gamma,
 }
 
 extern "C" int clite_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx, void* dx_masked,
-                                   float* dgamma, float* dbeta, int M, int C, float in_p, uint64_t in_seed, uint32_t in_site,
+                                   float* dgamma, float* dbeta, float* dcolsum, int M, int C, float in_p, uint64_t in_seed, uint32_t in_site,
                                    float out_p, uint64_t out_seed, uint32_t out_site, void* stream) {
   if (!ln_ok(M, C) || !dy || !x || !stats || !dx) return -1;
   constexpr int NW = 8, LN_BWD_MAX_WG = 256;
@@ -611,15 +617,15 @@ extern "C" int clite_layernorm_bwd(int dtype, const void* dy, const void* x, con
   if (C <= 1024) {
     constexpr int NCHV = 2;
     DISPATCH(dtype,
-             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV, NW>), dim3(grid), dim3(NW * 64), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
-             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV, NW>), dim3(grid), dim3(NW * 64), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
+             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV, NW>), dim3(grid), dim3(NW * 64), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, dcolsum, M, C, di, dout),
+             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV, NW>), dim3(grid), dim3(NW * 64), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, dcolsum, M, C, di, dout));
   } else {
     constexpr int NCHV = 4, NW4 = 8;      // 4 chunks per lane: 8 waves keep the row state in registers
     grid = (M + NW4 - 1) / NW4;
     if (grid > LN_BWD_MAX_WG) grid = LN_BWD_MAX_WG;
     DISPATCH(dtype,
-             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV, NW4>), dim3(grid), dim3(NW4 * 64), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, M, C, di, dout),
-             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV, NW4>), dim3(grid), dim3(NW4 * 64), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, M, C, di, dout));
+             hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV, NW4>), dim3(grid), dim3(NW4 * 64), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, dcolsum, M, C, di, dout),
+             hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV, NW4>), dim3(grid), dim3(NW4 * 64), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, dcolsum, M, C, di, dout));
   }
   return (int)hipGetLastError();
 }

@@ -75,7 +75,7 @@ _SIGNATURES = {
     "clite_image_to_nhwc4": [_I, _V, _V, _I, _I, _I, _I, _I, _I, _V],
     "clite_colsum": [_I, _V, _V, _I, _I, _V],
     "clite_layernorm_fwd": [_I, _V, _V, _V, _F, _V, _V, _I, _I, _F, _U64, _U32, _V],
-    "clite_layernorm_bwd": [_I, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _F, _U64, _U32, _F, _U64, _U32, _V],
+    "clite_layernorm_bwd": [_I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _F, _U64, _U32, _F, _U64, _U32, _V],
     "clite_embed_fwd": [_I, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_embed_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _I, _I, _V],
     "clite_attention_fwd": [_I, _V, _V, _V, _I, _I, _I, _F, _U64, _U32, _V],
@@ -318,8 +318,8 @@ def layernorm_fwd(dt, x, gamma, beta, eps, out, stats, M, Cc, drop=NO_DROP):
           "layernorm_fwd")
 
 
-def layernorm_bwd(dt, dy, x, stats, gamma, dx, dx_masked, dgamma, dbeta, M, Cc, drop_in=NO_DROP, drop_out=NO_DROP):
-    check(lib().clite_layernorm_bwd(dt, p(dy), p(x), p(stats), p(gamma), p(dx), p(dx_masked), p(dgamma), p(dbeta), M, Cc,
+def layernorm_bwd(dt, dy, x, stats, gamma, dx, dx_masked, dgamma, dbeta, M, Cc, drop_in=NO_DROP, drop_out=NO_DROP, dcolsum=None):
+    check(lib().clite_layernorm_bwd(dt, p(dy), p(x), p(stats), p(gamma), p(dx), p(dx_masked), p(dgamma), p(dbeta), p(dcolsum), M, Cc,
                                     drop_in[0], drop_in[1], drop_in[2], drop_out[0], drop_out[1], drop_out[2], stream_ptr(x)), "layernorm_bwd")
 
 

@@ -166,9 +166,11 @@ int clite_colsum(int dtype, const void* x, float* out, int M, int N, void* strea
 /* out = dropout(LayerNorm(x)); stats[row] = (mean, rstd) f32. C % 8 == 0, C <= 2048. Also nn.LayerNorm at loss.py:23. */
 int clite_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* out, float* stats,
                         int M, int C, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream);
-/* dx = LayerNorm backward of dropout_in(dy); dx_masked (optional) = dropout_out(dx); dgamma/dbeta (optional) += . */
+/* dx = LayerNorm backward of dropout_in(dy); dx_masked (optional) = dropout_out(dx); dgamma/dbeta (optional) += .
+ * dcolsum (optional, f32 [C]) += column sums of dx_masked (of dx when there is no masked output) as stored: the bias gradient of the
+ * nn.Linear whose output this LayerNorm normalised (BertSelfOutput.dense / BertOutput.dense; the token-type row of BertEmbeddings). */
 int clite_layernorm_bwd(int dtype, const void* dy, const void* x, const float* stats, const float* gamma, void* dx, void* dx_masked,
-                        float* dgamma, float* dbeta, int M, int C, float in_p, uint64_t in_seed, uint32_t in_site,
+                        float* dgamma, float* dbeta, float* dcolsum, int M, int C, float in_p, uint64_t in_seed, uint32_t in_site,
                         float out_p, uint64_t out_seed, uint32_t out_site, void* stream);
 /* BertEmbeddings sum: out[row] = word[ids[row]] + pos[row % L] + type[0] (token_type_ids = 0, position_ids = arange(L)) */
 int clite_embed_fwd(int dtype, const int64_t* ids, const void* word, const void* pos, const void* type, void* out,

@@ -149,13 +149,15 @@ def test_layernorm_fwd_bwd(dtype, M, Cc):
     _close(stats[:, 0], x.mean(1), 1e-5)
     dy, dyb = prep(rng.standard_normal((M, Cc), dtype=np.float32), dtype)
     dx = outbuf((M, Cc), dtype); dg = np.ones(Cc, np.float32); db = np.ones(Cc, np.float32)
-    L.clite_layernorm_bwd.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
-    assert L.clite_layernorm_bwd(dtype, ptr(dyb), ptr(xb), ptr(stats), ptr(g), ptr(dx), None, ptr(dg), ptr(db), M, Cc, 0.0, 0, 0, 0.0, 0, 0, None) == 0
+    dcs = np.ones(Cc, np.float32)
+    L.clite_layernorm_bwd.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
+    assert L.clite_layernorm_bwd(dtype, ptr(dyb), ptr(xb), ptr(stats), ptr(g), ptr(dx), None, ptr(dg), ptr(db), ptr(dcs), M, Cc, 0.0, 0, 0, 0.0, 0, 0, None) == 0
     gg = dy * g
     dxref = rstd * (gg - gg.mean(1, keepdims=True) - xh * (gg * xh).mean(1, keepdims=True))
     _close(val(dx, dtype), dxref, _tol(dtype))
     _close(dg, 1 + (dy * xh).sum(0), 1e-3)
     _close(db, 1 + dy.sum(0), 1e-3)
+    _close(dcs, 1 + val(dx, dtype).sum(0), 1e-4)        # column sums of dx as stored = bias gradient of the Linear in front of the LayerNorm
     # dropout: forward output mask == backward input mask == backward dx_masked mask for equal (seed, site)
     outd = outbuf((M, Cc), dtype)
     assert L.clite_layernorm_fwd(dtype, ptr(xb), ptr(g), ptr(b), 1e-12, ptr(outd), ptr(stats), M, Cc, 0.25, 1234, 7, None) == 0
@@ -164,8 +166,10 @@ def test_layernorm_fwd_bwd(dtype, M, Cc):
     assert abs(keep.mean() - 0.75) < 0.05
     _close(od[keep], (ref / 0.75)[keep], _tol(dtype))
     dxm = outbuf((M, Cc), dtype)
-    assert L.clite_layernorm_bwd(dtype, ptr(dyb), ptr(xb), ptr(stats), ptr(g), ptr(dx), ptr(dxm), None, None, M, Cc, 0.0, 0, 0, 0.25, 1234, 7, None) == 0
+    dcs[:] = 0
+    assert L.clite_layernorm_bwd(dtype, ptr(dyb), ptr(xb), ptr(stats), ptr(g), ptr(dx), ptr(dxm), None, None, ptr(dcs), M, Cc, 0.0, 0, 0, 0.25, 1234, 7, None) == 0
     assert np.array_equal(val(dxm, dtype) != 0, keep & (val(dx, dtype) != 0))
+    _close(dcs, val(dxm, dtype).sum(0), 1e-4)           # with a masked output, the sums are of the masked tensor
 
 
 @pytest.mark.parametrize("dtype", [BF16, F32])
