@@ -181,42 +181,63 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* ids, cons
   }
 }
 
-// dword[ids[row]] += d[row] (float atomics); rows whose id is padding_idx contribute nothing (nn.Embedding(padding_idx) semantics — and the
-// pad token is the one id thousands of rows share, i.e. the worst same-address atomic contention of the step)
+// dword[ids[row]] += d[row] for ids[row] != padding_idx (nn.Embedding(padding_idx) semantics), dpos[l] += sum_b d[b*L + l].
+// Workgroup = (position l, batch segment): a thread owns one 8-column chunk and walks the segment's captions at that position, so
+// (a) the position sum is a register accumulation, and (b) consecutive rows with the SAME token id — [CLS] at position 0 and [SEP] at the
+// last position of every caption — are summed in registers and leave as one atomic set per run instead of one per caption. (A kernel
+// with one atomic per row spent 100 us here: thousands of adders on the [CLS] / [SEP] rows serialise at the memory side.)
+constexpr int EMB_SEGS = 4, EMB_COLS = 16;      // C <= 128 * EMB_COLS
+DEV float ld1(const bf16* p) { return bf2f(*p); }
+DEV float ld1(const float* p) { return *p; }
 template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_word_kernel(const int64_t* ids, const T* d, float* dword, int M, int C, int vocab, int padding_idx) {
-  const int nchunk = C / 8;
-  size_t total = (size_t)M * nchunk;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    int c = (int)(i % nchunk);
-    int row = (int)(i / nchunk);
-    int64_t id = ids[row];
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d, float* __restrict__ dword, float* __restrict__ dpos,
+                                                        int B, int L, int C, int vocab, int padding_idx) {
+  const int l = blockIdx.x / EMB_SEGS, seg = blockIdx.x % EMB_SEGS;
+  const int per = (B + EMB_SEGS - 1) / EMB_SEGS;
+  const int b0 = seg * per, b1 = b0 + per < B ? b0 + per : B;
+  const int t = threadIdx.x;
+  // lane t owns columns t, t + 128, ...: a wave's float atomics then cover 256 contiguous bytes (the full-rate shape), and its 2-byte loads
+  // 128 contiguous bytes (the rows are small: 6 MB in all)
+  float pacc[EMB_COLS], wacc[EMB_COLS];
+#pragma unroll
+  for (int j = 0; j < EMB_COLS; ++j) { pacc[j] = 0.f; wacc[j] = 0.f; }
+  int64_t cur = -1;
+  auto flush = [&]() {
+    if (dword && cur >= 0 && cur != padding_idx) {
+#pragma unroll
+      for (int j = 0; j < EMB_COLS; ++j)
+        if (t + 128 * j < C) atomic_add_f32(dword + (size_t)cur * C + t + 128 * j, wacc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < EMB_COLS; ++j) wacc[j] = 0.f;
+  };
+  // the next caption's row is fetched before this one's atomics are issued (the loop is otherwise one load latency per caption)
+  float v[EMB_COLS], vn[EMB_COLS];
+  int64_t id = 0, idn = 0;
+  auto fetch = [&](int b, float (&dst)[EMB_COLS], int64_t& di) {
+    const size_t row = (size_t)b * L + l;
+    di = ids[row];
+#pragma unroll
+    for (int j = 0; j < EMB_COLS; ++j) dst[j] = t + 128 * j < C ? ld1(d + row * C + t + 128 * j) : 0.f;
+  };
+  if (b0 < b1) fetch(b0, vn, idn);
+  for (int b = b0; b < b1; ++b) {
+    id = idn;
+#pragma unroll
+    for (int j = 0; j < EMB_COLS; ++j) v[j] = vn[j];
+    if (b + 1 < b1) fetch(b + 1, vn, idn);
     if (id < 0) id = 0;
     if (id >= vocab) id = vocab - 1;
-    if (id == padding_idx) continue;
-    float v[8];
-    load8(d + (size_t)row * C + c * 8, v);
+    if (id != cur) { flush(); cur = id; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomic_add_f32(dword + (size_t)id * C + c * 8 + e, v[e]);
+    for (int j = 0; j < EMB_COLS; ++j) { pacc[j] += v[j]; wacc[j] += v[j]; }
   }
-}
-// dpos[l] += sum_b d[b*L + l]
-template <typename T>
-__global__ __launch_bounds__(256) void embed_bwd_pos_kernel(const T* d, float* dpos, int B, int L, int C) {
-  const int nchunk = C / 8;
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= L * nchunk) return;
-  int c = i % nchunk, l = i / nchunk;
-  float acc[8];
-  zero8(acc);
-  for (int b = 0; b < B; ++b) {
-    float v[8];
-    load8(d + ((size_t)b * L + l) * C + c * 8, v);
+  flush();
+  if (dpos && b1 > b0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    for (int j = 0; j < EMB_COLS; ++j)
+      if (t + 128 * j < C) atomic_add_f32(dpos + (size_t)l * C + t + 128 * j, pacc[j]);
   }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) dpos[(size_t)l * C + c * 8 + e] += acc[e];
 }
 
 // ------------------------------------------------------------------------------------------------ attention, L <= 32
@@ -643,19 +664,12 @@ extern "C" int clite_embed_fwd(int dtype, const int64_t* ids, const void* word, 
 
 extern "C" int clite_embed_bwd(int dtype, const int64_t* ids, const void* d, float* dword, float* dpos, int M, int L, int C, int vocab, int padding_idx,
                                void* stream) {
-  if (M <= 0 || L <= 0 || M % L || C % 8 || !ids || !d) return -1;
+  if (M <= 0 || L <= 0 || M % L || C % 8 || C > 128 * EMB_COLS || !ids || !d) return -1;
+  if (!dword && !dpos) return 0;
   hipStream_t st = (hipStream_t)stream;
-  int g1 = ew_grid((size_t)M * (C / 8)), g2 = (L * (C / 8) + 255) / 256;
-  if (dword) {
-    DISPATCH(dtype,
-             hipLaunchKernelGGL(embed_bwd_word_kernel<bf16>, dim3(g1), dim3(256), 0, st, ids, (const bf16*)d, dword, M, C, vocab, padding_idx),
-             hipLaunchKernelGGL(embed_bwd_word_kernel<float>, dim3(g1), dim3(256), 0, st, ids, (const float*)d, dword, M, C, vocab, padding_idx));
-  }
-  if (dpos) {
-    DISPATCH(dtype,
-             hipLaunchKernelGGL(embed_bwd_pos_kernel<bf16>, dim3(g2), dim3(256), 0, st, (const bf16*)d, dpos, M / L, L, C),
-             hipLaunchKernelGGL(embed_bwd_pos_kernel<float>, dim3(g2), dim3(256), 0, st, (const float*)d, dpos, M / L, L, C));
-  }
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(embed_bwd_kernel<bf16>, dim3(L * EMB_SEGS), dim3(128), 0, st, ids, (const bf16*)d, dword, dpos, M / L, L, C, vocab, padding_idx),
+           hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(L * EMB_SEGS), dim3(128), 0, st, ids, (const float*)d, dword, dpos, M / L, L, C, vocab, padding_idx));
   return (int)hipGetLastError();
 }
 

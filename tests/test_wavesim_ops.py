@@ -175,8 +175,10 @@ def test_layernorm_fwd_bwd(dtype, M, Cc):
 @pytest.mark.parametrize("dtype", [BF16, F32])
 def test_embedding_fwd_bwd(dtype):
     rng = np.random.default_rng(5)
-    B, Ls, Cc, V = 3, 7, 64, 50
+    B, Ls, Cc, V = 7, 7, 64, 50                     # 7 captions over 4 batch segments: uneven segments, runs of equal ids across captions
     ids = rng.integers(0, V, (B, Ls)).astype(np.int64)
+    ids[:, 0] = 5                                   # the same token at position 0 of every caption ([CLS])
+    ids[2:5, 3] = 9                                 # a run inside a column
     word, wb = prep(rng.standard_normal((V, Cc), dtype=np.float32), dtype)
     pos, pb = prep(rng.standard_normal((16, Cc), dtype=np.float32), dtype)
     typ, tb = prep(rng.standard_normal((2, Cc), dtype=np.float32), dtype)
