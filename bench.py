@@ -68,7 +68,7 @@ opt = O.build_optimizer(M.named_parameters())
 batch = {{"image": torch.randn(B, 3, 224, 224), "input_ids": torch.randint(1000, 30522, (B, 30)), "attention_mask": torch.ones(B, 30, dtype=torch.long)}}
 O.train_step(M, opt, batch, 0)
 n, t0 = 0, time.time()
-while n < 2 or (time.time() - t0 < 12 and n < 8):
+while n < 2 or (time.time() - t0 < 15 and n < 16):        # ~10-15 s of CPU work
     O.train_step(M, opt, batch, n + 1); n += 1
 dt = time.time() - t0
 print(json.dumps({{"value": B * n / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
@@ -89,7 +89,7 @@ def cpu_baseline(args):
 
 
 def pmc_traffic(args):
-    """HBM-side bytes of the igemm family per step (all 335 launches), from the committed PMC passes of this configuration
+    """HBM-side bytes of the igemm family per step (all its launches), from the committed PMC passes of this configuration
     (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be
     collected inside a timed run, so this is the profiles/ measurement, not a live one. None for other configurations."""
     if args.visual != "resnet50" or args.layers != 12 or args.batch != 128 or args.f32 or args.loss != "jsd":
