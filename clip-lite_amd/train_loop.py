@@ -124,8 +124,10 @@ class TrainStep:
         pool_main, pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
         graphs, keep = {}, {}
 
-        # data parallel: RCCL's watchdog / proxy threads keep making HIP calls of their own; only this thread's calls belong to the capture
-        mode = "thread_local" if self.exchange is not None else "global"
+        # other threads keep making HIP calls of their own during a capture — RCCL's watchdog / proxy threads in data parallel, the
+        # DataLoader's pin-memory thread in any real run (a capture in "global" mode is invalidated by them: hipErrorStreamCaptureInvalidated);
+        # only this thread's calls belong to the capture
+        mode = "thread_local"
 
         def capture(name, pool, fn):
             rt._zpools = {}                   # a segment zeroes the accumulators it uses itself
@@ -216,7 +218,7 @@ class TrainStep:
         saved_exchange, rt.exchange = rt.exchange, None      # no collectives inside a capture: the executors must not start buckets
         rt.begin_capture()
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):      # see _capture: other threads (pin-memory, RCCL) must not invalidate it
                 out = self.model(self._static_batch)
                 self.scaler.scale(out["loss"]).backward()
                 if self.exchange is None:
@@ -226,7 +228,7 @@ class TrainStep:
                 rt.end_capture()
             if self.exchange is not None:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g.pool()):
+                with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
                     self._capture_update()
                 self._g_update = g2
         except BaseException:
