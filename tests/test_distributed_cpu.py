@@ -48,6 +48,14 @@ def _worker(rank, world, port, tmp):
     # second step: nothing reported at all -> the whole arena is exchanged once
     arena.flat_g.copy_(mine)
     assert torch.allclose(arena.flat_g * ex.finish(), sum(allg) / world, atol=1e-6)
+    # third step: deferred mode (hard negatives / augmented views make the encoders run several times per step, so a module's "ready" report
+    # is premature): reports are ignored, more gradient arrives afterwards, finish() still reduces every element exactly once
+    ex.defer = True
+    arena.flat_g.copy_(mine * 0.5)
+    ex.region_ready(300, arena.total)
+    arena.flat_g.add_(mine * 0.5)                       # a second backward call adds to the same region after the report
+    assert torch.allclose(arena.flat_g * ex.finish(), sum(allg) / world, atol=1e-6)
+    ex.defer = False
     t = {"a": torch.tensor(float(rank))}
     D.average_across_processes(t)
     assert abs(t["a"].item() - (world - 1) / 2) < 1e-6
