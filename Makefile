@@ -10,8 +10,10 @@ SIMOBJS    := $(patsubst $(CSRC)/%.hip,build/sim/%.o,$(SRCS)) build/sim/wavesim.
 HIPFLAGS   := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wno-unused-value
 SIMFLAGS   := -x c++ -std=c++20 -O1 -g -fPIC -pthread -Itests/wavesim -Iinclude -I$(CSRC) -include tests/wavesim/wavesim.h -Wno-unknown-attributes -Wno-unused-value -Wno-psabi $(SIM_EXTRA)
 
-.PHONY: hip sim clean
+.PHONY: hip sim diag clean
 hip: $(LIBDIR)/libclite_hip.so
+# diagnostic build (tools/README.md): kernel-selection knobs from the environment + the round-1 register-staged engine; never loaded by the product
+diag: build/diag/libclite_hip_diag.so
 sim: tests/wavesim/_build/libclite_sim.so
 
 $(LIBDIR)/libclite_hip.so: $(OBJS)
@@ -21,6 +23,13 @@ $(LIBDIR)/libclite_hip.so: $(OBJS)
 build/hip/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/hip
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+DIAGOBJS   := $(patsubst $(CSRC)/%.hip,build/diag/%.o,$(SRCS))
+build/diag/libclite_hip_diag.so: $(DIAGOBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(DIAGOBJS)
+build/diag/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/diag
+	$(HIPCC) $(HIPFLAGS) -DCLITE_DIAG=1 $(DIAG_EXTRA) -c $< -o $@
 
 tests/wavesim/_build/libclite_sim.so: $(SIMOBJS)
 	@mkdir -p tests/wavesim/_build

@@ -4,6 +4,7 @@
 // loss.py:23), per-head attention forward/backward for captions of <= 32 tokens (config.py:69: 30).
 #include "vec.h"
 #include "rng.h"
+#include "det.h"
 #include "clite.h"
 
 using namespace clite;
@@ -192,7 +193,10 @@ DEV float ld1(const float* p) { return *p; }
 template <typename T>
 __global__ __launch_bounds__(128) void embed_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ d, float* __restrict__ dword, float* __restrict__ dpos,
                                                         int B, int L, int C, int vocab, int padding_idx) {
-  const int l = blockIdx.x / EMB_SEGS, seg = blockIdx.x % EMB_SEGS;
+  // (position, segment) pairs are walked grid-stride: normally one per workgroup; the deterministic-reduction mode (det.h) launches a single
+  // workgroup, whose threads own disjoint columns and add in program order
+  for (int blk = blockIdx.x; blk < L * EMB_SEGS; blk += gridDim.x) {
+  const int l = blk / EMB_SEGS, seg = blk % EMB_SEGS;
   const int per = (B + EMB_SEGS - 1) / EMB_SEGS;
   const int b0 = seg * per, b1 = b0 + per < B ? b0 + per : B;
   const int t = threadIdx.x;
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(128) void embed_bwd_kernel(const int64_t* __restric
 #pragma unroll
     for (int j = 0; j < EMB_COLS; ++j)
       if (t + 128 * j < C) atomic_add_f32(dpos + (size_t)l * C + t + 128 * j, pacc[j]);
+  }
   }
 }
 
@@ -631,8 +636,10 @@ extern "C" int clite_layernorm_bwd(int dtype, const void* dy, const void* x, con
                                    float out_p, uint64_t out_seed, uint32_t out_site, void* stream) {
   if (!ln_ok(M, C) || !dy || !x || !stats || !dx) return -1;
   constexpr int NW = 8, LN_BWD_MAX_WG = 256;
+  const bool det = clite::deterministic();      // det.h: one workgroup -> one contribution per parameter-gradient address
   int grid = (M + NW - 1) / NW;
   if (grid > LN_BWD_MAX_WG) grid = LN_BWD_MAX_WG;
+  if (det) grid = 1;
   Drop di{in_p, in_seed, in_site}, dout{out_p, out_seed, out_site};
   hipStream_t st = (hipStream_t)stream;
   if (C <= 1024) {
@@ -644,6 +651,7 @@ extern "C" int clite_layernorm_bwd(int dtype, const void* dy, const void* x, con
     constexpr int NCHV = 4, NW4 = 8;      // 4 chunks per lane: 8 waves keep the row state in registers
     grid = (M + NW4 - 1) / NW4;
     if (grid > LN_BWD_MAX_WG) grid = LN_BWD_MAX_WG;
+    if (det) grid = 1;
     DISPATCH(dtype,
              hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, NCHV, NW4>), dim3(grid), dim3(NW4 * 64), 0, st, (const bf16*)dy, (const bf16*)x, stats, gamma, (bf16*)dx, (bf16*)dx_masked, dgamma, dbeta, dcolsum, M, C, di, dout),
              hipLaunchKernelGGL((layernorm_bwd_kernel<float, NCHV, NW4>), dim3(grid), dim3(NW4 * 64), 0, st, (const float*)dy, (const float*)x, stats, gamma, (float*)dx, (float*)dx_masked, dgamma, dbeta, dcolsum, M, C, di, dout));
@@ -667,9 +675,10 @@ extern "C" int clite_embed_bwd(int dtype, const int64_t* ids, const void* d, flo
   if (M <= 0 || L <= 0 || M % L || C % 8 || C > 128 * EMB_COLS || !ids || !d) return -1;
   if (!dword && !dpos) return 0;
   hipStream_t st = (hipStream_t)stream;
+  const int egrid = clite::deterministic() ? 1 : L * EMB_SEGS;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(embed_bwd_kernel<bf16>, dim3(L * EMB_SEGS), dim3(128), 0, st, ids, (const bf16*)d, dword, dpos, M / L, L, C, vocab, padding_idx),
-           hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(L * EMB_SEGS), dim3(128), 0, st, ids, (const float*)d, dword, dpos, M / L, L, C, vocab, padding_idx));
+           hipLaunchKernelGGL(embed_bwd_kernel<bf16>, dim3(egrid), dim3(128), 0, st, ids, (const bf16*)d, dword, dpos, M / L, L, C, vocab, padding_idx),
+           hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(egrid), dim3(128), 0, st, ids, (const float*)d, dword, dpos, M / L, L, C, vocab, padding_idx));
   return (int)hipGetLastError();
 }
 

@@ -1,8 +1,13 @@
 // Host launchers (C ABI, include/clite.h) for the implicit-GEMM engine in igemm.h.
 #include "igemm_dma.h"
+#include "det.h"
+#include <atomic>
 #include <stdlib.h>
 
 using namespace clite;
+
+static std::atomic<int> g_deterministic{0};
+bool clite::deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
 
 namespace {
 
@@ -38,22 +43,27 @@ template <typename T> struct Cfg {
   typedef TileCfg<128, 64, BK, 32, 64> C128x64;     // ... or <= 64 (r, s, ci) columns
 };
 
-// The LDS-DMA pipelined kernel is the default; CLITE_IGEMM_LEGACY=1 selects the register-staged kernel (A/B timing, debugging).
-bool use_dma() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CLITE_IGEMM_LEGACY"); v = (e && e[0] == '1') ? 0 : 1; }
-  return v == 1;
-}
-int stages_pref() {      // CLITE_IGEMM_STAGES=3|4 forces a ring depth (timing experiments); default: chosen per launch
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CLITE_IGEMM_STAGES"); v = e ? atoi(e) : 0; }
-  return v;
-}
-int g2_pref() {          // CLITE_IGEMM_G2=0 disables, =2 forces the two-K-group kernel (timing experiments); default 1: small grids only
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CLITE_IGEMM_G2"); v = e ? atoi(e) : 1; }
-  return v;
-}
+// Kernel-selection knobs. The product library has none: every choice below is a fixed function of the problem shape. A diagnostic build
+// (-DCLITE_DIAG=1, tools/README.md) reads them from the environment for A/B timing and also carries the round-1 register-staged engine.
+#ifndef CLITE_DIAG
+#define CLITE_DIAG 0
+#endif
+#if CLITE_DIAG
+int diag_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+bool use_dma() { static int v = -1; if (v < 0) v = diag_env("CLITE_IGEMM_LEGACY", 0) ? 0 : 1; return v == 1; }
+int stages_pref() { static int v = -1; if (v < 0) v = diag_env("CLITE_IGEMM_STAGES", 0); return v; }     // 3|4 forces a ring depth
+int g2_pref() { static int v = -1; if (v < 0) v = diag_env("CLITE_IGEMM_G2", 1); return v; }              // 0 off, 2 forces the two-K-group kernel
+int xcd_split_pref() { static int v = -1; if (v < 0) v = diag_env("CLITE_XCD_SPLIT", 1); return v; }
+int split_target_pref() { static int v = -1; if (v < 0) v = diag_env("CLITE_SPLIT_TARGET", 0); return v; }
+int splitk_ws_pref() { static int v = -1; if (v < 0) v = diag_env("CLITE_SPLITK_WS", 1); return v; }
+#else
+constexpr bool use_dma() { return true; }
+constexpr int stages_pref() { return 0; }
+constexpr int g2_pref() { return 1; }
+constexpr int xcd_split_pref() { return 1; }
+constexpr int split_target_pref() { return 0; }
+constexpr int splitk_ws_pref() { return 1; }
+#endif
 template <class L> struct IsDgrad { static constexpr bool value = false; };
 template <typename T, int ROWS, int BK> struct IsDgrad<GatherKC<T, ROWS, BK, true>> { static constexpr bool value = true; };
 template <class L> struct ToDma;
@@ -70,18 +80,84 @@ template <typename T, int COLS, int BK> struct ToDma<GatherXC<T, COLS, BK>> {
   static type make(const GatherXC<T, COLS, BK>& l) { return type{l.ptr, l.bytes, l.g}; }
 };
 
+// ---- deterministic-reduction mode (det.h): column statistics of a GEMM output, from the stored tensor ---------------------------
+// Same quantities as the fused epilogues accumulate (sum v, sum v^2 of the stored values; or sum v, sum v*(bn_y - mean) when bn_y is set),
+// but each (replica, column) address receives exactly one contribution: row slab s of the GEMM rows goes to replica s, the 8 row lanes of
+// a workgroup fold through LDS in lane order, and a thread walks its rows in increasing order.
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_det_kernel(clite_epilogue ep, RowMap rm, int M, int N, int rows_per_slab) {
+  __shared__ float red[8][32 * 16];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cx) * 8;
+  const bool cvalid = col < N;
+  float mean[8], s1[8], s2[8];
+  zero8(mean); zero8(s1); zero8(s2);
+  if (cvalid && ep.bn_y) {
+    for (int r = 0; r < ep.bn_replicas; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mean[e] += ep.bn_stats[(size_t)r * ep.bn_rstride + col + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mean[e] *= ep.bn_inv_count;
+  }
+  int row_begin = blockIdx.y * rows_per_slab, row_end = row_begin + rows_per_slab;
+  if (row_end > M) row_end = M;
+  if (cvalid) {
+    for (int r = row_begin + ry; r < row_end; r += 8) {
+      const size_t idx = map_row(rm, r) * ep.ldc + col;
+      float v[8];
+      if (ep.out_f32 || sizeof(T) == 4) load8((const float*)ep.out + idx, v); else load8((const T*)ep.out + idx, v);
+      if (ep.bn_y) {
+        float y[8];
+        load8((const T*)ep.bn_y + idx, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * (y[e] - mean[e]); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[ry][cx * 16 + e] = s1[e]; red[ry][cx * 16 + 8 + e] = s2[e]; }
+  __syncthreads();
+  float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)blockIdx.y * ep.colsum_stride : 0);
+  for (int j = threadIdx.x; j < 32 * 16; j += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += red[r][j];
+    const int e = j & 15, c = (blockIdx.x * 32 + (j >> 4)) * 8 + (e & 7);
+    if (c < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + c, s);      // the only contribution to this address in this launch
+  }
+}
+template <typename T>
+int colstats_det(const clite_epilogue& ep, const RowMap& rm, int M, int N, hipStream_t st) {
+  int slabs = ep.colsum_replicas > 1 ? ep.colsum_replicas : 1;
+  if (slabs > M) slabs = M;
+  int rps = (M + slabs - 1) / slabs;
+  slabs = (M + rps - 1) / rps;
+  hipLaunchKernelGGL(colstats_det_kernel<T>, dim3((N / 8 + 31) / 32, slabs), dim3(256), 0, st, ep, rm, M, N, rps);
+  return (int)hipGetLastError();
+}
+
 template <typename T, class CFG, class LA, class LB>
 int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, int Ktot, int splits, hipStream_t st, RowMap rm = RowMap{}) {
+  if (deterministic()) {
+    if (ep.colsum) {       // statistics from the stored tensor, one contribution per address (colstats_det_kernel)
+      clite_epilogue e2 = ep;
+      e2.colsum = nullptr;
+      int rc = launch<T, CFG>(la, lb, e2, M, N, Ktot, splits, st, rm);
+      return rc ? rc : colstats_det<T>(ep, rm, M, N, st);
+    }
+    splits = 1;            // one workgroup per output tile over the whole K range: a single add per address
+  }
   int ktiles = (Ktot + CFG::BK - 1) / CFG::BK;
   if (splits < 1) splits = 1;
   if (splits > ktiles) splits = ktiles;
   int per = (ktiles + splits - 1) / splits;
   splits = (ktiles + per - 1) / per;
   int tiles = ((M + CFG::BM - 1) / CFG::BM) * ((N + CFG::BN - 1) / CFG::BN);
-  // >= 8 K splits: 1-D grid in which each XCD owns whole splits (igemm_dma.h); CLITE_XCD_SPLIT=0 keeps the (tile, split) grid
-  static int xs_pref = -1;
-  if (xs_pref < 0) { const char* e = getenv("CLITE_XCD_SPLIT"); xs_pref = e ? atoi(e) : 1; }
-  const int xsplits = (xs_pref && splits >= 8 && use_dma()) ? splits : 0;
+  // >= 8 K splits: 1-D grid in which each XCD owns whole splits (igemm_dma.h)
+  const int xsplits = (xcd_split_pref() && splits >= 8 && use_dma()) ? splits : 0;
   const dim3 grid = xsplits ? dim3(8 * ((splits + 7) / 8) * tiles, 1, 1) : dim3(tiles, 1, splits);
   if (use_dma()) {
     typedef typename ToDma<LA>::type DA;
@@ -120,7 +196,9 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
       hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
                          M, N, ktiles, per, xsplits);
   } else {
+#if CLITE_DIAG
     hipLaunchKernelGGL((igemm_kernel<T, CFG, LA, LB>), dim3(tiles, 1, splits), dim3(256), 0, st, la, lb, ep, rm, M, N, ktiles, per);
+#endif
   }
   return (int)hipGetLastError();
 }
@@ -130,8 +208,7 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
 // never below 8 K tiles per split.
 int pick_splits(int M, int N, int ktiles, int BM = 128, int BN = 128, bool window = false) {
   long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-  static int target = -1;       // CLITE_SPLIT_TARGET: workgroups to aim for (timing experiments)
-  if (target < 0) { const char* e = getenv("CLITE_SPLIT_TARGET"); target = e ? atoi(e) : 0; }
+  const int target = split_target_pref();
   // measured inside the step (tools/layer_profile.py): dense / 1x1 weight gradients with few output tiles are fastest at ~1
   // workgroup per CU (BERT 768x768: 39 -> 32 us; the 1x1 convs 5-15 % faster), windowed (3x3, 7x7) ones and larger outputs at ~2
   long tgt = target > 0 ? target : ((tiles < 64 && !window) ? 256 : 512);
@@ -223,9 +300,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 // number of K splits for the workspace form, or 0 when the launch does not qualify
 template <typename T>
 int splitk_plan(const clite_epilogue& ep, int M, int N, int ktiles) {
-  if (sizeof(T) != 2 || !ep.splitk_ws || ep.atomic || ep.drop_p > 0.f || ep.bn_y || ep.mask_after_residual || N % 8) return 0;
-  static int pref = -1;      // CLITE_SPLITK_WS=0 disables, =n aims for n workgroups (A/B timing)
-  if (pref < 0) { const char* e = getenv("CLITE_SPLITK_WS"); pref = e ? atoi(e) : 1; }
+  if (deterministic() || sizeof(T) != 2 || !ep.splitk_ws || ep.atomic || ep.drop_p > 0.f || ep.bn_y || ep.mask_after_residual || N % 8) return 0;
+  const int pref = splitk_ws_pref();
   if (!pref) return 0;
   // every split adds a full f32 tile of atomic traffic (64 KB; chip-wide ~1.3 TB/s): ~64 workgroups balance that against the number of
   // CUs fetching the weights (tools/probe_heads.py, sum over the heads' shapes: no split 482 us, 32 -> 371, 64 -> 339, 128 -> 357, 256 -> 425)
@@ -499,6 +575,8 @@ int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K, int lda
 }  // namespace
 
 extern "C" int clite_abi_version(void) { return CLITE_ABI_VERSION; }
+extern "C" int clite_set_deterministic(int on) { g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed); return 0; }
+extern "C" int clite_get_deterministic(void) { return deterministic() ? 1 : 0; }
 #if CLITE_STAMP
 extern "C" int clite_dbg_read(unsigned long long* host, int n) {     // diagnostic builds only
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clite_dbg), (size_t)n * 8, 0, hipMemcpyDeviceToHost);

@@ -676,6 +676,9 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
   }
 }
 
+#if defined(CLITE_DIAG) && CLITE_DIAG
+// Round-1 register-staged engine (global -> VGPR -> ds_write_b128, two LDS stages): diagnostic builds only, as the A/B yardstick for the
+// LDS-DMA kernels of igemm_dma.h. The product library does not contain it.
 template <typename T, class CFG, class LA, class LB>
 __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
@@ -770,6 +773,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(LA la, LB lb, Epilogue ep, R
 
   igemm_epilogue<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
 }
+
+#endif  // CLITE_DIAG
 
 }  // namespace clite
 #endif  // CLITE_IGEMM_H

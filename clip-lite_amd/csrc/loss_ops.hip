@@ -5,6 +5,7 @@
 // one wave owns one sample.
 #include "vec.h"
 #include "rng.h"
+#include "det.h"
 #include "clite.h"
 
 using namespace clite;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void critic_fwd_kernel(const T* f1, const T* f
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D / 8;
   const float tscale = expf(temperature[0]);
-  for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
+  for (int n = blockIdx.x * (blockDim.x >> 6) + wave; n < B; n += gridDim.x * (blockDim.x >> 6)) {
     int n1 = neg ? neg[n] : (n + 1 == B ? 0 : n + 1);
     float a[CR_MAXCH][8], b[CR_MAXCH][8], c[CR_MAXCH][8];
     load_row(f1 + (size_t)n * D, nchunk, lane, a);
@@ -68,7 +69,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void l2_normalize_kernel(const T* x, T* out, int B, int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D / 8;
-  for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
+  for (int n = blockIdx.x * (blockDim.x >> 6) + wave; n < B; n += gridDim.x * (blockDim.x >> 6)) {
     float a[CR_MAXCH][8];
     load_row(x + (size_t)n * D, nchunk, lane, a);
     float inv = 1.0f / fmaxf(sqrtf(dot_rows(a, a)), 1e-12f);
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const T* x, T* out, i
 __global__ __launch_bounds__(256) void infonce_lse_kernel(const float* Cm, int sr, int se, int B, const float* temperature, float* lse, float* acc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float t = expf(temperature[0]);
-  for (int i = blockIdx.x * 4 + wave; i < B; i += gridDim.x * 4) {
+  for (int i = blockIdx.x * (blockDim.x >> 6) + wave; i < B; i += gridDim.x * (blockDim.x >> 6)) {
     const float* line = Cm + (size_t)i * sr;
     float m = -INFINITY;
     for (int j = lane; j < B; j += 64) m = fmaxf(m, t * line[(size_t)j * se]);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void infonce_bwd_kernel(const float* Cm, int l
   const float t = expf(temperature[0]);
   const float g = gout[0] * scale / (2.0f * (float)B);
   float dt = 0.f;
-  for (int i = blockIdx.x * 4 + wave; i < B; i += gridDim.x * 4) {
+  for (int i = blockIdx.x * (blockDim.x >> 6) + wave; i < B; i += gridDim.x * (blockDim.x >> 6)) {
     const float lr = lse_r[i];
     for (int j0 = lane * 8; j0 < ldd; j0 += 64 * 8) {
       float o[8];
@@ -142,7 +143,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void l2_normalize_bwd_kernel(const T* x, const T* y, const T* dy, T* dx, int B, int D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D / 8;
-  for (int n = blockIdx.x * 4 + wave; n < B; n += gridDim.x * 4) {
+  for (int n = blockIdx.x * (blockDim.x >> 6) + wave; n < B; n += gridDim.x * (blockDim.x >> 6)) {
     float a[CR_MAXCH][8], yv[CR_MAXCH][8], d[CR_MAXCH][8];
     load_row(x + (size_t)n * D, nchunk, lane, a);
     load_row(y + (size_t)n * D, nchunk, lane, yv);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void critic_bwd_kernel(const T* f1, const T* f
   const int nchunk = D / 8;
   const float tscale = expf(temperature[0]);
   const float g = gout[0] * scale / (float)B;
-  for (int m = blockIdx.x * 4 + wave; m < B; m += gridDim.x * 4) {
+  for (int m = blockIdx.x * (blockDim.x >> 6) + wave; m < B; m += gridDim.x * (blockDim.x >> 6)) {
     // m1: the negative partner of row m; mp: the row whose negative partner is m (inverse permutation)
     int m1 = neg ? neg[m] : (m + 1 == B ? 0 : m + 1), mp = neg_inv ? neg_inv[m] : (m == 0 ? B - 1 : m - 1);
     const float* w = work + (size_t)m * 8;
@@ -207,7 +208,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void prior_tail_fwd_kernel(const T* h1, const float* w2, const float* b2, int B, int K, int softplus, float* logit, float* acc) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = K / 8;
-  for (int r = blockIdx.x * 4 + wave; r < 2 * B; r += gridDim.x * 4) {
+  for (int r = blockIdx.x * (blockDim.x >> 6) + wave; r < 2 * B; r += gridDim.x * (blockDim.x >> 6)) {
     float s = 0.f;
     for (int c = lane; c < nchunk; c += 64) {
       float h[8], w[8];
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void prior_tail_bwd_kernel(const T* h1, const 
 #pragma unroll
   for (int e = 0; e < 8; ++e) aw[e] = 0.f;
   const bool one_chunk = nchunk <= 64;
-  for (int r = blockIdx.x * 4 + wave; r < 2 * B; r += gridDim.x * 4) {
+  for (int r = blockIdx.x * (blockDim.x >> 6) + wave; r < 2 * B; r += gridDim.x * (blockDim.x >> 6)) {
     float d = sigmoid_f(logit[r]);
     float gl = r < B ? -(1.f - d) * g : d * g;       // d(-log D) = -(1-D), d(-log(1-D)) = D
     for (int c = lane; c < nchunk; c += 64) {
@@ -305,6 +306,10 @@ __global__ __launch_bounds__(256) void uniform_fill_kernel(T* out, size_t n, uin
 
 }  // namespace
 
+// deterministic-reduction mode (det.h): the kernels that add into shared scalars / weight rows run as ONE wave (grid 1 x 64 threads;
+// the kernels stride over samples by the waves actually launched), so every sum is formed in sample order
+#define DET_SINGLE_WAVE(grid) const bool det_ = clite::deterministic(); if (det_) (grid) = 1
+#define DET_BLOCK (det_ ? dim3(64) : dim3(256))
 #define DISPATCH(dtype, CALL_BF16, CALL_F32) \
   if ((dtype) == CLITE_BF16) { CALL_BF16; } else if ((dtype) == CLITE_F32) { CALL_F32; } else return -1;
 
@@ -313,9 +318,10 @@ extern "C" int clite_critic_jsd_fwd(int dtype, const void* f1, const void* f2, c
   if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !f1 || !f2 || !work || !acc) return -1;
   int grid = (B + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
+  DET_SINGLE_WAVE(grid);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(critic_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, B, D, neg, work, acc),
-           hipLaunchKernelGGL(critic_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, B, D, neg, work, acc));
+           hipLaunchKernelGGL(critic_fwd_kernel<bf16>, dim3(grid), DET_BLOCK, 0, st, (const bf16*)f1, (const bf16*)f2, temperature, B, D, neg, work, acc),
+           hipLaunchKernelGGL(critic_fwd_kernel<float>, dim3(grid), DET_BLOCK, 0, st, (const float*)f1, (const float*)f2, temperature, B, D, neg, work, acc));
   return (int)hipGetLastError();
 }
 extern "C" int clite_l2_normalize(int dtype, const void* x, void* out, int B, int D, void* stream) {
@@ -332,8 +338,9 @@ extern "C" int clite_infonce_fwd(const float* Cm, int ld, int B, const float* te
   if (B <= 0 || ld < B || !Cm || !temperature || !lse_r || !lse_c || !acc) return -1;
   int grid = (B + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(infonce_lse_kernel, dim3(grid), dim3(256), 0, st, Cm, ld, 1, B, temperature, lse_r, acc);          // rows: image -> text
-  hipLaunchKernelGGL(infonce_lse_kernel, dim3(grid), dim3(256), 0, st, Cm, 1, ld, B, temperature, lse_c, acc + 1);      // columns: text -> image
+  DET_SINGLE_WAVE(grid);
+  hipLaunchKernelGGL(infonce_lse_kernel, dim3(grid), DET_BLOCK, 0, st, Cm, ld, 1, B, temperature, lse_r, acc);          // rows: image -> text
+  hipLaunchKernelGGL(infonce_lse_kernel, dim3(grid), DET_BLOCK, 0, st, Cm, 1, ld, B, temperature, lse_c, acc + 1);      // columns: text -> image
   return (int)hipGetLastError();
 }
 extern "C" int clite_infonce_bwd(int dtype, const float* Cm, int ld, int B, const float* temperature, const float* lse_r, const float* lse_c,
@@ -341,9 +348,10 @@ extern "C" int clite_infonce_bwd(int dtype, const float* Cm, int ld, int B, cons
   if (B <= 0 || ld < B || ldd < B || ldd % 8 || !Cm || !temperature || !lse_r || !lse_c || !gout || !dC) return -1;
   int grid = (B + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
+  DET_SINGLE_WAVE(grid);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(infonce_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, Cm, ld, B, temperature, lse_r, lse_c, gout, scale, (bf16*)dC, ldd, dtemp),
-           hipLaunchKernelGGL(infonce_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, Cm, ld, B, temperature, lse_r, lse_c, gout, scale, (float*)dC, ldd, dtemp));
+           hipLaunchKernelGGL(infonce_bwd_kernel<bf16>, dim3(grid), DET_BLOCK, 0, st, Cm, ld, B, temperature, lse_r, lse_c, gout, scale, (bf16*)dC, ldd, dtemp),
+           hipLaunchKernelGGL(infonce_bwd_kernel<float>, dim3(grid), DET_BLOCK, 0, st, Cm, ld, B, temperature, lse_r, lse_c, gout, scale, (float*)dC, ldd, dtemp));
   return (int)hipGetLastError();
 }
 extern "C" int clite_l2_normalize_bwd(int dtype, const void* x, const void* y, const void* dy, void* dx, int B, int D, void* stream) {
@@ -361,9 +369,10 @@ extern "C" int clite_critic_jsd_bwd(int dtype, const void* f1, const void* f2, c
   if (B <= 0 || D % 8 || D > 64 * CR_MAXCH * 8 || !f1 || !f2 || !work || !gout || !df1 || !df2 || (!neg) != (!neg_inv)) return -1;
   int grid = (B + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
+  DET_SINGLE_WAVE(grid);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(critic_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)f1, (const bf16*)f2, temperature, work, gout, scale, B, D, neg, neg_inv, (bf16*)df1, (bf16*)df2, dtemp),
-           hipLaunchKernelGGL(critic_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f1, (const float*)f2, temperature, work, gout, scale, B, D, neg, neg_inv, (float*)df1, (float*)df2, dtemp));
+           hipLaunchKernelGGL(critic_bwd_kernel<bf16>, dim3(grid), DET_BLOCK, 0, st, (const bf16*)f1, (const bf16*)f2, temperature, work, gout, scale, B, D, neg, neg_inv, (bf16*)df1, (bf16*)df2, dtemp),
+           hipLaunchKernelGGL(critic_bwd_kernel<float>, dim3(grid), DET_BLOCK, 0, st, (const float*)f1, (const float*)f2, temperature, work, gout, scale, B, D, neg, neg_inv, (float*)df1, (float*)df2, dtemp));
   return (int)hipGetLastError();
 }
 extern "C" int clite_prior_tail_fwd(int dtype, const void* h1, const float* w2, const float* b2, int B, int K, int softplus, float* logit, float* acc,
@@ -371,9 +380,10 @@ extern "C" int clite_prior_tail_fwd(int dtype, const void* h1, const float* w2, 
   if (B <= 0 || K % 8 || !h1 || !w2 || !b2 || !logit || !acc) return -1;
   int grid = (2 * B + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
+  DET_SINGLE_WAVE(grid);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(prior_tail_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)h1, w2, b2, B, K, softplus, logit, acc),
-           hipLaunchKernelGGL(prior_tail_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)h1, w2, b2, B, K, softplus, logit, acc));
+           hipLaunchKernelGGL(prior_tail_fwd_kernel<bf16>, dim3(grid), DET_BLOCK, 0, st, (const bf16*)h1, w2, b2, B, K, softplus, logit, acc),
+           hipLaunchKernelGGL(prior_tail_fwd_kernel<float>, dim3(grid), DET_BLOCK, 0, st, (const float*)h1, w2, b2, B, K, softplus, logit, acc));
   return (int)hipGetLastError();
 }
 extern "C" int clite_prior_tail_bwd(int dtype, const void* h1, const float* w2, const float* logit, const float* gout, float scale, int B, int K,
@@ -382,9 +392,10 @@ extern "C" int clite_prior_tail_bwd(int dtype, const void* h1, const float* w2, 
   int grid = (2 * B + 3) / 4;
   if (grid > 16) grid = 16;          // <= 64 waves add into dw2 / db2 (see the kernel)
   hipStream_t st = (hipStream_t)stream;
+  DET_SINGLE_WAVE(grid);
   DISPATCH(dtype,
-           hipLaunchKernelGGL(prior_tail_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)h1, w2, logit, gout, scale, B, K, (bf16*)dh1, dw2, db2),
-           hipLaunchKernelGGL(prior_tail_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)h1, w2, logit, gout, scale, B, K, (float*)dh1, dw2, db2));
+           hipLaunchKernelGGL(prior_tail_bwd_kernel<bf16>, dim3(grid), DET_BLOCK, 0, st, (const bf16*)h1, w2, logit, gout, scale, B, K, (bf16*)dh1, dw2, db2),
+           hipLaunchKernelGGL(prior_tail_bwd_kernel<float>, dim3(grid), DET_BLOCK, 0, st, (const float*)h1, w2, logit, gout, scale, B, K, (float*)dh1, dw2, db2));
   return (int)hipGetLastError();
 }
 extern "C" int clite_loss_finalize(const float* acc, float prior_weight, float* out, void* stream) {

@@ -4,6 +4,7 @@
 // (optim/lookahead.py:88-101), and the bf16 weight copy the next forward reads — one pass over flat buffers.
 // Pure HBM streaming: per element 4 f32 reads (p, g, v, slow on sync steps) and up to 4 writes.
 #include "vec.h"
+#include "det.h"
 #include "clite.h"
 
 using namespace clite;
@@ -86,6 +87,7 @@ extern "C" int clite_sumsq(const float* x, uint64_t n, float* out, void* stream)
   if (!x || !out) return -1;
   size_t g = (n / 4 + 255) / 256;
   int grid = (int)(g < 2048 ? (g ? g : 1) : 2048);
+  if (clite::deterministic()) grid = 1;       // det.h: a single workgroup forms the whole sum in one order
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
   return (int)hipGetLastError();
 }

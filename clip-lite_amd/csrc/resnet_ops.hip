@@ -4,6 +4,7 @@
 // All tensors are NHWC with C % 8 == 0; each lane moves 16-byte (bf16) / 32-byte (f32) vectors; per-channel
 // reductions are folded through LDS and leave the workgroup as one float atomic per channel.
 #include "vec.h"
+#include "det.h"
 #include "clite.h"
 
 using namespace clite;
@@ -274,6 +275,17 @@ int bn_grid(int M, int C, int* rows_per_block) {
   *rows_per_block = spb * RPS;
   return (M + *rows_per_block - 1) / *rows_per_block;
 }
+// deterministic-reduction mode (det.h): workgroup b adds into replica b % R, so at most R workgroups -> one contribution per address
+int bn_grid_reduce(int M, int C, int R, int* rows_per_block) {
+  int grid = bn_grid(M, C, rows_per_block);
+  if (clite::deterministic() && grid > R) {
+    int RPS = 256 / (C / 8);
+    int sweeps = (M + RPS - 1) / RPS;
+    *rows_per_block = ((sweeps + R - 1) / R) * RPS;
+    grid = (M + *rows_per_block - 1) / *rows_per_block;
+  }
+  return grid;
+}
 int bn_ok(int M, int C) { return M > 0 && C >= 8 && C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0; }
 
 // ------------------------------------------------------------------------------------------------ pooling
@@ -474,7 +486,7 @@ extern "C" int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const
 extern "C" int clite_bn_centered_var(int dtype, const void* y, float* stats, int replicas, int rstride, int M, int C, void* stream) {
   if (!bn_ok(M, C) || !y || !stats || replicas < 1) return -1;
   int rpb;
-  int grid = bn_grid(M, C, &rpb);
+  int grid = bn_grid_reduce(M, C, replicas, &rpb);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
            hipLaunchKernelGGL(bn_centered_var_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)y, stats, replicas, rstride, M, C, rpb),
@@ -486,7 +498,7 @@ extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask
                                    int M, int C, void* stream) {
   if (!bn_ok(M, C) || !dout || !y || !stats || !dstats || replicas < 1) return -1;
   int rpb;
-  int grid = bn_grid(M, C, &rpb);
+  int grid = bn_grid_reduce(M, C, replicas, &rpb);
   hipStream_t st = (hipStream_t)stream;
   const bool nt = (size_t)M * C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
   if (nt) {
@@ -579,6 +591,7 @@ extern "C" int clite_colsum(int dtype, const void* x, float* out, int M, int N, 
   if (slabs < 8) slabs = 8;
   if (slabs > 64) slabs = 64;
   if (slabs > M) slabs = M;
+  if (clite::deterministic()) slabs = 1;      // det.h: one contribution per column
   int rpb = (M + slabs - 1) / slabs;
   slabs = (M + rpb - 1) / rpb;
   hipStream_t st = (hipStream_t)stream;

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -53,6 +53,8 @@ class OptimItem(C.Structure):
 _V, _I, _F, _U64, _U32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
 _SIGNATURES = {
     "clite_abi_version": [],
+    "clite_set_deterministic": [_I],
+    "clite_get_deterministic": [],
     "clite_gemm_nt": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
     "clite_gemm_nn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
     "clite_gemm_tn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
@@ -121,7 +123,19 @@ def lib():
         if l.clite_abi_version() != ABI_VERSION:
             raise RuntimeError("clip_lite_amd: libclite_hip.so ABI version mismatch; rebuild with `make hip`")
         _lib = l
+        if os.environ.get("CLITE_DETERMINISTIC", "0") not in ("", "0"):
+            l.clite_set_deterministic(1)
     return _lib
+
+
+def set_deterministic(on=True):
+    """Deterministic-reduction mode of the kernel library (include/clite.h: clite_set_deterministic): bit-identical runs, several times
+    slower. Also switched on by the environment variable CLITE_DETERMINISTIC=1."""
+    lib().clite_set_deterministic(int(bool(on)))
+
+
+def is_deterministic():
+    return bool(lib().clite_get_deterministic())
 
 
 def exported_symbols():

@@ -194,8 +194,8 @@ class DeviceRuntime:
         self.exchange = None
         self._spans = {}
         import os
-        self.s2_classes = os.environ.get("CLITE_S2_CLASSES", "1") != "0"     # 3x3/stride-2 dgrads as four parity-class GEMMs
-        self.fuse_bn_backward = os.environ.get("CLITE_FUSE_BN", "1") != "0"     # BatchNorm-backward reductions inside the dgrad epilogues (resnet.py)
+        self.s2_classes = True             # 3x3/stride-2 dgrads as four parity-class GEMMs (attribute: tools flip it for A/B runs)
+        self.fuse_bn_backward = True       # BatchNorm-backward reductions inside the dgrad epilogues (resnet.py)
         self._aux_streams, self._aux_busy, self._aux_keep, self.overlap_wgrad = {}, set(), {}, False
         self.steps = 0
         self.seed_dev, self._capturing, self._slots, self.graph_slots, self._graph_next = None, False, 0, 0, -1
@@ -309,9 +309,9 @@ class DeviceRuntime:
         return StepState(self.base_seed * 1000003 + self.steps, training)
 
     def new_side_stream(self):
-        """The text encoder's stream. CLITE_SIDE_PRIORITY (default 0) sets its priority (-1 = high) for experiments."""
+        """The text encoder's stream (default priority; a high-priority side stream measured no better)."""
         import os
-        return torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CLITE_SIDE_PRIORITY", "0")))
+        return torch.cuda.Stream(device=self.device)
 
     def begin_capture(self):
         if self.seed_dev is None:

@@ -23,8 +23,18 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 4
+#define CLITE_ABI_VERSION 5
 int clite_abi_version(void);
+
+/* Deterministic-reduction mode (process-wide, default off; the counterpart of torch.use_deterministic_algorithms for this library).
+ * Off: split-K partial products, BatchNorm / bias / LayerNorm statistics and the loss scalars meet through float atomics, so the
+ * summation order — and with it the last bits of every gradient — differs from run to run. On: every launcher picks a decomposition in
+ * which each address receives exactly one contribution per launch (unsplit K ranges, one row slab per statistics replica, single-wave
+ * loss kernels; clip-lite_amd/csrc/det.h), so two runs of the same step are bit-identical — which is what makes checkpoint-resume
+ * equivalence (reference utils/checkpointing.py:169-222, train.py:143-148) testable exactly. Several times slower; a testing aid.
+ * The flag is read when a kernel is enqueued (a captured hipGraph keeps the mode it was recorded in). Returns 0. */
+int clite_set_deterministic(int on);
+int clite_get_deterministic(void);
 
 /* storage type of activations / weights handed to a kernel. CLITE_F32 selects the exact-f32 parity mode
  * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 MFMA rate). Accumulation is f32 in both. */
