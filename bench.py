@@ -223,6 +223,14 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = t.item()
     loss = out["loss"].item()
+    replicas_identical = None
+    if dist_on:
+        # data parallel keeps every rank's parameters bit-identical (same mean gradient, same update): compare a 64-bit checksum of the arena
+        fp = model.runtime.arena.flat_p.double()
+        mine = torch.stack([fp.sum(), (fp * fp).sum(), fp[::97].abs().sum()])
+        every = [torch.empty_like(mine) for _ in range(tdist.get_world_size())]
+        tdist.all_gather(every, mine)
+        replicas_identical = all(torch.equal(every[0], e) for e in every)
     # every rank runs the instrumented steps (they contain the gradient exchange, a collective); rank 0 reports its timings
     model.overlap_encoders = False          # per-launch durations: nothing else may share the chip with the timed kernel
     gemm_ms, n_launch = kernel_roofline(eager_step, batches)
@@ -240,7 +248,7 @@ def main():
             "config": {"workload": f"{args.visual} + BERT-base({args.layers}L) + JSD-MI heads/priors, per-GPU batch {args.batch}, 224x224 images, "
                                    f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)" + ("" if args.loss == "jsd" else ", InfoNCE all-pairs loss"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
-            "loss": loss, "launch": "hipGraph replay" if step.graph else "eager",
+            "loss": loss, "launch": "hipGraph replay" if step.graph else "eager", "replicas_identical": replicas_identical,
             "roofline": {"bound": "mfma", "kernel": "clite::igemm_dma_kernel family (all conv/linear fwd+dgrad+wgrad launches of one step)",
                          "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": pmc_traffic(args),

@@ -1,6 +1,8 @@
 // Host launchers (C ABI, include/clite.h) for the implicit-GEMM engine in igemm.h.
 #include "igemm_dma.h"
+#include "wide_api.h"
 #include "det.h"
+#include <type_traits>
 #include <atomic>
 #include <stdlib.h>
 
@@ -64,6 +66,22 @@ constexpr int xcd_split_pref() { return 1; }
 constexpr int split_target_pref() { return 0; }
 constexpr int splitk_ws_pref() { return 1; }
 #endif
+// operands as gemm_wide.hip's 8-wave kernels take them (wide_api.h)
+template <typename T, int ROWS, int BK, bool D> WideOperand wide_op(const GatherKC<T, ROWS, BK, D>& l) {
+  WideOperand o{};
+  o.kind = D ? WOP_KC_DGRAD : WOP_KC; o.ptr = l.ptr; o.bytes = l.bytes; o.g = l.g;
+  return o;
+}
+template <typename T, int COLS, int BK> WideOperand wide_op(const StridedXC<T, COLS, BK>& l) {
+  WideOperand o{};
+  o.kind = WOP_XC_STRIDED; o.ptr = l.ptr; o.bytes = l.bytes; o.ld = l.ld; o.Cx = l.Cx; o.Ck = l.Ck; o.RS = l.RS;
+  return o;
+}
+template <typename T, int COLS, int BK> WideOperand wide_op(const GatherXC<T, COLS, BK>& l) {
+  WideOperand o{};
+  o.kind = WOP_XC_GATHER; o.ptr = l.ptr; o.bytes = l.bytes; o.g = l.g;
+  return o;
+}
 template <class L> struct IsDgrad { static constexpr bool value = false; };
 template <typename T, int ROWS, int BK> struct IsDgrad<GatherKC<T, ROWS, BK, true>> { static constexpr bool value = true; };
 template <class L> struct ToDma;
@@ -149,6 +167,13 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
       return rc ? rc : colstats_det<T>(ep, rm, M, N, st);
     }
     splits = 1;            // one workgroup per output tile over the whole K range: a single add per address
+  }
+  if constexpr (sizeof(T) == 2 && std::is_same<CFG, typename Cfg<T>::C128>::value) {
+    // bf16, 128-column-or-wider outputs: the wide-K 8-wave kernels (igemm_wide.h) where the shape allows
+    if (use_dma()) {
+      const int rcw = launch_wide(wide_op(la), wide_op(lb), ep, rm, M, N, Ktot, splits, st);
+      if (rcw != WIDE_NOT_TAKEN) return rcw;
+    }
   }
   int ktiles = (Ktot + CFG::BK - 1) / CFG::BK;
   if (splits < 1) splits = 1;

@@ -134,15 +134,15 @@ template <int ROWBYTES> DEV int xc_seg_xor(int k) {
 }
 
 // ---- XC strided (weights in dgrad, dY in wgrad, linear weights in input-grad): element (k, x) at ptr[(k0+krow)*ld + rs*Cx + x]
-template <typename T, int COLS, int BK>
+template <typename T, int COLS, int BK, int NW = 4>           // NW: waves per workgroup that share the tile's DMA instructions
 struct DmaXCStrided {
   static constexpr int EPC = 16 / (int)sizeof(T);
   static constexpr int ROWB = COLS * (int)sizeof(T);         // bytes per k-row of the image
   static constexpr int CPR = ROWB / 16;                      // 16-B chunks per k-row
   static constexpr int RPI = 64 / CPR;                       // k-rows per wave instruction
-  static constexpr int NI = BK / (4 * RPI);                  // instructions per wave per tile
+  static constexpr int NI = BK / (NW * RPI);                 // instructions per wave per tile
   static constexpr int BYTES = BK * ROWB;
-  static_assert(CPR <= 64 && 64 % CPR == 0 && BK % (4 * RPI) == 0, "tile shape");
+  static_assert(CPR <= 64 && 64 % CPR == 0 && BK % (NW * RPI) == 0 && NI >= 1, "tile shape");
   const void* ptr;
   uint32_t bytes;
   int ld, Cx, Ck, RS;
@@ -207,9 +207,9 @@ struct DmaXCStrided {
 };
 
 // ---- XC gather (wgrad's activation operand): k = output pixel p, x = (r, s, ci)
-template <typename T, int COLS, int BK>
+template <typename T, int COLS, int BK, int NW = 4>
 struct DmaXCGather {
-  typedef DmaXCStrided<T, COLS, BK> L;
+  typedef DmaXCStrided<T, COLS, BK, NW> L;
   static constexpr int EPC = L::EPC, ROWB = L::ROWB, CPR = L::CPR, RPI = L::RPI, NI = L::NI, BYTES = L::BYTES;
   const void* ptr;
   uint32_t bytes;

@@ -1,0 +1,463 @@
+// Wide-K, 8-wave form of the implicit-GEMM engine (bf16 only; same operands, epilogue semantics and C ABI as igemm_dma.h).
+//
+// What round 1's kernels (128 x 128 x 32 tiles, 4 waves, 3 workgroups per CU) left on the table, measured with tools/micro/tile_loop.hip
+// (the main loop's memory side alone, profiles/r2_tile_loop.txt):
+//   * a K tile of 32 bf16 is a 64-BYTE row: every L2 line (128 B) is requested twice, half a line at a time. With 128-byte rows
+//     (K tile = 64) the same 128 x 128 tile stages 15.4 TB/s instead of 10.7 (BERT FFN2 shape: 26.6 -> 18.4 us of memory side);
+//   * 256-row tiles stage 25-50 % fewer bytes per MFMA (256 x 128: FFN1 22.5 -> 14.9 us; 256 x 256: 13.3 us).
+// A 3-stage ring of 128-byte rows is 96-144 KB, i.e. ONE workgroup per CU, so the workgroup itself must keep two waves on every SIMD:
+// 512 threads = 8 waves, arranged per tile shape as
+//   W128 : 128 x 128, 2 x 2 waves of 64 x 64, x 2 K-GROUPS: both groups work on the same ring stage, group g on k-steps {2g, 2g+1} of the
+//          64-deep tile (each wave reads only its half of the K depth from LDS); group 1 hands its accumulators to group 0 at the end
+//   W256x128 : 256 x 128, 4 x 2 waves of 64 x 64
+//   W256     : 256 x 256, 2 x 4 waves of 128 x 64 (2-stage ring: 128 KB)
+// Operand images:
+//   KC (k contiguous: activations forward, dY in dgrad, weights forward)   [rows][128 B], 16-byte chunk c of row r in slot c ^ ((r>>1)&7):
+//       conflict-free ds_read_b128 fragments (a 16-lane group covers 8 even + 8 odd rows -> 16 distinct slots of the 256-byte bank row)
+//   XC (contraction index slow: both operands of wgrad, weights in dgrad)  [64 k][cols * 2 B] — igemm_dma.h's image, 64 k-rows deep,
+//       fragments by ds_read_b64_tr_b16.
+#ifndef CLITE_IGEMM_WIDE_H
+#define CLITE_IGEMM_WIDE_H
+#include "igemm_dma.h"
+
+namespace clite {
+
+constexpr int WIDE_NW = 8;       // waves per workgroup
+constexpr int WIDE_BK = 64;      // K tile (bf16 elements) = one 128-byte line per row
+
+// ---- KC gather, 128-byte rows. One wave instruction = 8 rows x 128 B.
+template <int ROWS, bool DGRAD>
+struct WideKC {
+  typedef bf16 T;
+  static constexpr int EPC = 8;
+  static constexpr int NI = ROWS / (8 * WIDE_NW);      // DMA instructions per wave per tile
+  static constexpr int BYTES = ROWS * 128;
+  static_assert(NI >= 1, "tile too small for 8 waves");
+  const void* ptr;
+  uint32_t bytes;
+  ConvGeom g;
+
+  struct State {
+    rsrc_t rs;
+    int base[NI], h0[NI], w0[NI];
+    uint32_t off[NI];
+    bool ok[NI];
+    int kc[NI];                 // element offset inside the K tile of the (swizzled) source chunk this lane fetches for row group j
+    int r, s, c0;
+  };
+  DEV void locate(State& st) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      int hi, wi;
+      bool v = st.base[j] >= 0 && st.r < g.R;
+      if (DGRAD) {
+        int hh = st.h0[j] - st.r, ww = st.w0[j] - st.s;
+        if (g.stride == 1) { hi = hh; wi = ww; }
+        else if (g.stride == 2) { v = v && ((hh | ww) & 1) == 0; hi = hh >> 1; wi = ww >> 1; }
+        else { v = v && hh % g.stride == 0 && ww % g.stride == 0; hi = hh / g.stride; wi = ww / g.stride; }
+        v = v && hh >= 0 && ww >= 0;
+      } else {
+        hi = st.h0[j] + st.r; wi = st.w0[j] + st.s;
+      }
+      v = v && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+      st.ok[j] = v;
+      st.off[j] = (uint32_t)(st.base[j] + hi * g.sH + wi * g.sW + st.c0 + st.kc[j]) * 2u;
+    }
+  }
+  DEV void init(State& st, int row0, int wave, int lane, int t_begin) const {
+    st.rs = make_rsrc(ptr, bytes);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int trow = (wave * NI + j) * 8 + (lane >> 3);        // row inside the tile
+      st.kc[j] = ((lane & 7) ^ ((trow >> 1) & 7)) * EPC;
+      const int row = row0 + trow;
+      if (row < g.rows) {
+        uint32_t n = fd_div(row, g.div_hw);
+        uint32_t rem = row - n * g.div_hw.d;
+        uint32_t rh = fd_div(rem, g.div_w);
+        uint32_t rw = rem - rh * g.div_w.d;
+        st.base[j] = n * g.sN;
+        if (DGRAD) { st.h0[j] = rh + g.pad; st.w0[j] = rw + g.padw; }
+        else { st.h0[j] = rh * g.stride - g.pad; st.w0[j] = rw * g.stride - g.padw; }
+      } else {
+        st.base[j] = -1; st.h0[j] = 0; st.w0[j] = 0;
+      }
+    }
+    int k0 = t_begin * WIDE_BK;
+    int rs = k0 / g.C;
+    st.c0 = k0 - rs * g.C;
+    st.r = rs / g.S;
+    st.s = rs - st.r * g.S;
+    locate(st);
+  }
+  DEV void issue(State& st, char* lds, int wave) const {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const bool v = st.ok[j] && st.c0 + st.kc[j] < g.C;
+      buf_load16_lds(st.rs, v ? st.off[j] : OOB_OFF, lds + (wave * NI + j) * 1024);
+      st.off[j] += 128;
+    }
+    st.c0 += WIDE_BK;
+    if (st.c0 >= g.C) {          // next window position (block-uniform branch)
+      st.c0 = 0;
+      if (++st.s == g.S) { st.s = 0; ++st.r; }
+      locate(st);
+    }
+  }
+  DEV static int frag_off(int x0, int ks, int lane) {
+    const int r = x0 + (lane & 31), c = ks * 2 + (lane >> 5);
+    return r * 128 + ((c ^ ((r >> 1) & 7)) << 4);
+  }
+  DEV static bf16x8 frag_at(const char* p) {
+    Chunk16 ch;
+    ch.u = *(const u32x4*)p;
+    return ch.h;
+  }
+};
+
+template <class L> struct WideIssue {
+  DEV static void go(const L& l, typename L::State& st, char* lds, int wave, int lane, int x0) { l.issue(st, lds, wave, lane, x0); }
+};
+template <int ROWS, bool D> struct WideIssue<WideKC<ROWS, D>> {
+  typedef WideKC<ROWS, D> L;
+  DEV static void go(const L& l, typename L::State& st, char* lds, int wave, int, int) { l.issue(st, lds, wave); }
+};
+
+// BM x BN tile, WAVES_M x WAVES_N waves of WM x WN each, x KG k-groups = 8 waves
+template <int BM_, int BN_, int WM_, int WN_, int KG_>
+struct WideCfg {
+  static constexpr int BM = BM_, BN = BN_, BK = WIDE_BK, WM = WM_, WN = WN_, KG = KG_;
+  static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
+  static constexpr int RM = WM / 32, RN = WN / 32;
+  static_assert(WAVES_M * WAVES_N * KG == WIDE_NW, "8 waves per workgroup");
+  static_assert(WM % 64 == 0, "the epilogue walks the tile in 64-row passes");
+  static constexpr int KS = (WIDE_BK / 16) / KG;               // k-steps of a K tile handled by one wave
+  // epilogue: passes of 64 tile rows through an f32 staging image
+  static constexpr int PR = 64;
+  static constexpr int EPI_PITCH = BN * 4 + 16;
+  static constexpr int EPI_BYTES = PR * EPI_PITCH;
+  static constexpr int CPRE = BN / 8;                          // 8-column chunks per row
+  static constexpr int RPSE = 512 / CPRE;                      // rows per sweep of the 512 threads
+  static constexpr int ITER = PR / RPSE;                       // rows of a pass handled by one thread
+  static constexpr int XCHG_BYTES = KG == 2 ? BM * BN * 4 : 0;
+  static constexpr int RED_BYTES = RPSE * CPRE * 16 * 4;
+};
+
+// Fused epilogue for the 8-wave kernels. EPI selects which of clite_epilogue's features are compiled in (the flags a launch does not use
+// must not cost scalar branches per row: igemm.h's note on igemm_epilogue_plain):
+//   0 generic: bias, activation, pre-activation store, activation derivative, dropout, residual, f32 / bf16 store, column statistics
+//   1 BatchNorm backward (conv dgrad): relu' mask (before or after the residual), residual, bf16 / f32 store, (sum v, sum v*(bn_y - mean))
+//   2 plain: bias, bf16 store, column statistics
+template <class CFG, int EPI>
+DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
+                       int tid, int lane, int kg, int wm0, int wn0) {
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  typedef bf16 T;
+  if constexpr (CFG::KG == 2) {
+    // group 1 -> group 0: element (i, j, r) of thread t at ((i*RN + j)*16 + r)*256 + t
+    float* xchg = (float*)smem;
+    const int t = tid & 255;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xchg[((i * RN + j) * 16 + r) * 256 + t] = acc[i][j][r];
+    }
+    lds_barrier();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += xchg[((i * RN + j) * 16 + r) * 256 + t];
+    }
+    lds_barrier();
+  }
+  if (EPI == 0 && ep.atomic) {
+    if (kg == 0) {
+      float* out = (float*)ep.out;
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) {
+          const int col = n0 + wn0 + j * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < M && col < N) atomic_add_f32(out + (size_t)row * ep.ldc + col, ep.alpha * acc[i][j][r]);
+          }
+        }
+    }
+    return;
+  }
+
+  constexpr int CPRE = CFG::CPRE, RPSE = CFG::RPSE, ITER = CFG::ITER, PITCH = CFG::EPI_PITCH;
+  const int ecol = (tid % CPRE) * 8, erow0 = tid / CPRE;
+  const int gcol = n0 + ecol;
+  const bool colok = gcol < N;
+  float csum[8], csq[8], bias[8], bn_mean[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; bias[e] = 0.f; bn_mean[e] = 0.f; }
+  if (EPI != 1 && colok && ep.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = ep.bias[gcol + e];
+  }
+  if (EPI == 1 && colok && ep.bn_y) {
+    for (int r = 0; r < ep.bn_replicas; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bn_mean[e] += ep.bn_stats[(size_t)r * ep.bn_rstride + gcol + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bn_mean[e] *= ep.bn_inv_count;
+  }
+  float keep_scale = 1.f;
+  uint64_t drop_seed = 0;
+  uint32_t drop_site = 0;
+  if (EPI == 0 && ep.drop_p > 0.f) {
+    keep_scale = 1.0f / (1.0f - ep.drop_p);
+    drop_seed = ep.drop_seed; drop_site = ep.drop_site;
+    seed_resolve(drop_seed, drop_site);
+  }
+  const bool stats = ep.colsum != nullptr;
+
+  for (int pass = 0; pass < CFG::BM / CFG::PR; ++pass) {
+    // the operands of all rows this thread writes in this pass are requested before the accumulators go through LDS
+    Raw8<T> pa[ITER], py[ITER], pr[ITER];
+    uint32_t gix[ITER];
+    bool okr[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int grow = m0 + pass * CFG::PR + erow0 + it * RPSE;
+      okr[it] = colok && grow < M;
+      gix[it] = okr[it] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
+      if (EPI != 2 && okr[it]) {
+        if (ep.dact_aux) pa[it].ld((const T*)ep.dact_aux + gix[it]);
+        if (EPI == 1 && ep.bn_y) py[it].ld((const T*)ep.bn_y + gix[it]);
+        if (ep.residual) pr[it].ld((const T*)ep.residual + gix[it]);
+      }
+    }
+    // the waves that own this pass's 64 rows stage them (static accumulator indices: half h of a wave's rows = acc[2h], acc[2h+1])
+#pragma unroll
+    for (int h = 0; h < RM / 2; ++h) {
+      if (kg == 0 && wm0 + h * 64 == pass * CFG::PR) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              const int col = wn0 + j * 32 + (lane & 31);
+              *(float*)(smem + row * PITCH + col * 4) = acc[h * 2 + ii][j][r];
+            }
+      }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (!okr[it]) continue;
+      const int rr = erow0 + it * RPSE;
+      const float* src = (const float*)(smem + rr * PITCH + ecol * 4);
+      const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      const size_t gidx = gix[it];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
+      if constexpr (EPI == 0) {
+        if (ep.preact) store8((T*)ep.preact + gidx, v);
+        if (ep.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (ep.act == ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (ep.act == ACT_TANH) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
+        }
+      }
+      float dfac[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dfac[e] = 1.f;
+      if (EPI != 2 && ep.dact_aux) {
+        float av[8];
+        pa[it].get(av);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = av[e];
+          dfac[e] = (EPI == 1 || ep.dact == 1) ? (a > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_f(a) : (1.f - a * a);
+        }
+        if (EPI == 0 || !ep.mask_after_residual) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
+        }
+      }
+      if (EPI == 0 && ep.drop_p > 0.f) {
+        float u[8];
+        dropout_uniform8(drop_seed, drop_site, gidx, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = u[e] >= ep.drop_p ? v[e] * keep_scale : 0.f;
+      }
+      if (EPI != 2 && ep.residual) {
+        float rv[8];
+        pr[it].get(rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (EPI == 1 && ep.dact_aux && ep.mask_after_residual) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
+      }
+      if (EPI != 2 && ep.out_f32) {
+        store8((float*)ep.out + gidx, v);
+      } else {
+        store8((T*)ep.out + gidx, v);
+        round8_bf16(v);   // statistics of what was stored
+      }
+      if (EPI == 1 && ep.bn_y) {
+        float yv[8];
+        py[it].get(yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * (yv[e] - bn_mean[e]); }
+      } else if (stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+      }
+    }
+    lds_barrier();
+  }
+
+  if (stats) {
+    // threads sharing a column chunk are tid, tid + CPRE, ...: fold them through LDS, one atomic per column into replica blockIdx.x % R
+    float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
+    float* red = (float*)smem;                      // [RPSE][CPRE*16]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + e] = csum[e];
+      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + 8 + e] = csq[e];
+    }
+    lds_barrier();
+    for (int idx = tid; idx < CPRE * 16; idx += 512) {
+      float s = 0.f;
+      for (int r = 0; r < RPSE; ++r) s += red[r * (CPRE * 16) + idx];
+      const int chunk = idx / 16, e = idx % 16;
+      const int col = n0 + chunk * 8 + (e & 7);
+      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
+    }
+  }
+}
+
+template <class CFG, class LA, class LB, int NSTAGE, int EPI>
+__global__ __launch_bounds__(512) void igemm_wide_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split, int xsplits) {
+  constexpr int BM = CFG::BM, BN = CFG::BN;
+  constexpr int RM = CFG::RM, RN = CFG::RN, KS = CFG::KS;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int RING = NSTAGE * STAGE;
+  constexpr int E1 = CFG::EPI_BYTES > CFG::XCHG_BYTES ? CFG::EPI_BYTES : CFG::XCHG_BYTES;
+  constexpr int E2 = E1 > CFG::RED_BYTES ? E1 : CFG::RED_BYTES;
+  constexpr int SMEM = RING > E2 ? RING : E2;
+  constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
+  static_assert(SMEM <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int kg = wave / (CFG::WAVES_M * CFG::WAVES_N);                 // k-group (0 when KG == 1)
+  const int w = wave - kg * (CFG::WAVES_M * CFG::WAVES_N);
+  const int wm0 = (w / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (w % CFG::WAVES_N) * CFG::WN;
+
+  const int tiles_n = (N + BN - 1) / BN;
+  int wg, zsplit;
+  if (xsplits > 0) {
+    // split-K with >= 8 splits (weight gradients): all output tiles of one K range run on ONE XCD (igemm_dma.h)
+    const int ntile = ((M + BM - 1) / BM) * tiles_n;
+    const int j = blockIdx.x >> 3;
+    zsplit = (blockIdx.x & 7) + 8 * (j / ntile);
+    wg = j % ntile;
+    if (zsplit >= xsplits) return;
+  } else {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+    wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    zsplit = blockIdx.z;
+  }
+  const int tm = wg / tiles_n;
+  const int tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t_begin = zsplit * ktiles_per_split;
+  int t_end = t_begin + ktiles_per_split;
+  if (t_end > ktiles) t_end = ktiles;
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, wave, lane, t_begin);
+  lb.init(sb, n0, wave, lane, t_begin);
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // loop-invariant LDS offsets of this lane's MFMA fragments: k-steps kg*KS .. kg*KS + KS - 1 of every K tile
+  int aoff[RM][KS], boff[RN][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i) aoff[i][ks] = LA::frag_off(wm0 + i * 32, kg * KS + ks, lane);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) boff[j][ks] = LB::frag_off(wn0 + j * 32, kg * KS + ks, lane);
+  }
+
+#pragma unroll
+  for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+    if (t_begin + pz < t_end) {
+      WideIssue<LA>::go(la, sa, smem + pz * STAGE, wave, lane, m0);
+      WideIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
+    }
+  }
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    // tile t has landed once at most min(NSTAGE-2, tiles after t) younger tiles are still outstanding
+    const int after = t_end - 1 - t;
+    if (NSTAGE >= 3 && after >= 1) wait_vmcnt<LOADS_PER_TILE>();
+    else wait_vmcnt<0>();
+    barrier_raw();            // everyone's part of tile t has landed; everyone is done reading the buffer tile t+NSTAGE-1 overwrites
+    const char* abuf = smem + buf * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+    // first k-step's fragment reads go out before the next tile's DMA is issued (the issue overlaps the LDS latency)
+    bf16x8 af0[RM], bf0[RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) bf0[j] = LB::frag_at(bbuf + boff[j][0]);
+    if (t + NSTAGE - 1 < t_end) {
+      int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+      WideIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+      WideIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 af[RM], bfr[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+    }
+    if (++buf == NSTAGE) buf = 0;
+  }
+  lds_barrier();          // no DMA outstanding; every wave is past its last fragment read: the LDS is free for the epilogue
+  wide_epilogue<CFG, EPI>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, kg, wm0, wn0);
+}
+
+}  // namespace clite
+#endif  // CLITE_IGEMM_WIDE_H

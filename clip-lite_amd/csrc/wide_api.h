@@ -1,0 +1,22 @@
+// Internal interface between the launchers of gemm.hip and the wide-K 8-wave kernels of gemm_wide.hip (separate translation units so
+// the two instantiation sets compile in parallel).
+#ifndef CLITE_WIDE_API_H
+#define CLITE_WIDE_API_H
+#include "igemm.h"
+
+namespace clite {
+
+enum { WOP_KC = 0, WOP_KC_DGRAD = 1, WOP_XC_STRIDED = 2, WOP_XC_GATHER = 3 };
+struct WideOperand {      // one GEMM operand as the loaders of igemm_wide.h / igemm_dma.h describe it
+  int kind;
+  const void* ptr;
+  uint32_t bytes;
+  ConvGeom g;             // WOP_KC, WOP_KC_DGRAD, WOP_XC_GATHER
+  int ld, Cx, Ck, RS;     // WOP_XC_STRIDED
+};
+constexpr int WIDE_NOT_TAKEN = -1000;
+// bf16 only. Returns WIDE_NOT_TAKEN when the launch stays on the 4-wave kernels (shape, policy), else the HIP status of the launch.
+int launch_wide(const WideOperand& a, const WideOperand& b, const clite_epilogue& ep, const RowMap& rm, int M, int N, int Ktot, int splits, hipStream_t st);
+
+}  // namespace clite
+#endif

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "clite_abi_version": [],
     "clite_set_deterministic": [_I],
     "clite_get_deterministic": [],
+    "clite_set_tile_policy": [_I],
     "clite_gemm_nt": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
     "clite_gemm_nn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
     "clite_gemm_tn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
@@ -136,6 +137,14 @@ def set_deterministic(on=True):
 
 def is_deterministic():
     return bool(lib().clite_get_deterministic())
+
+
+TILE_AUTO, TILE_W128, TILE_W256x128, TILE_W256, TILE_NARROW = 0, 1, 2, 3, 4
+
+
+def set_tile_policy(policy=TILE_AUTO):
+    """Tile-shape policy of the bf16 GEMM / conv launchers (include/clite.h: clite_set_tile_policy); the forced forms are for parity tests."""
+    check(lib().clite_set_tile_policy(int(policy)), "set_tile_policy")
 
 
 def exported_symbols():

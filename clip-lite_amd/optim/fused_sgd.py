@@ -54,6 +54,19 @@ class FusedSGD(torch.optim.Optimizer):
                 n4 = (n + 3) // 4 * 4
                 for s in range(0, n4, CHUNK):
                     rows.append((o + s, min(CHUNK, n4 - s), lr, wd))
+        # frozen tensors: no work item, so the update kernel never zeroes their slice of flat_g — yet several backward kernels write
+        # gradients unconditionally (BatchNorm dgamma/dbeta, LayerNorm, embeddings). Their (merged) spans are zeroed explicitly.
+        spans = []
+        for g, (_, _, on) in zip(self.param_groups, key):
+            if on:
+                continue
+            for p in g["params"]:
+                o, n = self.arena.index[p._clite[1]]
+                if spans and spans[-1][1] == o:
+                    spans[-1][1] = o + n
+                else:
+                    spans.append([o, o + n])
+        self._frozen_spans = [tuple(x) for x in spans]
         arr = (hip.OptimItem * len(rows))()
         for i, (s, c, lr, wd) in enumerate(rows):
             arr[i].start, arr[i].count, arr[i].lr, arr[i].wd = s, c, lr, wd
@@ -75,6 +88,8 @@ class FusedSGD(torch.optim.Optimizer):
         inside the update kernel. Returns the (device) total norm of the pre-scaled gradients."""
         self.max_norm = float(max_norm)
         self.arena.join()
+        self._build_items()
+        self.zero_frozen()           # stale / unconditional gradients of frozen tensors must not enter the norm
         self.sumsq.zero_()
         hip.sumsq(self.arena.flat_g, self.arena.total, self.sumsq)
         return self.sumsq.sqrt() * self.grad_prescale
@@ -120,10 +135,15 @@ class FusedSGD(torch.optim.Optimizer):
         ev.record()
         self._hp_used[i] = True
 
+    def zero_frozen(self):
+        for lo, hi in getattr(self, "_frozen_spans", ()):
+            self.arena.flat_g[lo:hi].zero_()
+
     @torch.no_grad()
     def launch(self):
         self.arena.join()
         self._build_items()
+        self.zero_frozen()
         hip.sgd_step(self.arena.flat_p, self.arena.flat_g, self.flat_v, self.flat_slow, self.arena.flat_lp,
                      C.c_void_p(self._items.data_ptr()), self._n_items, self.hp, self.sumsq)
         self._dirty = False

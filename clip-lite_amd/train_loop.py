@@ -26,6 +26,8 @@ def build_parser():
     group.add_argument("--log-every", type=int, default=500, help="Log training curves after every these many iterations.")
     group.add_argument("--climax-freq", type=int, default=1000, help="Frequency to checkpoint at during climax (last 20%% training)")
     group = parser.add_argument_group("MI355X launch path (not in the reference)")
+    group.add_argument("--allow-eager-fallback", action="store_true", help="If the hipGraph capture of the step fails, log an error and continue with "
+                       "eager launches instead of stopping.")
     group.add_argument("--no-hip-graph", action="store_true", help="Launch every kernel of the step from Python instead of replaying the "
                        "captured hipGraphs of the step (TrainStep graph mode; batches of another shape always take the eager path).")
     return parser
@@ -59,8 +61,15 @@ class TrainStep:
     Data parallel (`exchange` given): the step is recorded as two graphs — [forward + backward] and [gradient norm + update] —
     with the RCCL all-reduce of the flat gradient arena issued eagerly between them (collectives stay outside the captures)."""
 
-    def __init__(self, model, optimizer, scheduler, scaler, clip_grad_norm, exchange=None, graph=False, graph_warmup=2):
+    def __init__(self, model, optimizer, scheduler, scaler, clip_grad_norm, exchange=None, graph=False, graph_warmup=2, pad_to=None,
+                 allow_eager_fallback=False):
+        """pad_to: caption length the step is captured at (DATA.MAX_CAPTION_LENGTH). The reference's collate pads each batch to ITS longest
+        caption (data/dataloader.py:218-236), so L changes from batch to batch; shorter batches are right-padded (id 0 = [PAD], mask 0) into
+        the captured buffers. Masked positions receive exactly zero attention weight and feed nothing downstream of the [CLS] pooler, so
+        features, loss and gradients are those of the unpadded batch. allow_eager_fallback: continue with eager launches if the capture
+        fails (default: raise — a silently eager run is ~2.5x slower)."""
         self.model, self.optimizer, self.scheduler, self.scaler = model, optimizer, scheduler, scaler
+        self.pad_to, self.allow_eager_fallback = pad_to, allow_eager_fallback
         self.clip, self.exchange = clip_grad_norm, exchange
         self.inner = optimizer.optimizer if hasattr(optimizer, "optimizer") else optimizer
         self.graph = bool(graph)
@@ -68,8 +77,10 @@ class TrainStep:
         self._eager_steps = 0
         self._g = self._g_update = self._graphs = None
         self._static_batch = self._static_out = None
+        self.replays = self.eager_steps = 0        # how many steps took the captured / the eager launch path
 
     def _eager(self, batch):
+        self.eager_steps += 1
         self.optimizer.zero_grad()
         output_dict = self.model(batch)
         loss = output_dict["loss"]
@@ -87,6 +98,8 @@ class TrainStep:
     def _capture_update(self):
         self.inner.arena.join()
         if self.clip and self.clip > 0:
+            self.inner._build_items()
+            self.inner.zero_frozen()          # frozen tensors' unconditional gradients must not enter the norm
             self.inner.sumsq.zero_()
             hip_sumsq(self.inner)
         self.inner.launch()
@@ -117,7 +130,7 @@ class TrainStep:
         from .loss import jsd_backward, jsd_forward
         from .resnet import resnet_backward, resnet_forward
         m, rt = self.model, self.model.runtime
-        sb = self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        sb = self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self._padded(batch).items()}
         self.optimizer.zero_grad()            # no-op after a completed step (the update kernel leaves the gradients zeroed)
         torch.cuda.synchronize()
         saved_exchange, rt.exchange = rt.exchange, None      # the executors must not start collectives inside a capture
@@ -173,8 +186,9 @@ class TrainStep:
                 capture("update", pool_main, update)
         except BaseException:
             rt.abort_capture()
-            rt.exchange = saved_exchange
             raise
+        finally:
+            rt.exchange = saved_exchange      # eager steps (a batch of another shape, eval) keep the overlapped exchange
         A = rt.arena
         self._regions = {k: A.region(k + ".") for k in ("text_encoder", "image_encoder", "loss")}
         self._g, self._graphs, self._keep, self._static_out = graphs["update"], graphs, keep, keep["result"]
@@ -211,7 +225,7 @@ class TrainStep:
 
     def _capture_single(self, batch):
         rt = self.model.runtime
-        self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        self._static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self._padded(batch).items()}
         self.optimizer.zero_grad()            # no-op after a completed step (the update kernel leaves the gradients zeroed)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -233,20 +247,51 @@ class TrainStep:
                 self._g_update = g2
         except BaseException:
             rt.abort_capture()
-            rt.exchange = saved_exchange
             raise
+        finally:
+            rt.exchange = saved_exchange
         self._g, self._static_out = g, out
 
-    def _same_shapes(self, batch):
+    _CAPTION_KEYS = ("input_ids", "attention_mask", "neg_input_ids", "neg_attention_mask", "aug_input_ids", "aug_attention_mask")
+
+    def _padded(self, batch):
+        """Caption tensors right-padded with zeros to `pad_to` columns (see __init__); other entries untouched."""
+        if not self.pad_to:
+            return batch
+        out = dict(batch)
+        for k in self._CAPTION_KEYS:
+            v = batch.get(k)
+            if torch.is_tensor(v) and v.dim() == 2 and v.shape[1] < self.pad_to:
+                w = torch.zeros(v.shape[0], self.pad_to, dtype=v.dtype, device=v.device)
+                w[:, :v.shape[1]] = v
+                out[k] = w
+        return out
+
+    def _fits(self, batch):
+        """The batch can be fed to the captured step: same tensors, same shapes — caption tensors may be SHORTER than captured."""
         sb = self._static_batch
-        return all((k in sb and torch.is_tensor(sb[k]) and sb[k].shape == v.shape and sb[k].dtype == v.dtype) for k, v in batch.items() if torch.is_tensor(v))
+        for k, v in batch.items():
+            if not torch.is_tensor(v):
+                continue
+            if k not in sb or not torch.is_tensor(sb[k]) or sb[k].dtype != v.dtype:
+                return False
+            if sb[k].shape == v.shape:
+                continue
+            if not (k in self._CAPTION_KEYS and v.dim() == 2 and v.shape[0] == sb[k].shape[0] and v.shape[1] < sb[k].shape[1]):
+                return False
+        return all(k in batch for k, v in sb.items() if torch.is_tensor(v))
 
     def _replay(self, batch):
         rt = self.model.runtime
+        self.replays += 1
         for k, v in batch.items():
             if torch.is_tensor(v):
                 dst = self._static_batch[k]
-                dst.copy_(v, non_blocking=True)
+                if dst.shape == v.shape:
+                    dst.copy_(v, non_blocking=True)
+                else:                                   # a batch whose longest caption is shorter than the captured length
+                    dst.zero_()
+                    dst[:, :v.shape[1]].copy_(v, non_blocking=True)
         sync = self.optimizer.advance() if hasattr(self.optimizer, "advance") else False
         alpha = getattr(self.optimizer, "alpha", 1.0)
         if self.exchange is not None:
@@ -273,12 +318,15 @@ class TrainStep:
                 return self._eager(batch)
             try:
                 self._capture(batch)
-            except Exception as e:      # noqa: BLE001 — never lose the run to the launch-path optimisation: same kernels, eager launches
-                logger.warning(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}); continuing with eager launches")
+            except Exception as e:      # noqa: BLE001
                 self.graph, self._g, self._graphs = False, None, None
                 torch.cuda.synchronize()
+                if not self.allow_eager_fallback:
+                    raise RuntimeError(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}). Pass --no-hip-graph (TrainStep(graph=False)) "
+                                       "to launch eagerly, or --allow-eager-fallback to continue after a failed capture.") from e
+                logger.error(f"capture of the train step failed ({type(e).__name__}: {e}); continuing with eager launches (~2.5x slower)")
                 return self._eager(batch)
-        if not self._same_shapes(batch) or not self.model.training:
+        if not self._fits(batch) or not self.model.training:
             return self._eager(batch)             # a batch of another shape (e.g. a ragged last one): same kernels, launched from Python
         return self._replay(batch)
 
@@ -322,7 +370,8 @@ def main(_A: argparse.Namespace):
     if dist.is_master_process():
         checkpoint_manager = CheckpointManager(_A.checkpoints_dir + _C.RUN_ID, model=model, optimizer=optimizer, scheduler=scheduler, scaler=scaler)
 
-    step = TrainStep(model, optimizer, scheduler, scaler, _C.OPTIM.CLIP_GRAD_NORM, exchange, graph=not _A.no_hip_graph)
+    step = TrainStep(model, optimizer, scheduler, scaler, _C.OPTIM.CLIP_GRAD_NORM, exchange, graph=not _A.no_hip_graph,
+                     pad_to=min(int(_C.DATA.MAX_CAPTION_LENGTH), 32), allow_eager_fallback=_A.allow_eager_fallback)
     for iteration in range(start_iteration + 1, _C.OPTIM.NUM_ITERATIONS + 1):
         timer.tic()
         batch = next(train_dataloader_iter)

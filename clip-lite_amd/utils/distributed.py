@@ -25,13 +25,14 @@ def _backend():
 
 def launch(job_fn: Callable, num_machines: int = 1, num_gpus_per_machine: int = 1, machine_rank: int = 0,
            dist_url: str = "tcp://127.0.0.1:23456", args=()):
-    if "RANK" in os.environ and "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
-        # started by torch.distributed.run: one process per GPU already exists
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        # started by torch.distributed.run: one process per GPU already exists — never spawn from here, whatever --num-gpus-per-machine says
         local_rank = int(os.environ.get("LOCAL_RANK", 0))
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=_backend(), init_method="env://")
-        synchronize()
+        if int(os.environ["WORLD_SIZE"]) > 1:
+            dist.init_process_group(backend=_backend(), init_method="env://")
+            synchronize()
         return job_fn(*args)
     assert torch.cuda.is_available(), "No GPU visible: cannot launch distributed processes."
     world_size = num_machines * num_gpus_per_machine

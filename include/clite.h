@@ -36,6 +36,13 @@ int clite_abi_version(void);
 int clite_set_deterministic(int on);
 int clite_get_deterministic(void);
 
+/* Tile-shape policy of the bf16 GEMM / conv launchers (process-wide, default 0). 0: automatic — per launch, the largest of the 128 x 128,
+ * 256 x 128 and 256 x 256 wide-K tiles (K tile 64 = whole 128-byte lines, 8 waves; clip-lite_amd/csrc/igemm_wide.h) that still fills the
+ * 256 CUs. 1 / 2 / 3: force that wide tile wherever an instantiation exists. 4: keep every launch on the 4-wave 128 x 128 x 32 kernels.
+ * The forced forms exist so that every instantiation can be parity-tested on small problems; results are identical up to the
+ * summation order of the K loop. Returns 0, or -1 for an unknown policy. */
+int clite_set_tile_policy(int policy);
+
 /* storage type of activations / weights handed to a kernel. CLITE_F32 selects the exact-f32 parity mode
  * (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 MFMA rate). Accumulation is f32 in both. */
 enum { CLITE_BF16 = 0, CLITE_F32 = 1 };

@@ -68,3 +68,112 @@ def test_gradient_exchange_world2_gloo(tmp_path):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Two-rank data-parallel TRAIN STEPS, end to end on the product's own update path (reference train.py:174-178,211-226): each rank
+# back-propagates its own shard into the flat gradient arena, GradientExchange sums the arenas (gloo), FusedSGD clips by the global norm
+# of the MEAN gradient and applies SGD(momentum, wd, per-name lr) + Lookahead with the schedule's multiplier — through the same
+# clite_sumsq / clite_sgd_step kernels as on the GPU, here in their wave-simulator build (tests/simlib.py). The oracle is the reference
+# optimiser stack (oracle/ref_model.py: torch.optim.SGD + Lookahead restatement, pinned by tests/golden/optim.npz) fed the average of
+# the per-shard gradients, each shard run on its own (local BatchNorm statistics, local mean loss) — SURVEY.md §8(e)'s semantics.
+def _tiny_net():
+    torch.manual_seed(5)
+    return torch.nn.ModuleDict({
+        "image_encoder": torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 8)),
+        "text_encoder": torch.nn.Sequential(torch.nn.Linear(10, 8), torch.nn.Tanh()),
+        "loss": torch.nn.Linear(8, 1),
+    })
+
+
+def _tiny_loss(net, x, t):
+    a, b = net["image_encoder"](x), net["text_encoder"](t)
+    o = net["loss"](a * b).squeeze(-1)
+    return torch.nn.functional.softplus(-o).mean() + torch.nn.functional.softplus(torch.roll(o, 1)).mean()      # local mean, local negatives
+
+
+def _shard(step, rank, n=6):
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return torch.randn(n, 12, generator=g), torch.randn(n, 10, generator=g)
+
+
+STEPS, WARM, TOTAL, CLIP = 7, 2, 20, 0.05      # clipping active on some steps, Lookahead (k = 3) syncs twice, warm-up then cosine
+
+
+def _dp_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    import simlib
+    from clip_lite_amd import hip
+    from clip_lite_amd.optim import FusedSGD, Lookahead
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    from clip_lite_amd.runtime import Arena
+    from clip_lite_amd.utils import distributed as D
+    simlib.build_sim()
+    hip._lib, hip._allow_host_tensors = hip._bind(C.CDLL(simlib.SIM_SO)), True      # the same csrc/optim_ops.hip, compiled for the host
+    net = _tiny_net()
+    if rank == 1:                                   # rank 1 starts from different parameters: the broadcast must repair that
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.5)
+    arena = Arena(net.named_parameters(), torch.device("cpu"), lowp=False)
+
+    class M:
+        _rt = type("R", (), {"arena": arena})()
+        buffers = staticmethod(lambda: [])          # BatchNorm buffers stay rank-local (DDP would broadcast rank 0's every forward)
+        parameters = staticmethod(lambda: net.parameters())
+    D.broadcast_parameters(M)
+    groups = [{"params": [p], "lr": 0.2 if "image_encoder" in n else 1e-3, "weight_decay": 1e-4} for n, p in net.named_parameters()]
+    opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
+    sched = LinearWarmupCosineAnnealingLR(opt, total_steps=TOTAL, warmup_steps=WARM)
+    ex = D.GradientExchange(arena, bucket_elems=64)
+    lo_img, hi_img = arena.index["image_encoder.0.weight"][0], arena.index["text_encoder.0.weight"][0]
+    for step in range(STEPS):
+        opt.zero_grad()
+        _tiny_loss(net, *_shard(step, rank)).backward()            # autograd accumulates into the arena views (p.grad is flat_g)
+        ex.region_ready(hi_img, arena.total)                       # heads + text encoder first, as backward finishes them ...
+        ex.region_ready(lo_img, hi_img)                            # ... then the image encoder
+        opt.optimizer.grad_prescale = ex.finish()                  # SUM over ranks now, 1/world inside the update kernel
+        opt.clip_grad_norm(CLIP)
+        opt.step()
+        sched.step()
+    allp = [torch.empty_like(arena.flat_p) for _ in range(world)]
+    tdist.all_gather(allp, arena.flat_p)
+    assert torch.equal(allp[0], allp[1]), "ranks diverged"
+    if rank == 0:
+        torch.save({n: p.detach().clone() for n, p in net.named_parameters()}, os.path.join(tmp, "dp_params.pt"))
+    tdist.destroy_process_group()
+    open(os.path.join(tmp, f"dp_ok{rank}"), "w").write("ok")
+
+
+def test_two_rank_train_steps_match_shardwise_oracle(tmp_path):
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "dp_ok0").exists() and (tmp_path / "dp_ok1").exists()
+    got = torch.load(tmp_path / "dp_params.pt")
+    # the oracle: one process, shard by shard
+    sys.path.insert(0, ROOT)
+    from oracle import ref_model as O
+    world = 2
+    net = _tiny_net()
+    replicas = [_tiny_net() for _ in range(world)]                 # per-rank BatchNorm buffers; parameters are tied to `net` below
+    opt = O.build_optimizer(net.named_parameters(), cnn_lr=0.2, trans_lr=1e-3, lr=1e-3, k=3, alpha=0.5)
+    for step in range(STEPS):
+        mult = O.lr_multiplier("cosine", step, TOTAL, WARM, 0.0)
+        for g in opt.param_groups:
+            g["lr"] = g["initial_lr"] * mult
+        mean = [torch.zeros_like(p) for p in net.parameters()]
+        for r in range(world):
+            replicas[r].load_state_dict({k: v for k, v in net.state_dict().items() if "running" not in k and "num_batches" not in k}, strict=False)
+            grads = torch.autograd.grad(_tiny_loss(replicas[r], *_shard(step, r)), list(replicas[r].parameters()))
+            for m, g in zip(mean, grads):
+                m += g / world
+        for p, m in zip(net.parameters(), mean):
+            p.grad = m
+        torch.nn.utils.clip_grad_norm_(list(net.parameters()), CLIP)
+        opt.step()
+    for n, p in net.named_parameters():
+        assert torch.allclose(got[n], p.detach(), rtol=1e-5, atol=1e-6), (n, (got[n] - p).abs().max().item())

@@ -10,6 +10,19 @@ pytestmark = pytest.mark.gpu
 BF16, F32 = 0, 1
 
 
+@pytest.fixture(autouse=True, params=[0, 1, 2, 3, 4], ids=["auto", "w128", "w256x128", "w256", "narrow"])
+def tile_policy(request):
+    """Every case runs under the automatic tile choice and with each tile family forced (include/clite.h: clite_set_tile_policy), so every
+    instantiation of the wide-K 8-wave kernels and of the 4-wave kernels meets the same references. f32 launches ignore the policy."""
+    dt = request.node.callspec.params.get("dt", BF16) if hasattr(request.node, "callspec") else BF16
+    if dt == F32 and request.param != 0:
+        pytest.skip("f32 launches do not depend on the tile policy")
+    from clip_lite_amd import hip
+    hip.set_tile_policy(request.param)
+    yield request.param
+    hip.set_tile_policy(0)
+
+
 def _hip():
     from clip_lite_amd import hip
     return hip

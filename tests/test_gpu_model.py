@@ -200,3 +200,38 @@ def test_f32_mode_matches_reference_golden(name, mode, layers):
         assert abs(g[n].norm().item() - ref) <= 2e-3 * max(ref, 1e-3 * gmax), (n, g[n].norm().item(), ref)
     c1 = g["image_encoder.img_encoder.conv1.weight"].float().cpu().numpy()
     assert np.abs(c1 - fx["g_conv1"]).max() <= 2e-3 * np.abs(fx["g_conv1"]).max()
+
+
+def test_full_size_config2_f32_matches_oracle_fixture():
+    """The benchmarked workload itself (BASELINE.json configs[1]: ResNet-50 + BERT-base 12 layers + JSD heads / priors, batch 128, 224 x 224,
+    30 tokens) in the exact-f32 mode against the oracle's fp32 CPU forward + backward of the SAME weights (tests/detfill.py) and inputs,
+    generated once in the build container by tests/golden/make_golden_full.py (tests/golden/full_c2_b128.npz: too slow for this box).
+    Bars: loss and its components within 1e-4 (the north-star bar); per top-level module the gradient norm within 2e-3 relative; the four
+    small stored gradients within 2e-3 of their max."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_full", os.path.join(G, "make_golden_full.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                      # only its inputs(): same seeded batch and noise as the fixture
+    fx = np.load(os.path.join(G, "full_c2_b128.npz"))
+    M = build("resnet50", "train_sbert", 12, False, 2048)
+    batch, noise = gen.inputs()
+    M.loss.set_prior_noise(noise[0].cuda(), noise[1].cuda())
+    out = M({k: v.cuda() for k, v in batch.items()})
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(out["loss"].item() - float(fx["loss"])) < 1e-4, (out["loss"].item(), float(fx["loss"]))
+    for k, v in out["loss_components"].items():
+        assert abs(float(v) - float(fx["comp_" + k])) < 1e-4, (k, float(v), float(fx["comp_" + k]))
+    norms = {}
+    for n, p in M.named_parameters():
+        top = n.split(".")[0]
+        norms[top] = norms.get(top, 0.0) + float((p.grad.double() ** 2).sum())
+    for k, v in norms.items():
+        want = float(fx["gradnorm_" + k])
+        assert abs(v ** 0.5 - want) <= 2e-3 * want, (k, v ** 0.5, want)
+    grads = dict(M.named_parameters())
+    for key in fx.files:
+        if key.startswith("grad_"):
+            want = torch.from_numpy(fx[key])
+            got = grads[key[5:]].grad.detach().float().cpu().reshape(want.shape)
+            assert (got - want).abs().max().item() <= 2e-3 * max(want.abs().max().item(), 1e-8), key

@@ -318,6 +318,50 @@ def test_graph_replay_matches_eager_steps():
         assert torch.allclose(b0[k].float(), b1[k].float(), rtol=5e-3, atol=1e-4), k
 
 
+def test_graph_replay_takes_shorter_caption_batches_padded():
+    """The reference's collate pads every batch to ITS longest caption (data/dataloader.py:218-236), so L varies batch to batch. TrainStep(pad_to=
+    MAX_CAPTION_LENGTH) captures at the maximum length and right-pads shorter batches (id 0, mask 0) into the captured buffers: every such
+    step must REPLAY (no eager fallback) and walk the same trajectory as an eager run on the unpadded batches — masked positions get exactly
+    zero attention weight and feed nothing downstream of the [CLS] pooler. Dropout off (its mask indices depend on L), exact-f32 kernels;
+    tolerances as test_graph_replay_matches_eager_steps."""
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    from clip_lite_amd.optim import FusedSGD, Lookahead
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    from clip_lite_amd.train_loop import TrainStep
+    from clip_lite_amd.utils.common import GradScaler
+    B, LMAX = 8, 12
+    batches = []
+    for i, L in enumerate((12, 10, 12, 9, 12, 7)):
+        ids = torch.randint(1000, 30522, (B, L), generator=torch.Generator().manual_seed(40 + i))
+        mask = torch.ones(B, L, dtype=torch.long)
+        ids[1, L - 3:], mask[1, L - 3:] = 0, 0                     # and one caption shorter than the batch's longest
+        batches.append({"image": det_tensor(f"pimg{i}", (B, 3, 64, 64), "normal").cuda(), "input_ids": ids.cuda(), "attention_mask": mask.cuda()})
+    results = []
+    for graph in (False, True):
+        torch.manual_seed(7)
+        te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
+        te.strans.hidden_dropout_prob = te.strans.attention_probs_dropout_prob = 0.0
+        M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=False)).to("cuda").train()
+        p_init = M.runtime.arena.flat_p.clone()
+        groups = [{"params": [p], "lr": 1e-3 if "image_encoder" in n else 1e-4, "weight_decay": 1e-4} for n, p in M.named_parameters()]
+        opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
+        sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
+        step = TrainStep(M, opt, sched, GradScaler(True), 10.0, None, graph=graph, graph_warmup=1, pad_to=LMAX if graph else None)
+        losses = []
+        for b in batches:                 # prior noise stays ON: eager and replayed steps draw it from the same device-side seed sequence
+            losses.append(step(b)["loss"].item())
+        torch.cuda.synchronize()
+        if graph:
+            assert step.eager_steps == 1 and step.replays == len(batches) - 1, (step.eager_steps, step.replays)      # capture on a SHORT batch (L = 10)
+        results.append((losses, M.runtime.arena.flat_p - p_init))
+    (l0, d0), (l1, d1) = results
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 2e-3, (l0, l1)
+    rel = ((d0 - d1).norm() / d0.norm()).item()
+    assert d0.norm().item() > 1e-3 and rel < 2e-2, (d0.norm().item(), rel)
+
+
 def test_graph_two_segment_step_with_exchange_single_rank():
     """Data-parallel form of the captured step: one hipGraph per phase (image/text forward, heads, image/text backward, update)
     with the all-reduces of the three gradient regions issued eagerly on the exchange stream between them. Forced on with one
@@ -381,6 +425,30 @@ def test_bench_under_torchrun_with_rccl_exchange_one_rank():
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
     assert res["launch"] == "hipGraph replay" and res["n_gpus"] == 1 and res["value"] > 0 and np.isfinite(res["loss"])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_keep_identical_parameters_through_captured_steps():
+    """Two ranks (one process each, both on this box's single GPU: `--single-device`, so the process group is gloo — RCCL needs one GPU per
+    rank) run bench.py's captured data-parallel step: per-phase hipGraphs with the three gradient-region all-reduces issued between them
+    (train_loop.TrainStep._replay_direct), different synthetic shards per rank. After warm-up + 5 replayed steps every rank's parameter
+    arena must be bit-identical (bench.py compares a 64-bit checksum across ranks: `replicas_identical`), i.e. each rank applied the same
+    mean gradient (reference train.py:174-178)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "3", "--batch", "16", "--visual", "resnet18", "--layers", "2",
+           "--backend", "gloo", "--single-device", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["launch"] == "hipGraph replay" and res["n_gpus"] == 2 and res["config"]["global_batch"] == 32
+    assert res["replicas_identical"] is True and np.isfinite(res["loss"])
 
 
 @pytest.mark.gpu

@@ -10,6 +10,19 @@ from simlib import Conv, bf16_round, from_bf16, lib, make_ep, ptr, to_bf16
 BF16, F32 = 0, 1
 
 
+@pytest.fixture(autouse=True, params=[1, 2, 3], ids=["w128", "w256x128", "w256"])
+def tile_policy(request):
+    """Every bf16 case runs once per wide-tile instantiation family (include/clite.h: clite_set_tile_policy forces the 128 x 128, 256 x 128 or
+    256 x 256 8-wave kernel wherever one exists; launches it does not cover — N <= 64, f32 — stay on the 4-wave kernels). f32 cases are
+    independent of the policy and run once."""
+    dtype = request.node.callspec.params.get("dtype", BF16) if hasattr(request.node, "callspec") else BF16
+    if dtype == F32 and request.param != 1:
+        pytest.skip("f32 launches do not depend on the tile policy")
+    assert lib().clite_set_tile_policy(request.param) == 0
+    yield request.param
+    lib().clite_set_tile_policy(0)
+
+
 def _prep(x, dtype):
     """returns (exact value array the kernel sees, buffer to pass)"""
     if dtype == BF16:
