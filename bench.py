@@ -88,30 +88,86 @@ def cpu_baseline(args):
         return {"value": None, "unit": "pairs/s", "cores": None, "kind": "port", "sample": f"cpu baseline did not finish within 240 s ({type(e).__name__})"}
 
 
+def kernel_source_hash():
+    """sha256 over everything that decides what the kernels do and how they are launched: csrc/, include/clite.h and the Python executors.
+    tools/pmc_traffic.py stores it next to the PMC byte counts; bench.py reports those counts only while the hash still matches."""
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "clip-lite_amd")
+    files = [os.path.join(ROOT, "include", "clite.h")]
+    for d, _, fs in sorted(os.walk(pkg)):
+        if "__pycache__" in d or os.sep + "lib" in d:
+            continue
+        files += [os.path.join(d, f) for f in sorted(fs) if f.endswith((".hip", ".h", ".py"))]
+    for f in sorted(files):
+        h.update(os.path.relpath(f, ROOT).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_hbm_traffic.json")
+
+
 def pmc_traffic(args):
-    """HBM-side bytes of the igemm family per step (all its launches), from the committed PMC passes of this configuration
-    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): counters cannot be
-    collected inside a timed run, so this is the profiles/ measurement, not a live one. None for other configurations."""
-    if args.visual != "resnet50" or args.layers != 12 or args.batch != 128 or args.f32 or args.loss != "jsd":
-        return None
+    """HBM-side bytes of the igemm family per step (all its launches) from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md: counters cannot be collected inside a timed
+    run). Reported only for the configuration they were taken on AND only while the kernel sources are the ones they were taken with
+    (kernel_source_hash); otherwise null — a stale number is worse than none."""
+    if args.visual != "resnet50" or args.layers != 12 or args.batch != 128 or args.f32 or args.loss != "jsd" or getattr(args, "fp8", False):
+        return None, "no PMC pass for this configuration"
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_igemm_hbm_traffic.json")) as f:
-            return json.load(f)["igemm_hbm_GB_per_step"] * 1e9
+        with open(TRAFFIC_JSON) as f:
+            d = json.load(f)
     except Exception:      # noqa: BLE001
-        return None
+        return None, "profiles/r2_hbm_traffic.json absent"
+    if d.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"PMC passes of {d.get('date')} were taken on other kernel sources (hash {d.get('kernel_source_hash')}): re-run tools/pmc_traffic.py"
+    return d["igemm_hbm_GB_per_step"] * 1e9, f"rocprofv3 PMC passes of {d.get('date')}, kernel sources {d['kernel_source_hash']} (profiles/r2_hbm_traffic.json)"
 
 
-def kernel_roofline(step_fn, batches, steps=3):
+def describe_launch(name, a, esz):
+    """(label, M, N, K, algorithmic bytes) of one implicit-GEMM launch from its C-ABI arguments: every operand read once and the output
+    written once (weight gradients: + the f32 accumulator read-modify-write) — SURVEY.md §8(d)'s per-launch figure."""
+    if name.startswith("clite_conv"):
+        cv = a[2]._obj
+        P, Q = cv.N * cv.Ho * cv.Wo, cv.N * cv.H * cv.W
+        kk = cv.R * cv.S * cv.C
+        lab = f"{cv.C:4d}->{cv.K:4d} {cv.R}x{cv.S}/{cv.stride} {cv.H:3d}->{cv.Ho:3d}"
+        if name == "clite_conv_fwd":
+            return lab, P, cv.K, kk, esz * (Q * cv.C + P * cv.K + cv.K * kk)
+        if name == "clite_conv_dgrad_s2class":     # one input-parity class of a 3x3 / stride-2 dgrad: a quarter of the pixels, its own taps
+            ph, pw = a[3], a[4]
+            taps = (1 if (ph + 1) & 1 else 2) * (1 if (pw + 1) & 1 else 2)
+            return lab + f" class {ph}{pw}", Q // 4, cv.C, taps * cv.K, esz * (Q * cv.C // 4 + P * cv.K + cv.K * taps * cv.C)
+        if name == "clite_conv_dgrad":
+            return lab, Q, cv.C, cv.R * cv.S * cv.K, esz * (Q * cv.C + P * cv.K + cv.K * kk)
+        return lab, cv.K, kk, P, esz * (Q * cv.C + P * cv.K) + 4 * cv.K * kk
+    if name.startswith("clite_stem"):
+        N, Ho, Wo = a[3], a[6], a[7]
+        P = N * Ho * Wo
+        if name == "clite_stem_fwd":
+            return "stem 7x7", P, 64, 224, esz * (N * a[4] * a[5] * 4 + P * 64)
+        return "stem 7x7", 64, 224, P, esz * (N * a[4] * a[5] * 4 + P * 64)
+    M, N, K = a[4], a[5], a[6]
+    if name == "clite_gemm_tn":
+        return "linear", M, N, K, esz * (K * M + K * N) + 4 * M * N
+    return "linear", M, N, K, esz * (M * K + N * K + M * N)
+
+
+IGEMM_ENTRY_POINTS = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_dgrad_s2class", "clite_conv_wgrad",
+                      "clite_stem_fwd", "clite_stem_wgrad")
+
+
+def kernel_roofline(step_fn, batches, steps=3, esz=2):
     """Average duration of the dominant kernel family (the implicit-GEMM engine: every conv / linear forward, dgrad and wgrad launch),
-    measured with events recorded on the stream the kernels are launched on, against its algorithmic FLOPs."""
+    measured with events recorded on the stream the kernels are launched on, with the algorithmic bytes and FLOPs of the same launches
+    (describe_launch) summed live. Returns (ms per step, launches per step, algorithmic bytes per step, launched FLOPs per step)."""
     from clip_lite_amd import hip
-    names = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_wgrad", "clite_stem_fwd", "clite_stem_wgrad")
     lib = hip.lib()
-    events, originals = [], {}
+    events, tally = [], [0.0, 0.0]
 
     def wrap(name):
         fn = getattr(lib, name)
-        originals[name] = fn
 
         def timed(*a):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -119,13 +175,16 @@ def kernel_roofline(step_fn, batches, steps=3):
             rc = fn(*a)
             e1.record()
             events.append((e0, e1))
+            _, M, N, K, nbytes = describe_launch(name, a, esz)
+            tally[0] += nbytes
+            tally[1] += 2.0 * M * N * K
             return rc
         return timed
 
     class Proxy:
         def __getattr__(self, k):
             return wrapped.get(k) or getattr(lib, k)
-    wrapped = {n: wrap(n) for n in names}
+    wrapped = {n: wrap(n) for n in IGEMM_ENTRY_POINTS}
     hip._lib = Proxy()
     try:
         for i in range(steps):
@@ -134,7 +193,7 @@ def kernel_roofline(step_fn, batches, steps=3):
     finally:
         hip._lib = lib
     total_ms = sum(e0.elapsed_time(e1) for e0, e1 in events)
-    return total_ms / steps, len(events) // steps
+    return total_ms / steps, len(events) // steps, tally[0] / steps, tally[1] / steps
 
 
 def main():
@@ -233,13 +292,14 @@ def main():
         replicas_identical = all(torch.equal(every[0], e) for e in every)
     # every rank runs the instrumented steps (they contain the gradient exchange, a collective); rank 0 reports its timings
     model.overlap_encoders = False          # per-launch durations: nothing else may share the chip with the timed kernel
-    gemm_ms, n_launch = kernel_roofline(eager_step, batches)
+    gemm_ms, n_launch, alg_bytes, launch_flops = kernel_roofline(eager_step, batches, esz=4 if args.f32 else 2)
     model.overlap_encoders = True
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
         gemm_tflops = FLOP_PER_PAIR * args.batch / (gemm_ms * 1e-3) / 1e12 if args.visual == "resnet50" and args.layers == 12 else None
+        traffic, traffic_note = pmc_traffic(args)
         res = {
             "metric": "image-caption pairs/sec (global batch) — ResNet-50+BERT bs1024, 1/2/4/8 MI355X",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -249,11 +309,12 @@ def main():
                                    f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)" + ("" if args.loss == "jsd" else ", InfoNCE all-pairs loss"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
             "loss": loss, "launch": "hipGraph replay" if step.graph else "eager", "replicas_identical": replicas_identical,
-            "roofline": {"bound": "mfma", "kernel": "clite::igemm_dma_kernel family (all conv/linear fwd+dgrad+wgrad launches of one step)",
+            "roofline": {"bound": "mfma", "kernel": "clite::igemm_dma_kernel / igemm_wide_kernel family (all conv/linear fwd+dgrad+wgrad launches of one step)",
                          "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": pmc_traffic(args),
+                         "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": traffic,
                          "launches_per_step": n_launch, "kernel_ms_per_step": gemm_ms,
-                         "algorithmic_bytes": 21.0e9, "traffic_note": "bytes per step over the same launches; PMC passes in profiles/r1_igemm_hbm_traffic.json",
+                         "algorithmic_bytes": alg_bytes, "launched_flops": launch_flops, "traffic_note": traffic_note,
+                         "kernel_source_hash": kernel_source_hash(),
                          "whole_step_frac": FLOP_PER_PAIR * args.batch / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if gemm_tflops else None},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -4,14 +4,18 @@
 // (optim/lookahead.py:88-101), and the bf16 weight copy the next forward reads — one pass over flat buffers.
 // Pure HBM streaming: per element 4 f32 reads (p, g, v, slow on sync steps) and up to 4 writes.
 #include "vec.h"
-#include "det.h"
 #include "clite.h"
 
 using namespace clite;
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* x, size_t n, float* out) {
+// Squared gradient norm in two fixed-order stages: every workgroup stores ONE partial (plain store, its own slot), then a single workgroup
+// folds the partials in slot order. No float atomics: the result is a pure function of the data, so every data-parallel rank derives the
+// same clip factor from the same all-reduced gradients and the replicas stay bit-identical (torch's clip_grad_norm_ has that property;
+// an atomically accumulated norm differs in the last bit from rank to rank, and BatchNorm amplifies such differences step after step).
+constexpr int SUMSQ_MAX_GRID = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* x, size_t n, float* partials) {
   __shared__ float red[4];
   float s = 0.f;
   size_t n4 = n / 4;
@@ -24,7 +28,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* x, size_t n, fl
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomic_add_f32(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partials, int n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);      // `out` is pre-zeroed by contract; += keeps the accumulate semantics
 }
 
 // hp: [0] lr multiplier (schedule), [1] momentum, [2] max grad norm (<= 0: no clipping), [3] lookahead sync flag,
@@ -83,12 +96,13 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16* 
 
 }  // namespace
 
-extern "C" int clite_sumsq(const float* x, uint64_t n, float* out, void* stream) {
-  if (!x || !out) return -1;
+extern "C" int clite_sumsq(const float* x, uint64_t n, float* out, float* partials, int n_partials, void* stream) {
+  if (!x || !out || !partials || n_partials < 1) return -1;
   size_t g = (n / 4 + 255) / 256;
-  int grid = (int)(g < 2048 ? (g ? g : 1) : 2048);
-  if (clite::deterministic()) grid = 1;       // det.h: a single workgroup forms the whole sum in one order
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, out);
+  int grid = (int)(g < (size_t)SUMSQ_MAX_GRID ? (g ? g : 1) : SUMSQ_MAX_GRID);
+  if (grid > n_partials) grid = n_partials;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, partials);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partials, grid, out);
   return (int)hipGetLastError();
 }
 

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -95,7 +95,7 @@ _SIGNATURES = {
     "clite_loss_finalize": [_V, _F, _V, _V],
     "clite_add": [_I, _V, _V, _V, _U64, _V],
     "clite_uniform_fill": [_I, _V, _U64, _U64, _U32, _V],
-    "clite_sumsq": [_V, _U64, _V, _V],
+    "clite_sumsq": [_V, _U64, _V, _V, _I, _V],
     "clite_sgd_step": [_V, _V, _V, _V, _V, _V, _I, _V, _V, _V],
     "clite_cast_bf16": [_V, _V, _U64, _V],
 }
@@ -413,8 +413,8 @@ def uniform_fill(dt, out, n, seed, site):
     check(lib().clite_uniform_fill(dt, p(out), n, seed, site, stream_ptr(out)), "uniform_fill")
 
 
-def sumsq(x, n, out):
-    check(lib().clite_sumsq(p(x), n, p(out), stream_ptr(x)), "sumsq")
+def sumsq(x, n, out, partials):
+    check(lib().clite_sumsq(p(x), n, p(out), p(partials), partials.numel(), stream_ptr(x)), "sumsq")
 
 
 def sgd_step(pf, gf, vf, slow, cast, items_ptr, n_items, hp, ss):

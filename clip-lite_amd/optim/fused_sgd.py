@@ -30,6 +30,7 @@ class FusedSGD(torch.optim.Optimizer):
         self.flat_slow = self.arena.flat_p.clone()
         self.hp = torch.zeros(8, device=dev, dtype=torch.float32)
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.sumsq_partials = torch.zeros(1024, device=dev, dtype=torch.float32)      # clite_sumsq's fixed-order first stage
         self.max_norm = 0.0
         self.grad_prescale = 1.0
         self._items = None
@@ -91,7 +92,7 @@ class FusedSGD(torch.optim.Optimizer):
         self._build_items()
         self.zero_frozen()           # stale / unconditional gradients of frozen tensors must not enter the norm
         self.sumsq.zero_()
-        hip.sumsq(self.arena.flat_g, self.arena.total, self.sumsq)
+        hip.sumsq(self.arena.flat_g, self.arena.total, self.sumsq, self.sumsq_partials)
         return self.sumsq.sqrt() * self.grad_prescale
 
     def zero_grad(self, set_to_none: bool = False):

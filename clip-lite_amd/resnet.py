@@ -228,22 +228,38 @@ def _bn_backward_apply(rt, u, dz, dstats):
     return dy
 
 
-def resnet_backward(rt, net, ctx, dfeat):
+def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False):
     """dfeat: [N][C] gradient of the pooled features (compute dtype). Accumulates parameter gradients into the arena.
 
     BatchNorm backward needs two per-channel reductions over the masked incoming gradient before it can produce its output. Where
     that gradient is written by a dgrad GEMM, the GEMM's epilogue applies the ReLU mask and accumulates both reductions while it
     stores (clite_epilogue.bn_y), so the separate reduction pass (3 tensor reads) disappears: inside a block for every unit but the
-    last, and across blocks whenever the block-input gradient comes out of one kernel (identity shortcut)."""
+    last, and across blocks whenever the block-input gradient comes out of one kernel (identity shortcut).
+
+    Only dgrad -> BN backward -> dgrad ... is a dependency chain; every weight-gradient GEMM needs just dy and the saved input and feeds
+    nothing but the gradient arena. `defer` (a list) collects them as closures instead of launching them, so the caller can run them
+    elsewhere — the captured step (train_loop.TrainStep) replays the weight gradients of the late stages on the text encoder's stream once
+    BERT's backward has drained, beside the HBM-bound BatchNorm chain of the early stages. `stop_block` / `resume` cut the chain in two
+    segments for that: the first call stops after block `stop_block` and parks (dout, pre) in ctx; `resume=True` continues from there."""
     N = ctx["N"]
     dt = rt.dt
-    Hc, Wc, Cout = ctx["final"]
-    dout = _alloc(rt, N * Hc * Wc, Cout)
-    hip.avgpool_bwd(dt, dfeat, dout, N, Hc * Wc, Cout)
     blocks = list(net.blocks())
     recs = ctx["recs"]
-    pre = None          # when set: `dout` is already masked by the block-output ReLU and `pre` holds the last unit's reductions
-    for bi in range(len(recs) - 1, -1, -1):
+
+    def wgrad(fn, *tensors):
+        if defer is None:
+            rt.aux_launch(fn, *tensors)
+        else:
+            defer.append(fn)          # the closure keeps dy / x referenced until it has run
+
+    if resume:
+        dout, pre, first = ctx.pop("bwd_state")
+    else:
+        Hc, Wc, Cout = ctx["final"]
+        dout = _alloc(rt, N * Hc * Wc, Cout)
+        hip.avgpool_bwd(dt, dfeat, dout, N, Hc * Wc, Cout)
+        pre, first = None, len(recs) - 1          # pre: when set, `dout` is already masked by the block-output ReLU and `pre` holds the last unit's reductions
+    for bi in range(first, stop_block - 1, -1):
         units, ud, Hin, Win = recs[bi]
         last = units[-1]
         identity = ud is None
@@ -262,7 +278,7 @@ def resnet_backward(rt, net, ctx, dfeat):
         for i in range(len(units) - 1, -1, -1):
             u = units[i]
             if u.conv.weight.requires_grad:
-                rt.aux_launch(lambda dy=dy, u=u: hip.conv_wgrad(dy, u.x, u.cv, rt.arena.g(u.conv.weight)), dy)
+                wgrad(lambda dy=dy, u=u: hip.conv_wgrad(dy, u.x, u.cv, rt.arena.g(u.conv.weight)), dy)
             Cin = u.conv.in_channels
             dx = _alloc(rt, u.x.shape[0], Cin)
             if i > 0 and not rt.fuse_bn_backward:
@@ -290,11 +306,15 @@ def resnet_backward(rt, net, ctx, dfeat):
                     hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None))
                     if ud is not None:
                         if ud.conv.weight.requires_grad:
-                            rt.aux_launch(lambda dyd=dyd, ud=ud: hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight)), dyd)
+                            wgrad(lambda dyd=dyd, ud=ud: hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight)), dyd)
                         # shortcut branch accumulated in place (dx += dgrad); a strided 1x1 shortcut takes the scatter-add path of clite_conv_dgrad
                         hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx, Cin, residual=dx))
                 dout = dx
-        rt.grads_ready(blocks[bi])
+        if defer is None:
+            rt.grads_ready(blocks[bi])
+    if stop_block > 0:
+        ctx["bwd_state"] = (dout, pre, stop_block - 1)
+        return
     xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq = ctx["stem"]
     da0 = _alloc(rt, N * Ho * Wo, 64)
     hip.maxpool_bwd(dt, dout, idx, da0, N, Ho, Wo, 64)
@@ -302,9 +322,15 @@ def resnet_backward(rt, net, ctx, dfeat):
     u0.y, u0.stats, u0.bn = y0, st0, net.bn1
     dy0, _ = _bn_backward(rt, u0, da0, a0, N)
     if net.conv1.weight.requires_grad:
-        dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)
-        hip.stem_wgrad(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, dwv)
-        hip.stem_unpack_grad(dwv, rt.arena.g(net.conv1.weight))
-    rt.join_aux()
-    rt.grads_ready(net.conv1)
-    rt.grads_ready(net.bn1)
+        def stem_wgrad(dy0=dy0):
+            dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)
+            hip.stem_wgrad(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, dwv)
+            hip.stem_unpack_grad(dwv, rt.arena.g(net.conv1.weight))
+        if defer is None:
+            stem_wgrad()
+        else:
+            defer.append(stem_wgrad)
+    if defer is None:
+        rt.join_aux()
+        rt.grads_ready(net.conv1)
+        rt.grads_ready(net.bn1)

@@ -109,9 +109,9 @@ class TrainStep:
     # (measured: 84 % of a one-graph step had exactly one kernel in flight), so real concurrency between the two encoders needs
     # separate graphs on separate streams:
     #
-    #   main : [image fwd] ------------> [heads fwd + bwd] --> [image bwd] --------------------> [norm + update]
-    #   side : [text  fwd] --(join)--^          (fork)-----> [text  bwd] --(join)---------------^
-    #   comm :                                     all-reduce(heads)  all-reduce(text)  all-reduce(image)     (data parallel)
+    #   main : [image fwd] ------------> [heads fwd + bwd] --> [image bwd: layer4,3 | layer2,1,stem chain] [wgrads 2,1,stem] --> [norm + update]
+    #   side : [text  fwd] --(join)--^          (fork)-----> [text  bwd] ------(after layer3's chain)--> [wgrads of layer4,3] --(join)--^
+    #   comm :                                     all-reduce(heads)                     all-reduce(text)  all-reduce(image)     (data parallel)
     #
     # Graphs that replay on the same stream share a memory pool (they run in capture order); the two streams use different pools,
     # and every tensor that crosses a stream (features, their gradients) is kept referenced for the lifetime of the graphs.
@@ -165,8 +165,27 @@ class TrainStep:
             keep["result"] = {"loss": out[0].clone(), "loss_components": {"total_loss": out[0].clone(), "cross_modal_loss": out[1].clone(),
                                                                           "visual_loss": out[3].clone(), "textual_loss": out[4].clone()}}
 
-        def image_bwd():
-            resnet_backward(rt, m.image_encoder.img_encoder, keep["ctx_i"], keep["dimg"].contiguous())
+        # image backward in two chain segments with the weight gradients collected instead of launched (resnet_backward's `defer`): those of
+        # the late stages (layer3, layer4 — compute-bound, small tensors) replay on the text encoder's stream after BERT's backward, beside
+        # the HBM-bound BatchNorm chain of layer2 / layer1; the rest follow the chain on the main stream
+        inet = m.image_encoder.img_encoder
+        split = len(inet.layer1) + len(inet.layer2)
+
+        def image_bwd_a():
+            keep["wg_a"] = []
+            resnet_backward(rt, inet, keep["ctx_i"], keep["dimg"].contiguous(), defer=keep["wg_a"], stop_block=split)
+
+        def image_bwd_b():
+            keep["wg_b"] = []
+            resnet_backward(rt, inet, keep["ctx_i"], None, defer=keep["wg_b"], resume=True)
+
+        def wgrad_a():
+            for fn in keep["wg_a"]:
+                fn()
+
+        def wgrad_b():
+            for fn in keep["wg_b"]:
+                fn()
 
         def text_bwd():
             bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous())
@@ -182,7 +201,10 @@ class TrainStep:
                 capture("text_fwd", pool_side, text_fwd)
                 capture("heads", pool_main, heads)
                 capture("text_bwd", pool_side, text_bwd)
-                capture("image_bwd", pool_main, image_bwd)
+                capture("image_bwd_a", pool_main, image_bwd_a)
+                capture("wgrad_a", pool_side, wgrad_a)
+                capture("image_bwd_b", pool_main, image_bwd_b)
+                capture("wgrad_b", pool_main, wgrad_b)
                 capture("update", pool_main, update)
         except BaseException:
             rt.abort_capture()
@@ -207,9 +229,16 @@ class TrainStep:
             ex.reduce_span(*self._regions["loss"], after=main)
         with torch.cuda.stream(side):
             G["text_bwd"].replay()
-        G["image_bwd"].replay()
         if ex is not None:
-            ex.reduce_span(*self._regions["text_encoder"], after=side)
+            ex.reduce_span(*self._regions["text_encoder"], after=side)          # ordered after BERT's backward only (the event is taken now)
+        G["image_bwd_a"].replay()
+        side.wait_stream(main)                     # the late stages' dy are final
+        with torch.cuda.stream(side):
+            G["wgrad_a"].replay()
+        G["image_bwd_b"].replay()
+        G["wgrad_b"].replay()
+        if ex is not None:
+            main.wait_stream(side)
             ex.reduce_span(*self._regions["image_encoder"], after=main)
             covered = sorted(self._regions.values())
             pos = 0
@@ -333,7 +362,7 @@ class TrainStep:
 
 def hip_sumsq(opt):
     from . import hip
-    hip.sumsq(opt.arena.flat_g, opt.arena.total, opt.sumsq)
+    hip.sumsq(opt.arena.flat_g, opt.arena.total, opt.sumsq, opt.sumsq_partials)
 
 
 def main(_A: argparse.Namespace):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 5
+#define CLITE_ABI_VERSION 6
 int clite_abi_version(void);
 
 /* Deterministic-reduction mode (process-wide, default off; the counterpart of torch.use_deterministic_algorithms for this library).
@@ -258,8 +258,10 @@ typedef struct clite_optim_item {   /* one workgroup's slice of one parameter te
   float wd;                         /* weight decay of the owning tensor's param group */
   uint32_t reserved;
 } clite_optim_item;
-/* out (f32 scalar, pre-zeroed) += sum x^2 — the global gradient norm of clip_grad_norm_ */
-int clite_sumsq(const float* x, uint64_t n, float* out, void* stream);
+/* out (f32 scalar, pre-zeroed) += sum x^2 — the global gradient norm of clip_grad_norm_. Two fixed-order stages through `partials`
+ * (device f32[n_partials], n_partials >= 1; 1024 slots use the whole chip): no float atomics, so the value is a pure function of x and every
+ * data-parallel rank derives the same clip factor from the same all-reduced gradients (replicas stay bit-identical). */
+int clite_sumsq(const float* x, uint64_t n, float* out, float* partials, int n_partials, void* stream);
 /* hp (device f32[6]): lr multiplier, momentum, max grad norm (<=0 off), lookahead-sync flag, lookahead alpha, grad pre-scale.
  * g' = g*prescale*clip + wd*p; v = mu*v + g'; p -= lr*mult*v; on sync steps p = alpha*p + (1-alpha)*slow, slow = p.
  * g is zeroed; cast_bf16 (optional) receives the bf16 copy of p at the same offsets. */

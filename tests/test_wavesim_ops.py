@@ -357,9 +357,9 @@ def test_uniform_and_optimizer():
     v = rng.standard_normal(n).astype(np.float32); slow = rng.standard_normal(n).astype(np.float32)
     p0, g0, v0, s0 = p.copy(), g.copy(), v.copy(), slow.copy()
     items = (Item * 3)(Item(0, 1024, 0.2, 1e-4, 0), Item(1024, 1024, 0.2, 1e-4, 0), Item(2048, 512, 1e-3, 0.0, 0))
-    L.clite_sumsq.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
-    ss = np.zeros(1, np.float32)
-    assert L.clite_sumsq(ptr(g), n, ptr(ss), None) == 0
+    L.clite_sumsq.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    ss, parts = np.zeros(1, np.float32), np.zeros(7, np.float32)      # 7 partial slots: the launcher caps its grid at the slots it is given
+    assert L.clite_sumsq(ptr(g), n, ptr(ss), ptr(parts), 7, None) == 0
     assert abs(ss[0] - (g0.astype(np.float64) ** 2).sum()) < 1e-2
     cast = np.zeros(n, np.uint16)
     for sync in (0.0, 1.0):

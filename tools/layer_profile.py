@@ -13,30 +13,6 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 
-def describe(name, a, esz):
-    """-> (label, M, N, K, min_bytes)"""
-    if name.startswith("clite_conv"):
-        cv = a[2]._obj
-        P, Q = cv.N * cv.Ho * cv.Wo, cv.N * cv.H * cv.W
-        kk = cv.R * cv.S * cv.C
-        lab = f"{cv.C:4d}->{cv.K:4d} {cv.R}x{cv.S}/{cv.stride} {cv.H:3d}->{cv.Ho:3d}"
-        if name == "clite_conv_fwd":
-            return lab, P, cv.K, kk, esz * (Q * cv.C + P * cv.K + cv.K * kk)
-        if name == "clite_conv_dgrad":
-            return lab, Q, cv.C, cv.R * cv.S * cv.K, esz * (Q * cv.C + P * cv.K + cv.K * kk)
-        return lab, cv.K, kk, P, esz * (Q * cv.C + P * cv.K) + 4 * cv.K * kk
-    if name.startswith("clite_stem"):
-        N, Ho, Wo = a[3], a[6], a[7]
-        P = N * Ho * Wo
-        if name == "clite_stem_fwd":
-            return "stem 7x7", P, 64, 224, esz * (N * a[4] * a[5] * 4 + P * 64)
-        return "stem 7x7", 64, 224, P, esz * (N * a[4] * a[5] * 4 + P * 64)
-    M, N, K = a[4], a[5], a[6]
-    if name == "clite_gemm_tn":
-        return "linear", M, N, K, esz * (K * M + K * N) + 4 * M * N
-    return "linear", M, N, K, esz * (M * K + N * K + M * N)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
@@ -58,7 +34,7 @@ def main():
     for i in range(3):
         step(batches[i % 2])
     torch.cuda.synchronize()
-    names = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_wgrad", "clite_stem_fwd", "clite_stem_wgrad")
+    names = bench.IGEMM_ENTRY_POINTS
     lib = hip.lib()
     recs = []
 
@@ -70,7 +46,7 @@ def main():
             e0.record()
             rc = fn(*a)
             e1.record()
-            recs.append((name, describe(name, a, 4 if args.f32 else 2), e0, e1))
+            recs.append((name, bench.describe_launch(name, a, 4 if args.f32 else 2), e0, e1))
             return rc
         return timed
     wrapped = {n: wrap(n) for n in names}

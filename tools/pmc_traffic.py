@@ -2,13 +2,20 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline
-    python tools/pmc_traffic.py <fetch .db> <write .db> profiles/r1_igemm_hbm_traffic.json
+    python tools/pmc_traffic.py <fetch .db> <write .db> profiles/r2_hbm_traffic.json
+
+The output records the date and bench.kernel_source_hash() (sha256 over csrc/, include/clite.h and the Python executors): bench.py reports
+`roofline.traffic` only while that hash matches the tree it runs from, so a kernel change without new PMC passes yields null, not a stale number.
 
 Both counters are reported in KiB; FETCH_SIZE is doubled (gfx950 tallies 64 B per 128-B request, MI355X_MICROARCH.md). Steps are counted by
 the update kernel's dispatches (one per step); bench.py's per-launch roofline pass runs extra eager steps, which are steps like any other."""
+import datetime
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_family(db, counter):
@@ -19,7 +26,7 @@ def per_family(db, counter):
     for name, val, n in rows:
         if "sgd_step_kernel" in name:
             steps = n
-        key = "igemm" if ("igemm" in name or "splitk_finish" in name) else "bn" if "bn_" in name else "other"
+        key = "igemm" if ("igemm" in name or "splitk_finish" in name or "colstats_det" in name) else "bn" if "bn_" in name else "other"
         fam[key][0] += val
         fam[key][1] += n
     return fam, steps
@@ -30,7 +37,10 @@ def main():
     f, sf = per_family(fdb, "FETCH_SIZE")
     w, sw = per_family(wdb, "WRITE_SIZE")
     kib = 1024.0
+    import bench
     res = {
+        "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+        "kernel_source_hash": bench.kernel_source_hash(),
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline; tools/pmc_traffic.py",
         "correction": "FETCH_SIZE doubled (gfx950 tallies 64 B per 128-B request, MI355X_MICROARCH.md); WRITE_SIZE as reported; float-atomic traffic (weight gradients, split-K workspaces) is in WRITE_SIZE",
         "steps_in_pass": [sf, sw],
