@@ -155,7 +155,20 @@ def describe_launch(name, a, esz):
 
 
 IGEMM_ENTRY_POINTS = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_dgrad_s2class", "clite_conv_wgrad",
-                      "clite_stem_fwd", "clite_stem_wgrad")
+                      "clite_stem_fwd", "clite_stem_wgrad", "clite_wgrad_group")
+
+
+def describe_group(a, esz):
+    """Members of one clite_wgrad_group call -> [(label, M, N, K, algorithmic bytes)]"""
+    out = []
+    for it in a[1][:a[2]]:
+        if it.kind == 0:
+            cv = it.cv
+            P, Q, kk = cv.N * cv.Ho * cv.Wo, cv.N * cv.H * cv.W, cv.R * cv.S * cv.C
+            out.append((f"{cv.C:4d}->{cv.K:4d} {cv.R}x{cv.S}/{cv.stride} {cv.H:3d}->{cv.Ho:3d}", cv.K, kk, P, esz * (Q * cv.C + P * cv.K) + 4 * cv.K * kk))
+        else:
+            out.append(("linear", it.M, it.N, it.K, esz * (it.K * it.M + it.K * it.N) + 4 * it.M * it.N))
+    return out
 
 
 def kernel_roofline(step_fn, batches, steps=3, esz=2):
@@ -175,9 +188,10 @@ def kernel_roofline(step_fn, batches, steps=3, esz=2):
             rc = fn(*a)
             e1.record()
             events.append((e0, e1))
-            _, M, N, K, nbytes = describe_launch(name, a, esz)
-            tally[0] += nbytes
-            tally[1] += 2.0 * M * N * K
+            members = describe_group(a, esz) if name == "clite_wgrad_group" else [describe_launch(name, a, esz)]
+            for _, M, N, K, nbytes in members:
+                tally[0] += nbytes
+                tally[1] += 2.0 * M * N * K
             return rc
         return timed
 

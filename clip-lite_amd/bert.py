@@ -125,13 +125,20 @@ def _alloc(rt, *shape):
     return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
 
 
-def _linear_grads(rt, lin, dy, x, M, dw=None, db=None, bias_done=False):
+def _linear_grads(rt, lin, dy, x, M, dw=None, db=None, bias_done=False, defer=None):
     """dW[N][K] += dy^T x ; db += colsum(dy) for a LinearParams (or explicit arena views for fused q/k/v). bias_done: the kernel that
-    produced dy already accumulated its column sums into the bias gradient (clite_layernorm_bwd's dcolsum)."""
+    produced dy already accumulated its column sums into the bias gradient (clite_layernorm_bwd's dcolsum). defer: a hip.WgradGroup that
+    collects the launches instead (bert_backward)."""
     N, K = dy.shape[1], x.shape[1]
     if dw is None:
         dw = rt.arena.g(lin.weight) if lin.weight.requires_grad else None
         db = rt.arena.g(lin.bias) if (lin.bias is not None and lin.bias.requires_grad and not bias_done) else None
+    if defer is not None:
+        if dw is not None:
+            defer.linear(dy, x, N, K, M, dw)
+        if db is not None:
+            defer.call(lambda: hip.colsum(rt.dt, dy, db, M, N))
+        return
 
     def launch():
         if dw is not None:
@@ -197,19 +204,28 @@ def bert_forward(rt, net, input_ids, attention_mask, step):
     return pooled, ctx
 
 
-def bert_backward(rt, net, ctx, dpooled):
+def bert_backward(rt, net, ctx, dpooled, defer=None):
+    """defer: a hip.WgradGroup — the 4 x 12 + 1 linear weight gradients are collected and left to the caller to launch (as one grouped launch)
+    instead of being enqueued one by one between the input-gradient GEMMs."""
     dt, A = rt.dt, rt.arena
     B, L = ctx["B"], ctx["L"]
     Hd, heads, inner = net.hidden, net.heads, net.inner
     M = B * L
+    own_group = None
+    if defer is None and rt.group_wgrad and not rt.overlap_wgrad and not rt._capturing:      # (a capture cannot allocate the pinned staging)
+        defer = own_group = hip.WgradGroup(rt.dt)          # uncaptured backward: grouped launch at the end of this call
     # pooler: dpre = dpooled * (1 - y^2); h[:, 0] rows only
     dpre = _alloc(rt, B, Hd)
     hip.tanh_bwd(dt, dpooled, ctx["pooled"], dpre, B * Hd)
     pw = net.pooler.dense
     if pw.weight.requires_grad:
-        hip.gemm_tn(dt, dpre, ctx["h_last"], Hd, Hd, B, hip.epilogue(A.g(pw.weight), Hd, atomic=True, out_f32=True), ldb=L * Hd)
+        if defer is not None:
+            defer.linear(dpre, ctx["h_last"], Hd, Hd, B, A.g(pw.weight), ldb=L * Hd)
+        else:
+            hip.gemm_tn(dt, dpre, ctx["h_last"], Hd, Hd, B, hip.epilogue(A.g(pw.weight), Hd, atomic=True, out_f32=True), ldb=L * Hd)
         hip.colsum(dt, dpre, A.g(pw.bias), B, Hd)
-    rt.grads_ready(net.pooler)
+    if own_group is None:
+        rt.grads_ready(net.pooler)
     dh = torch.zeros(M, Hd, device=rt.device, dtype=rt.tdtype)
     hip.gemm_nn(dt, dpre, A.w(pw.weight), B, Hd, Hd, hip.epilogue(dh, L * Hd, ws=rt.gemm_ws(B, Hd)))
     for (layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2) in reversed(ctx["layers"]):
@@ -220,10 +236,10 @@ def bert_backward(rt, net, ctx, dpooled):
         hip.layernorm_bwd(dt, dh, s2, st2, out.LayerNorm.weight, ds2, ds2m, A.g(out.LayerNorm.weight), A.g(out.LayerNorm.bias), M, Hd, drop_out=d2,
                           dcolsum=A.g(out.dense.bias))
         dz2 = ds2m if ds2m is not None else ds2
-        _linear_grads(rt, out.dense, dz2, g, M, bias_done=True)
+        _linear_grads(rt, out.dense, dz2, g, M, bias_done=True, defer=defer)
         df = _alloc(rt, M, inner)
         hip.gemm_nn(dt, dz2, A.w(out.dense.weight), M, inner, Hd, hip.epilogue(df, inner, dact_aux=f, dact=hip.DACT_GELU))
-        _linear_grads(rt, layer.intermediate.dense, df, h1, M)
+        _linear_grads(rt, layer.intermediate.dense, df, h1, M, defer=defer)
         dh1 = _alloc(rt, M, Hd)
         hip.gemm_nn(dt, df, A.w(layer.intermediate.dense.weight), M, Hd, inner, hip.epilogue(dh1, Hd, residual=ds2))
         # LayerNorm 1 -> (dropout) -> attention output projection
@@ -232,23 +248,28 @@ def bert_backward(rt, net, ctx, dpooled):
         hip.layernorm_bwd(dt, dh1, s1, st1, so.LayerNorm.weight, ds1, ds1m, A.g(so.LayerNorm.weight), A.g(so.LayerNorm.bias), M, Hd, drop_out=d1,
                           dcolsum=A.g(so.dense.bias))
         dz1 = ds1m if ds1m is not None else ds1
-        _linear_grads(rt, so.dense, dz1, ctxt, M, bias_done=True)
+        _linear_grads(rt, so.dense, dz1, ctxt, M, bias_done=True, defer=defer)
         dctx = _alloc(rt, M, Hd)
         hip.gemm_nn(dt, dz1, A.w(so.dense.weight), M, Hd, Hd, hip.epilogue(dctx, Hd))
         dqkv = _alloc(rt, M, 3 * Hd)
         hip.attention_bwd(dt, qkv, ctx["mask"], dctx, dqkv, B, L, heads, da)
         wqkv = A.span([sa.query.weight, sa.key.weight, sa.value.weight])
         _linear_grads(rt, None, dqkv, h, M, dw=A.span([sa.query.weight, sa.key.weight, sa.value.weight], grad=True).view(3 * Hd, Hd),
-                      db=A.span([sa.query.bias, sa.key.bias, sa.value.bias], grad=True))
+                      db=A.span([sa.query.bias, sa.key.bias, sa.value.bias], grad=True), defer=defer)
         dhp = _alloc(rt, M, Hd)
         hip.gemm_nn(dt, dqkv, wqkv, M, Hd, 3 * Hd, hip.epilogue(dhp, Hd, residual=ds1))
         dh = dhp
-        rt.grads_ready(layer)
+        if own_group is None:
+            rt.grads_ready(layer)
     emb = net.embeddings
     ds0 = _alloc(rt, M, Hd)
     hip.layernorm_bwd(dt, dh, ctx["s0"], ctx["st0"], emb.LayerNorm.weight, ds0, None, A.g(emb.LayerNorm.weight), A.g(emb.LayerNorm.bias), M, Hd,
                       drop_in=ctx["d0"], dcolsum=A.g(emb.token_type_embeddings.weight)[0])      # token_type_ids = 0: every row adds to row 0
     hip.embed_bwd(dt, ctx["ids"], ds0, A.g(emb.word_embeddings.weight), A.g(emb.position_embeddings.weight), M, L, Hd, net.vocab,
                   padding_idx=0)      # HF BertEmbeddings: nn.Embedding(vocab, hidden, padding_idx=pad_token_id = 0)
-    rt.join_aux()
-    rt.grads_ready(emb)
+    if own_group is not None:
+        own_group.launch()
+        rt.grads_ready(net)
+    else:
+        rt.join_aux()
+        rt.grads_ready(emb)

@@ -1,0 +1,274 @@
+// Grouped weight gradients: ONE launch for many independent dW_p[M_p][N_p] += A_p^T B_p (conv wgrad: A = dY, B = im2col(x); linear wgrad:
+// A = dY, B = x), contracted over the pixels / tokens K_p.
+//
+// Why: a single weight gradient cannot fill the chip — its output is a few dozen 128 x 128 tiles — so igemm_dma_kernel splits K until ~500
+// workgroups exist and pays for it: every split adds a whole f32 output tile of float-atomic traffic (chip-wide ~1.3 TB/s) plus a prologue
+// and an epilogue. Measured on MI355X (tools/probe_tn_full.py): the BERT FFN gradient 3072 x 768 x 3840 runs at 328 TF/s alone, the same
+// kernel at 12288 x 2304 x 3840 (tiles enough, no split) at 666 TF/s; 512 x 4608 x 6272 (layer4 3x3) 425 -> 716 TF/s. The weight gradients of a
+// backward pass are independent of each other, so the captured train step (train_loop.TrainStep) collects them per stage and launches each
+// collection once: thousands of workgroups without splitting the short-K problems at all; only the long-K / small-output ones (layer1, layer2:
+// 100k-400k pixels into 64 x 576 outputs) are cut into k-chunks of <= 128 K tiles so that all workgroups run about equally long.
+//
+// Layout of the workspace the caller hands over (device copy + pinned host staging of the same size): [items][wg map]; the library fills the
+// host side, copies it with one hipMemcpyAsync on the launch stream (a memcpy node when the stream is being captured) and launches. bf16 only;
+// the exact-f32 mode and the deterministic-reduction mode run the members one by one through clite_conv_wgrad / clite_gemm_tn.
+#include "igemm_dma.h"
+#include "det.h"
+#include <string.h>
+#include <vector>
+
+using namespace clite;
+
+namespace {
+
+constexpr int GBK = 32;                 // K tile (bf16)
+constexpr int KCHUNK = 128;             // K tiles per workgroup at most
+
+template <class LA, class LB>
+struct GroupItem {
+  LA la;
+  LB lb;
+  float* out;
+  int ldc, M, N, ktiles, chunk;
+};
+struct WgEntry { uint32_t item, tile_m, tile_n, kchunk; };      // one per workgroup
+
+template <class CFG, class LA, class LB, int NSTAGE>
+__global__ __launch_bounds__(256) void igemm_group_kernel(const GroupItem<LA, LB>* __restrict__ items, const WgEntry* __restrict__ map) {
+  typedef bf16 T;
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int LOADS_PER_TILE = LA::NI + LB::NI;
+  __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+  const WgEntry e = map[blockIdx.x];
+  const GroupItem<LA, LB>& it = items[wave_uniform((int)e.item)];
+  const LA la = it.la;
+  const LB lb = it.lb;
+  const int M = it.M, N = it.N;
+  const int m0 = wave_uniform((int)e.tile_m) * BM, n0 = wave_uniform((int)e.tile_n) * BN;
+  const int t_begin = wave_uniform((int)e.kchunk) * it.chunk;
+  int t_end = t_begin + it.chunk;
+  if (t_end > it.ktiles) t_end = it.ktiles;
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, wave, lane, t_begin);
+  lb.init(sb, n0, wave, lane, t_begin);
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int aoff[RM][BK / 16], boff[RN][BK / 16];
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i) aoff[i][ks] = LA::frag_off(wm0 + i * 32, ks, lane);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) boff[j][ks] = LB::frag_off(wn0 + j * 32, ks, lane);
+  }
+#pragma unroll
+  for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+    if (t_begin + pz < t_end) {
+      DmaIssue<LA>::go(la, sa, smem + pz * STAGE, wave, lane, m0);
+      DmaIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
+    }
+  }
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t) {      // igemm_dma_kernel's pipeline: counted vmcnt, one raw barrier per K tile
+    const int after = t_end - 1 - t;
+    if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
+    else wait_vmcnt<0>();
+    barrier_raw();
+    const char* abuf = smem + buf * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+    bf16x8 af0[RM], bf0[RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) bf0[j] = LB::frag_at(bbuf + boff[j][0]);
+    if (t + NSTAGE - 1 < t_end) {
+      int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+      DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+      DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 af[RM], bfr[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+    }
+    if (++buf == NSTAGE) buf = 0;
+  }
+  float* out = it.out;
+  const int ldc = it.ldc;
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const int col = n0 + wn0 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) atomic_add_f32(out + (size_t)row * ldc + col, acc[i][j][r]);
+      }
+    }
+}
+
+FastDiv fastdiv_make(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.mul = 0; f.shift = 0; f.d = 1; return f; }
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = l;
+  f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  return f;
+}
+ConvGeom geom_fwd(const clite_conv& c) {
+  ConvGeom g;
+  g.H = c.H; g.W = c.W; g.C = c.C;
+  g.sN = c.H * c.W * c.C; g.sH = c.W * c.C; g.sW = c.C;
+  g.RH = c.Ho; g.RW = c.Wo; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
+  g.rows = c.N * c.Ho * c.Wo;
+  g.div_hw = fastdiv_make(c.Ho * c.Wo);
+  g.div_w = fastdiv_make(c.Wo);
+  return g;
+}
+
+typedef TileCfg<128, 128, GBK, 64, 64> C128;
+typedef TileCfg<64, 128, GBK, 64, 32> C64x128;
+typedef TileCfg<128, 64, GBK, 32, 64> C128x64;
+typedef DmaXCStrided<bf16, 128, GBK> XS128;
+typedef DmaXCStrided<bf16, 64, GBK> XS64;
+typedef DmaXCGather<bf16, 128, GBK> XG128;
+typedef DmaXCGather<bf16, 64, GBK> XG64;
+
+struct Plan { int M, N, Ktot, ktiles, chunk, nchunks, tm, tn; };
+Plan plan(int M, int N, int Ktot, int BM, int BN) {
+  Plan p;
+  p.M = M; p.N = N; p.Ktot = Ktot;
+  p.ktiles = (Ktot + GBK - 1) / GBK;
+  p.nchunks = (p.ktiles + KCHUNK - 1) / KCHUNK;
+  p.chunk = (p.ktiles + p.nchunks - 1) / p.nchunks;
+  p.nchunks = (p.ktiles + p.chunk - 1) / p.chunk;
+  p.tm = (M + BM - 1) / BM; p.tn = (N + BN - 1) / BN;
+  return p;
+}
+
+// one bucket = one kernel instantiation; items and map entries are appended to the host staging image
+template <class CFG, class LA, class LB>
+struct Bucket {
+  std::vector<GroupItem<LA, LB>> items;
+  std::vector<WgEntry> map;
+  void add(const LA& la, const LB& lb, float* out, int ldc, const Plan& p) {
+    GroupItem<LA, LB> it;
+    it.la = la; it.lb = lb; it.out = out; it.ldc = ldc; it.M = p.M; it.N = p.N; it.ktiles = p.ktiles; it.chunk = p.chunk;
+    const uint32_t idx = (uint32_t)items.size();
+    items.push_back(it);
+    // all tiles of one k-chunk are neighbours in the grid: they read the same operand rows
+    for (int c = 0; c < p.nchunks; ++c)
+      for (int a = 0; a < p.tm; ++a)
+        for (int b = 0; b < p.tn; ++b) map.push_back(WgEntry{idx, (uint32_t)a, (uint32_t)b, (uint32_t)c});
+  }
+  size_t item_bytes() const { return (items.size() * sizeof(GroupItem<LA, LB>) + 255) / 256 * 256; }
+  size_t bytes() const { return item_bytes() + (map.size() * sizeof(WgEntry) + 255) / 256 * 256; }
+  void stage(char* host, size_t off) const {
+    if (items.empty()) return;
+    memcpy(host + off, items.data(), items.size() * sizeof(GroupItem<LA, LB>));
+    memcpy(host + off + item_bytes(), map.data(), map.size() * sizeof(WgEntry));
+  }
+  int launch(char* dev, size_t off, hipStream_t st) const {
+    if (items.empty()) return 0;
+    hipLaunchKernelGGL((igemm_group_kernel<CFG, LA, LB, 3>), dim3((unsigned)map.size()), dim3(256), 0, st,
+                       (const GroupItem<LA, LB>*)(dev + off), (const WgEntry*)(dev + off + item_bytes()));
+    return (int)hipGetLastError();
+  }
+};
+
+bool fits32(size_t elems, size_t esize) { return elems * esize < 0xF0000000ull; }
+
+}  // namespace
+
+extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n, void* ws_dev, void* ws_host, uint64_t ws_bytes, void* stream) {
+  if (!items || n <= 0) return n == 0 ? 0 : -1;
+  hipStream_t st = (hipStream_t)stream;
+  // members one by one: the exact-f32 mode (one k-ordered chain per output tracks the CPU reference), the deterministic-reduction mode
+  // (one contribution per address) and callers without a workspace
+  if (dtype != CLITE_BF16 || clite::deterministic() || !ws_dev || !ws_host) {
+    for (int i = 0; i < n; ++i) {
+      const clite_wgrad_item& w = items[i];
+      int rc;
+      if (w.kind == 0) {
+        rc = clite_conv_wgrad(w.a, w.b, &w.cv, w.out, stream);
+      } else {
+        clite_epilogue ep = {};
+        ep.out = w.out; ep.ldc = w.ldc; ep.out_f32 = 1; ep.atomic = 1; ep.alpha = 1.f;
+        rc = clite_gemm_tn(w.a, w.lda, w.b, w.ldb, w.M, w.N, w.K, dtype, &ep, stream);
+      }
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  Bucket<C128, XS128, XG128> conv_full;
+  Bucket<C64x128, XS64, XG128> conv_fewk;     // <= 64 output channels
+  Bucket<C128x64, XS128, XG64> conv_fewc;     // <= 64 (r, s, ci) columns
+  Bucket<C128, XS128, XS128> linear;
+  for (int i = 0; i < n; ++i) {
+    const clite_wgrad_item& w = items[i];
+    if (!w.a || !w.b || !w.out) return -1;
+    if (w.kind == 0) {
+      const clite_conv& c = w.cv;
+      if (c.dtype != CLITE_BF16 || c.C % 8 || c.K % 8 || (c.R * c.S > 1 && (c.C % 32 || c.K % 32))) return -1;
+      if (!fits32((size_t)c.N * c.H * c.W * c.C, 4) || !fits32((size_t)c.N * c.Ho * c.Wo * c.K, 4)) return -1;
+      const int P = c.N * c.Ho * c.Wo, Ncols = c.R * c.S * c.C;
+      const uint32_t yb = (uint32_t)((size_t)P * c.K * 2), xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * 2);
+      if (c.K <= 64) conv_fewk.add(XS64{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 64, 128));
+      else if (Ncols <= 64) conv_fewc.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG64{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 64));
+      else conv_full.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 128));
+    } else if (w.kind == 1) {
+      if (w.M <= 0 || w.N <= 0 || w.K <= 0 || w.M % 8 || w.N % 8 || w.lda % 8 || w.ldb % 8 || w.lda < w.M || w.ldb < w.N) return -1;
+      if (!fits32((size_t)w.K * w.lda, 4) || !fits32((size_t)w.K * w.ldb, 4)) return -1;
+      const uint32_t ab = (uint32_t)((((size_t)w.K - 1) * w.lda + w.M) * 2), bb = (uint32_t)((((size_t)w.K - 1) * w.ldb + w.N) * 2);
+      linear.add(XS128{w.a, ab, w.lda, w.M, w.K, 1}, XS128{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 128, 128));
+    } else {
+      return -1;
+    }
+  }
+  const size_t o0 = 0, o1 = o0 + conv_full.bytes(), o2 = o1 + conv_fewk.bytes(), o3 = o2 + conv_fewc.bytes(), need = o3 + linear.bytes();
+  if (need > ws_bytes) return -2;
+  char* host = (char*)ws_host;
+  char* dev = (char*)ws_dev;
+  // fill the host image, copy it once, then enqueue the (up to four) launches: they read `dev` after the copy, in stream order
+  conv_full.stage(host, o0); conv_fewk.stage(host, o1); conv_fewc.stage(host, o2); linear.stage(host, o3);
+  int rc = (int)hipMemcpyAsync(dev, host, need, hipMemcpyHostToDevice, st);
+  if (rc) return rc;
+  if ((rc = conv_full.launch(dev, o0, st))) return rc;
+  if ((rc = conv_fewk.launch(dev, o1, st))) return rc;
+  if ((rc = conv_fewc.launch(dev, o2, st))) return rc;
+  return linear.launch(dev, o3, st);
+}
+
+// Workspace bytes that certainly hold the descriptors of `n_items` members with `total_workgroups` workgroups in all (each member contributes
+// ceil(M/BM) * ceil(N/BN) * ceil(ceil(K/32)/128) of them): 512 B per member, 16 B per workgroup, alignment slack.
+extern "C" int clite_wgrad_group_workspace(int n_items, int64_t total_workgroups, uint64_t* bytes) {
+  if (n_items < 0 || total_workgroups < 0 || !bytes) return -1;
+  *bytes = (uint64_t)n_items * 512 + (uint64_t)total_workgroups * 16 + 4096;
+  return 0;
+}

@@ -46,6 +46,11 @@ class Bn(C.Structure):
     ]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32)]
+
+
 class OptimItem(C.Structure):
     _fields_ = [("start", C.c_uint64), ("count", C.c_uint32), ("lr", C.c_float), ("wd", C.c_float), ("reserved", C.c_uint32)]
 
@@ -63,6 +68,8 @@ _SIGNATURES = {
     "clite_conv_dgrad": [_V, _V, _V, _V, _V],
     "clite_conv_dgrad_s2class": [_V, _V, _V, _I, _I, _V, _V],
     "clite_conv_wgrad": [_V, _V, _V, _V, _V],
+    "clite_wgrad_group": [_I, _V, _I, _V, _V, _U64, _V],
+    "clite_wgrad_group_workspace": [_I, C.c_int64, _V],
     "clite_stem_fwd": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
     "clite_stem_wgrad": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
     "clite_stem_pack": [_V, _V, _I, _V],
@@ -255,6 +262,77 @@ def s2_classes_ok(cv):
 
 def conv_wgrad(dy, x, cv, dw):
     check(lib().clite_conv_wgrad(p(dy), p(x), C.byref(cv), p(dw), stream_ptr(dy)), "conv_wgrad")
+
+
+import collections
+_inflight_groups = collections.deque()
+
+
+class WgradGroup:
+    """Weight gradients collected during a backward pass and launched together (include/clite.h: clite_wgrad_group). The backward executors
+    call conv() / linear() where they would have launched clite_conv_wgrad / clite_gemm_tn, and call() for anything else that only feeds
+    the gradient arena (bias column sums, the stem's packed gradient); launch() enqueues the lot on the current stream. The object keeps
+    every operand referenced and owns the descriptor workspace (device + pinned host), so it must outlive a captured graph that contains
+    its launch."""
+
+    def __init__(self, dt, workspace=None):
+        """workspace: optional pre-allocated (device uint8 tensor, pinned host uint8 tensor) of equal size — required when launch() runs
+        inside a stream capture, where pinned memory cannot be allocated (alloc_workspace())."""
+        self.dt, self.items, self.extra, self.keep, self.wgs = dt, [], [], [], 0
+        self.ws_dev, self.ws_host = workspace if workspace is not None else (None, None)
+
+    @staticmethod
+    def alloc_workspace(device, nbytes=1 << 20):
+        """1 MiB holds ~60 000 workgroups' descriptors: an order of magnitude more than ResNet-101 + BERT-base need."""
+        return torch.empty(nbytes, dtype=torch.uint8, device=device), torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+
+    @staticmethod
+    def _wgs(M, N, K, bm=128, bn=128):
+        kt = (K + 31) // 32
+        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * ((kt + 127) // 128)
+
+    def conv(self, dy, x, cv, dw):
+        it = WgradItem()
+        it.kind, it.a, it.b, it.out, it.cv = 0, p(dy), p(x), p(dw), cv
+        self.items.append(it)
+        self.keep += [dy, x, dw]
+        ncols = cv.R * cv.S * cv.C
+        self.wgs += self._wgs(cv.K, ncols, cv.N * cv.Ho * cv.Wo, 64 if cv.K <= 64 else 128, 64 if ncols <= 64 else 128)
+
+    def linear(self, A, B, M, N, K, out, lda=None, ldb=None, ldc=None):
+        """out[M][N] += A[K][M]^T B[K][N] (f32 accumulate)."""
+        it = WgradItem()
+        it.kind, it.a, it.b, it.out = 1, p(A), p(B), p(out)
+        it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, K, lda or M, ldb or N, ldc or N
+        self.items.append(it)
+        self.keep += [A, B, out]
+        self.wgs += self._wgs(M, N, K)
+
+    def call(self, fn):
+        self.extra.append(fn)
+
+    def launch(self):
+        if self.items:
+            arr = (WgradItem * len(self.items))(*self.items)
+            first = self.keep[0]
+            if self.ws_dev is None and first.is_cuda:
+                nbytes = C.c_uint64(0)
+                check(lib().clite_wgrad_group_workspace(len(self.items), self.wgs, C.byref(nbytes)), "wgrad_group_workspace")
+                self.ws_dev = torch.empty(nbytes.value, dtype=torch.uint8, device=first.device)
+                self.ws_host = torch.empty(nbytes.value, dtype=torch.uint8).pin_memory()
+            nb = self.ws_dev.numel() if self.ws_dev is not None else 0
+            check(lib().clite_wgrad_group(self.dt, arr, len(self.items), p(self.ws_dev), self.ws_host.data_ptr() if self.ws_host is not None else None,
+                                          nb, stream_ptr(first)), "wgrad_group")
+            if first.is_cuda and not torch.cuda.is_current_stream_capturing():
+                # the descriptor copy and the launches are only enqueued: keep this object (its pinned staging, its operands) alive until the
+                # stream has passed them — the host allocator knows nothing about the library's own hipMemcpyAsync
+                ev = torch.cuda.Event()
+                ev.record()
+                while _inflight_groups and _inflight_groups[0][0].query():
+                    _inflight_groups.popleft()
+                _inflight_groups.append((ev, self))
+        for fn in self.extra:
+            fn()
 
 
 def stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, ep):

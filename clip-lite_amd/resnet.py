@@ -237,20 +237,25 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
     last, and across blocks whenever the block-input gradient comes out of one kernel (identity shortcut).
 
     Only dgrad -> BN backward -> dgrad ... is a dependency chain; every weight-gradient GEMM needs just dy and the saved input and feeds
-    nothing but the gradient arena. `defer` (a list) collects them as closures instead of launching them, so the caller can run them
-    elsewhere — the captured step (train_loop.TrainStep) replays the weight gradients of the late stages on the text encoder's stream once
-    BERT's backward has drained, beside the HBM-bound BatchNorm chain of the early stages. `stop_block` / `resume` cut the chain in two
+    nothing but the gradient arena. `defer` (a hip.WgradGroup) collects them instead of launching them, so the caller can run them together
+    and elsewhere — the captured step (train_loop.TrainStep) launches the weight gradients of the late stages as ONE grouped launch on the
+    text encoder's stream once BERT's backward has drained, beside the HBM-bound BatchNorm chain of the early stages. `stop_block` / `resume` cut the chain in two
     segments for that: the first call stops after block `stop_block` and parks (dout, pre) in ctx; `resume=True` continues from there."""
     N = ctx["N"]
     dt = rt.dt
     blocks = list(net.blocks())
     recs = ctx["recs"]
+    own_group = None
+    if defer is None and rt.group_wgrad and not rt.overlap_wgrad and not rt._capturing:      # (a capture cannot allocate the pinned staging)
+        # uncaptured (eager / autograd) backward: the same grouped launch, issued at the end of this call on the same stream
+        defer = own_group = hip.WgradGroup(rt.dt)
 
-    def wgrad(fn, *tensors):
+    def wgrad(dy_, u_):
+        dw = rt.arena.g(u_.conv.weight)
         if defer is None:
-            rt.aux_launch(fn, *tensors)
+            rt.aux_launch(lambda: hip.conv_wgrad(dy_, u_.x, u_.cv, dw), dy_)
         else:
-            defer.append(fn)          # the closure keeps dy / x referenced until it has run
+            defer.conv(dy_, u_.x, u_.cv, dw)          # hip.WgradGroup: keeps dy / x referenced until it has been launched
 
     if resume:
         dout, pre, first = ctx.pop("bwd_state")
@@ -278,7 +283,7 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         for i in range(len(units) - 1, -1, -1):
             u = units[i]
             if u.conv.weight.requires_grad:
-                wgrad(lambda dy=dy, u=u: hip.conv_wgrad(dy, u.x, u.cv, rt.arena.g(u.conv.weight)), dy)
+                wgrad(dy, u)
             Cin = u.conv.in_channels
             dx = _alloc(rt, u.x.shape[0], Cin)
             if i > 0 and not rt.fuse_bn_backward:
@@ -306,13 +311,14 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                     hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None))
                     if ud is not None:
                         if ud.conv.weight.requires_grad:
-                            wgrad(lambda dyd=dyd, ud=ud: hip.conv_wgrad(dyd, ud.x, ud.cv, rt.arena.g(ud.conv.weight)), dyd)
+                            wgrad(dyd, ud)
                         # shortcut branch accumulated in place (dx += dgrad); a strided 1x1 shortcut takes the scatter-add path of clite_conv_dgrad
                         hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx, Cin, residual=dx))
                 dout = dx
         if defer is None:
             rt.grads_ready(blocks[bi])
     if stop_block > 0:
+        assert own_group is None
         ctx["bwd_state"] = (dout, pre, stop_block - 1)
         return
     xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq = ctx["stem"]
@@ -329,8 +335,11 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         if defer is None:
             stem_wgrad()
         else:
-            defer.append(stem_wgrad)
-    if defer is None:
+            defer.call(stem_wgrad)
+    if own_group is not None:
+        own_group.launch()
+        rt.grads_ready(net)           # every gradient of the encoder became final with that launch
+    elif defer is None:
         rt.join_aux()
         rt.grads_ready(net.conv1)
         rt.grads_ready(net.bn1)

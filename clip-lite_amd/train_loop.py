@@ -171,24 +171,27 @@ class TrainStep:
         inet = m.image_encoder.img_encoder
         split = len(inet.layer1) + len(inet.layer2)
 
+        from . import hip
+        ws = {k: hip.WgradGroup.alloc_workspace(rt.device) for k in ("a", "b", "t")}      # pinned staging cannot be allocated inside a capture
+
         def image_bwd_a():
-            keep["wg_a"] = []
+            keep["wg_a"] = hip.WgradGroup(rt.dt, ws["a"])
             resnet_backward(rt, inet, keep["ctx_i"], keep["dimg"].contiguous(), defer=keep["wg_a"], stop_block=split)
 
         def image_bwd_b():
-            keep["wg_b"] = []
+            keep["wg_b"] = hip.WgradGroup(rt.dt, ws["b"])
             resnet_backward(rt, inet, keep["ctx_i"], None, defer=keep["wg_b"], resume=True)
 
         def wgrad_a():
-            for fn in keep["wg_a"]:
-                fn()
+            keep["wg_a"].launch()
 
         def wgrad_b():
-            for fn in keep["wg_b"]:
-                fn()
+            keep["wg_b"].launch()
 
         def text_bwd():
-            bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous())
+            keep["wg_t"] = hip.WgradGroup(rt.dt, ws["t"])          # BERT's 49 linear weight gradients: one grouped launch at the end of its backward
+            bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous(), defer=keep["wg_t"])
+            keep["wg_t"].launch()
 
         def update():
             self._capture_update()

@@ -120,6 +120,26 @@ int clite_conv_dgrad_s2class(const void* dy, const void* wsub, const clite_conv*
 /* dw[K][R][S][C] (f32) += dy^T * im2col(x): autograd of the same call; float-atomic split-K. */
 int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream);
 
+/* Grouped weight gradients: every member is one independent dW (f32) += A^T B of the backward pass, all enqueued as ONE launch per tile
+ * family so that thousands of workgroups exist without splitting the short-K members (a lone weight gradient has a few dozen output tiles
+ * and needs split-K + float atomics to fill 256 CUs: 328 vs 666 TF/s on the BERT FFN gradient; clip-lite_amd/csrc/gemm_group.hip).
+ *   kind 0: conv weight gradient — a = dy [N][Ho][Wo][K], b = x [N][H][W][C], cv, out = dw [K][R][S][C]   (as clite_conv_wgrad)
+ *   kind 1: linear weight gradient — out[M][N] (row stride ldc) += a[K][M]^T b[K][N]                     (as clite_gemm_tn with ep.atomic)
+ * ws_dev / ws_host: device workspace and PINNED host staging of ws_bytes each (clite_wgrad_group_workspace gives a sufficient size); the
+ * library fills ws_host, copies it with one hipMemcpyAsync on `stream` and launches — under stream capture that is a memcpy node, so ws_host
+ * must stay alive and unchanged for as long as the captured graph is replayed. With dtype = CLITE_F32, in deterministic-reduction mode, or
+ * with ws_dev / ws_host NULL the members are launched one by one. Returns 0, -1 (bad member), -2 (workspace too small) or a HIP status. */
+typedef struct clite_wgrad_item {
+  int32_t kind;
+  const void* a;
+  const void* b;
+  float* out;
+  clite_conv cv;                 /* kind 0 */
+  int32_t M, N, K, lda, ldb, ldc;  /* kind 1 */
+} clite_wgrad_item;
+int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n, void* ws_dev, void* ws_host, uint64_t ws_bytes, void* stream);
+int clite_wgrad_group_workspace(int n_items, int64_t total_workgroups, uint64_t* bytes);
+
 /* ResNet stem conv1 = nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (torchvision, reference encoder.py:36-38) on the
  * pre-padded NHWC4 image from clite_image_to_nhwc4 (Hp >= 2*(Ho-1)+7, Wp >= 2*(Wo-1)+8, Wp even). wv is the weight packed
  * as [64][7][8][4] (clite_stem_pack from f32 [64][7][7][3]); clite_stem_unpack_grad folds the packed gradient back (+=). */

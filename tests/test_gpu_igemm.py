@@ -234,3 +234,40 @@ def test_splitk_workspace_form_matches_fused_path(kind, M, N, K):
         assert _rel(out, ref) < 6e-3 and _rel(pre, z) < 6e-3
         assert _rel(cs[0], out.sum(0)) < 1e-3 and _rel(cs[1], (out ** 2).sum(0)) < 1e-3
     assert _rel(outs[1][0], outs[0][0]) < 8e-3
+
+
+def test_grouped_weight_gradients_match_members(tile_policy):
+    """clite_wgrad_group on the GPU: the weight gradients of a ResNet-50 stage slice (all three conv tile families, one member with
+    > 128 K tiles per workgroup chunk) and two BERT linear gradients as ONE grouped launch set accumulate the same values (+= onto a
+    non-zero arena) as torch fp32 on the same bf16 inputs; and the member-by-member path of the same entry point (deterministic mode)
+    agrees. Bound 2e-3 of max (fp32 accumulation, summation order only)."""
+    if tile_policy != 0:
+        pytest.skip("independent of the tile policy")
+    hip = _hip()
+    g = torch.Generator(device="cuda").manual_seed(17)
+    cases = [(8, 56, 56, 64, 64, 3, 1, 1), (8, 56, 56, 64, 256, 1, 1, 0), (8, 28, 28, 512, 128, 1, 1, 0), (16, 14, 14, 256, 256, 3, 1, 1), (32, 7, 7, 2048, 512, 1, 1, 0)]
+    for det in (False, True):
+        hip.set_deterministic(det)
+        try:
+            grp = hip.WgradGroup(BF16)
+            checks = []
+            for (N, H, W, Cc, K, R, st, pad) in cases:
+                cv = hip.conv_desc(BF16, N, H, W, Cc, K, R, R, st, pad)
+                x, dy = _t((N, H, W, Cc), g, BF16), _t((N, cv.Ho, cv.Wo, K), g, BF16)
+                dw = torch.ones(K, R, R, Cc, device="cuda")
+                grp.conv(dy, x, cv, dw)
+                w32 = torch.zeros(K, Cc, R, R, device="cuda", requires_grad=True)
+                with torch.backends.cudnn.flags(enabled=False):
+                    F.conv2d(x.float().permute(0, 3, 1, 2), w32, stride=st, padding=pad).backward(dy.float().permute(0, 3, 1, 2))
+                checks.append((dw, 1 + w32.grad.permute(0, 2, 3, 1)))
+            for (M, N, K) in [(3072, 768, 3840), (768, 768, 3840)]:
+                A, B = _t((K, M), g, BF16), _t((K, N), g, BF16)
+                out = torch.ones(M, N, device="cuda")
+                grp.linear(A, B, M, N, K, out)
+                checks.append((out, 1 + A.float().t() @ B.float()))
+            grp.launch()
+            torch.cuda.synchronize()
+            for got, ref in checks:
+                assert _rel(got, ref) < 2e-3
+        finally:
+            hip.set_deterministic(False)

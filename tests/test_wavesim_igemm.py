@@ -271,3 +271,43 @@ def test_stem_conv7x7(dtype):
     dw = np.ones((64, 7, 7, 3), np.float32)
     assert lib().clite_stem_unpack_grad(ptr(dwv), ptr(dw), None) == 0
     _close(dw, 1 + conv_wgrad_ref(dy, imgr.transpose(0, 2, 3, 1), w.shape, 2, 3))
+
+
+def test_grouped_weight_gradients():
+    """clite_wgrad_group: conv weight gradients of all three tile families (<= 64 output channels, <= 64 (r, s, ci) columns, general) and a
+    linear weight gradient with a strided operand, as ONE grouped launch set, accumulate (+=) the same values as the per-member entry points
+    compute — including a member whose K range is cut into several k-chunks (> 128 K tiles)."""
+    from simlib import Conv
+
+    class Item(C.Structure):
+        _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
+                    ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32)]
+
+    rng = np.random.default_rng(5)
+    L = lib()
+    L.clite_wgrad_group.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.clite_wgrad_group_workspace.argtypes = [C.c_int, C.c_int64, C.c_void_p]
+    items, refs, outs, hold = [], [], [], []
+    for (N, H, W, Cc, K, R, st, pad) in [(2, 8, 8, 32, 64, 3, 1, 1), (3, 6, 6, 64, 136, 1, 1, 0), (2, 9, 7, 128, 160, 1, 2, 0), (9, 24, 24, 32, 64, 1, 1, 0)]:
+        Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+        cv = Conv(BF16, N, H, W, Cc, K, R, R, st, pad, Ho, Wo)
+        x, xb = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), BF16)
+        dy, dyb = _prep(rng.standard_normal((N, Ho, Wo, K), dtype=np.float32), BF16)
+        dw = np.ones((K, R, R, Cc), np.float32)
+        it = Item(); it.kind, it.a, it.b, it.out, it.cv = 0, ptr(dyb).value, ptr(xb).value, ptr(dw).value, cv
+        items.append(it); outs.append(dw); refs.append(1 + conv_wgrad_ref(dy, x, dw.shape, st, pad)); hold += [xb, dyb]
+    Kt, M, N = 300, 72, 136                                   # linear member, B rows strided (ldb > N)
+    A, Ab = _prep(rng.standard_normal((Kt, M), dtype=np.float32), BF16)
+    B, Bb = _prep(rng.standard_normal((Kt, 2 * N), dtype=np.float32), BF16)
+    out = np.ones((M, N), np.float32)
+    it = Item(); it.kind, it.a, it.b, it.out = 1, ptr(Ab).value, ptr(Bb).value, ptr(out).value
+    it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, Kt, M, 2 * N, N
+    items.append(it); outs.append(out); refs.append(1 + A.T @ B[:, :N]); hold += [Ab, Bb]
+    nb = C.c_uint64(0)
+    assert L.clite_wgrad_group_workspace(len(items), 4096, C.byref(nb)) == 0
+    ws_dev, ws_host = np.zeros(nb.value, np.uint8), np.zeros(nb.value, np.uint8)
+    arr = (Item * len(items))(*items)
+    assert L.clite_wgrad_group(BF16, arr, len(items), ptr(ws_dev), ptr(ws_host), nb.value, None) == 0
+    for got, ref in zip(outs, refs):
+        _close(got, ref)
+    assert L.clite_wgrad_group(BF16, arr, len(items), ptr(ws_dev), ptr(ws_host), 64, None) == -2          # workspace too small: refused, nothing launched

@@ -49,6 +49,11 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return hipSuccess;
 }
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+inline hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t) {      // host memory both sides here
+  memcpy(dst, src, n);
+  return hipSuccess;
+}
 
 namespace wavesim {
 struct WaveCtx {

@@ -46,7 +46,12 @@ def main():
             e0.record()
             rc = fn(*a)
             e1.record()
-            recs.append((name, bench.describe_launch(name, a, 4 if args.f32 else 2), e0, e1))
+            if name == "clite_wgrad_group":      # one launch set, many members: reported as one row (sum of the members' work)
+                ms = bench.describe_group(a, 4 if args.f32 else 2)
+                d = (f"group of {len(ms)} wgrads", sum(m[1] for m in ms), 1, 1, sum(m[4] for m in ms))
+                recs.append((name, d + (sum(2.0 * m[1] * m[2] * m[3] for m in ms),), e0, e1))
+            else:
+                recs.append((name, bench.describe_launch(name, a, 4 if args.f32 else 2) + (None,), e0, e1))
             return rc
         return timed
     wrapped = {n: wrap(n) for n in names}
@@ -65,10 +70,10 @@ def main():
         key = (name, d)
         agg.setdefault(key, []).append(e0.elapsed_time(e1))
     rows = []
-    for (name, (lab, M, N, K, nbytes)), ts in agg.items():
+    for (name, (lab, M, N, K, nbytes, flops)), ts in agg.items():
         n = len(ts) // REP
         us = sum(ts) / len(ts) * 1e3
-        rows.append((name[6:], lab, M, N, K, n, us, 2.0 * M * N * K / us / 1e6, nbytes / us / 1e3))
+        rows.append((name[6:], lab, M, N, K, n, us, (flops if flops is not None else 2.0 * M * N * K) / us / 1e6, nbytes / us / 1e3))
     tot = sum(r[5] * r[6] for r in rows)
     print(f"{'op':12s} {'layer':28s} {'M':>8s} {'N':>6s} {'K':>8s} {'n':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s} {'%':>5s}")
     for r in sorted(rows, key=lambda r: -r[5] * r[6]):
