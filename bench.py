@@ -19,6 +19,7 @@ import torch  # noqa: E402
 import torch.distributed as tdist  # noqa: E402
 
 FLOP_PER_PAIR = 40.19e9            # 6.699 GMAC fwd x 2 x 3 (fwd + dgrad + wgrad), ResNet-50 + BERT-base L=30 + heads
+FLOP_PER_PAIR_BY_VISUAL = {"resnet50": 40.19e9, "resnet101": 62.47e9}      # SURVEY.md §8d (C2 / C5), with BERT-base 12 layers
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
@@ -220,6 +221,8 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--f32", action="store_true", help="exact-f32 parity kernels instead of bf16")
     ap.add_argument("--loss", default="jsd", choices=["jsd", "infonce"], help="cross-modal term: the reference's JSD estimator or the InfoNCE all-pairs variant (BASELINE config 4)")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: forward convs and BERT linears on OCP e4m3 operands (per-tensor current scaling, "
+                    "v_mfma_f32_32x32x16_fp8_fp8, f32 accumulate); backward stays bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL over xGMI); gloo is for single-GPU logic tests")
@@ -256,6 +259,7 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):      # the encoders print a construction banner like the reference's; keep stdout = the JSON line
         model, opt, sched = build(args, device)
     cdist.broadcast_parameters(model)
+    model.runtime.fp8 = bool(args.fp8)
     exchange = None
     if dist_on:
         exchange = cdist.GradientExchange(model.runtime.arena)
@@ -312,13 +316,14 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
-        gemm_tflops = FLOP_PER_PAIR * args.batch / (gemm_ms * 1e-3) / 1e12 if args.visual == "resnet50" and args.layers == 12 else None
+        flop_pair = FLOP_PER_PAIR_BY_VISUAL.get(args.visual) if args.layers == 12 else None
+        gemm_tflops = flop_pair * args.batch / (gemm_ms * 1e-3) / 1e12 if flop_pair else None
         traffic, traffic_note = pmc_traffic(args)
         res = {
             "metric": "image-caption pairs/sec (global batch) — ResNet-50+BERT bs1024, 1/2/4/8 MI355X",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.f32 else "bf16", "data": "synthetic" + (", fed from pinned host memory every step" if args.host_input else ""),
+            "dtype": "f32" if args.f32 else ("fp8 (e4m3 forward operands) + bf16" if args.fp8 else "bf16"), "data": "synthetic" + (", fed from pinned host memory every step" if args.host_input else ""),
             "config": {"workload": f"{args.visual} + BERT-base({args.layers}L) + JSD-MI heads/priors, per-GPU batch {args.batch}, 224x224 images, "
                                    f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)" + ("" if args.loss == "jsd" else ", InfoNCE all-pairs loss"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},
@@ -329,7 +334,7 @@ def main():
                          "launches_per_step": n_launch, "kernel_ms_per_step": gemm_ms,
                          "algorithmic_bytes": alg_bytes, "launched_flops": launch_flops, "traffic_note": traffic_note,
                          "kernel_source_hash": kernel_source_hash(),
-                         "whole_step_frac": FLOP_PER_PAIR * args.batch / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if gemm_tflops else None},
+                         "whole_step_frac": flop_pair * args.batch / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS if gemm_tflops else None},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args)

@@ -171,28 +171,37 @@ def bert_forward(rt, net, input_ids, attention_mask, step):
     d0 = drop(p_h)
     hip.layernorm_fwd(dt, s0, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, h, st0, M, Hd, d0)
     ctx = {"B": B, "L": L, "ids": ids, "mask": mask, "s0": s0, "st0": st0, "d0": d0, "layers": []}
+    fp8 = rt.fp8 and rt.lowp
+
+    def linear(x, w, Mr, N, K, ep):
+        """x [Mr][K] @ w[N][K]^T through the fused epilogue: bf16 MFMA, or OCP e4m3 operands with per-tensor current scaling (clite_gemm_nt_fp8)."""
+        if fp8:
+            hip.gemm_nt_fp8(hip.Fp8Tensor(x, dt), hip.Fp8Tensor(w, dt), Mr, N, K, ep)
+        else:
+            hip.gemm_nt(dt, x, w, Mr, N, K, ep)
+
     for layer in net.encoder.layer:
         sa, so = layer.attention.self, layer.attention.output
         wqkv = A.span([sa.query.weight, sa.key.weight, sa.value.weight])
         bqkv = A.span([sa.query.bias, sa.key.bias, sa.value.bias], lowp=False)
         qkv = _alloc(rt, M, 3 * Hd)
-        hip.gemm_nt(dt, h, wqkv, M, 3 * Hd, Hd, hip.epilogue(qkv, 3 * Hd, bias=bqkv))
+        linear(h, wqkv, M, 3 * Hd, Hd, hip.epilogue(qkv, 3 * Hd, bias=bqkv))
         ctxt = _alloc(rt, M, Hd)
         da = drop(p_a)
         hip.attention_fwd(dt, qkv, mask, ctxt, B, L, heads, da)
         s1 = _alloc(rt, M, Hd)
         d1 = drop(p_h)
-        hip.gemm_nt(dt, ctxt, A.w(so.dense.weight), M, Hd, Hd, hip.epilogue(s1, Hd, bias=so.dense.bias, drop=d1, residual=h))
+        linear(ctxt, A.w(so.dense.weight), M, Hd, Hd, hip.epilogue(s1, Hd, bias=so.dense.bias, drop=d1, residual=h))
         h1 = _alloc(rt, M, Hd)
         st1 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
         hip.layernorm_fwd(dt, s1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, h1, st1, M, Hd)
         f = _alloc(rt, M, inner)      # FFN pre-activation (kept for GELU')
         g = _alloc(rt, M, inner)
-        hip.gemm_nt(dt, h1, A.w(layer.intermediate.dense.weight), M, inner, Hd,
-                    hip.epilogue(g, inner, bias=layer.intermediate.dense.bias, act=hip.ACT_GELU, preact=f))
+        linear(h1, A.w(layer.intermediate.dense.weight), M, inner, Hd,
+               hip.epilogue(g, inner, bias=layer.intermediate.dense.bias, act=hip.ACT_GELU, preact=f))
         s2 = _alloc(rt, M, Hd)
         d2 = drop(p_h)
-        hip.gemm_nt(dt, g, A.w(layer.output.dense.weight), M, Hd, inner, hip.epilogue(s2, Hd, bias=layer.output.dense.bias, drop=d2, residual=h1))
+        linear(g, A.w(layer.output.dense.weight), M, Hd, inner, hip.epilogue(s2, Hd, bias=layer.output.dense.bias, drop=d2, residual=h1))
         h2 = _alloc(rt, M, Hd)
         st2 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
         hip.layernorm_fwd(dt, s2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, h2, st2, M, Hd)

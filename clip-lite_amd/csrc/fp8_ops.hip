@@ -1,0 +1,252 @@
+// OCP e4m3 forward path (BASELINE.json configs[4]: "fp8 weights/activations on CDNA4 fp8 MFMA"; the reference has no fp8 semantics —
+// the policy is this build's, stated in DESIGN.md): per-tensor current scaling, quantised operands for the forward conv / linear GEMMs,
+// f32 accumulation on v_mfma_f32_32x32x16_fp8_fp8, bf16 outputs; backward stays bf16 on the saved bf16 activations.
+//
+//   clite_fp8_quantize : amax = max|x| (integer atomic max on the f32 bit pattern: order-independent), scale = 448 / amax,
+//                        q = e4m3(clamp(x * scale, +-448)); scales = {scale, 1 / scale}
+//   clite_gemm_nt_fp8 / clite_conv_fwd_fp8 : igemm_dma_kernel's pipeline over 64-byte K slabs = 64 fp8 elements (K tile 64), fragments by
+//                        ds_read_b64 (8 fp8 per lane and k-step), epilogue of igemm.h applied to acc * a_scales[1] * b_scales[1].
+#include "igemm_dma.h"
+#include "clite.h"
+
+using namespace clite;
+
+namespace {
+
+typedef uint8_t fp8;
+constexpr float FP8_MAX = 448.f;
+
+template <typename T>
+__global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, size_t n8, float* amax) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    load8(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+  }
+  __shared__ float red[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // non-negative floats order like their bit patterns: an integer max needs no float atomics and is order-independent. One atomic per
+  // workgroup: same-address atomics retire at ~90 per microsecond chip-wide, so thousands of them per call would cost more than the pass
+  if (threadIdx.x == 0) atomic_max_u32((uint32_t*)amax, f32_bits(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_fp8_kernel(const T* __restrict__ x, size_t n8, const float* __restrict__ amax, fp8* __restrict__ out, float* scales) {
+  const float a = amax[0];
+  const float scale = a > 0.f ? FP8_MAX / a : 1.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scales[0] = scale; scales[1] = a > 0.f ? a / FP8_MAX : 1.f; }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    load8(x + i * 8, v);
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p = fminf(fmaxf(v[2 * e] * scale, -FP8_MAX), FP8_MAX), q = fminf(fmaxf(v[2 * e + 1] * scale, -FP8_MAX), FP8_MAX);
+      w[e] = cvt2_fp8(p, q);
+    }
+    *(u32x2*)(out + i * 8) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+  }
+}
+
+// ---- GEMM on fp8 operands. KC x KC only (both operands k-contiguous: activations x weights, the forward direction).
+// LDS image: igemm_dma.h's KC image [rows][64 B] with 16-byte chunk c of row r in slot c ^ ((r>>2)&3); a k-step is 16 fp8 = one chunk, and
+// lane (r, h) reads bytes 8h..8h+7 of it.
+template <int ROWS> using FKC = DmaKC<fp8, ROWS, 64, false>;
+DEV int fp8_frag_off(int x0, int ks, int lane) {
+  const int r = x0 + (lane & 31);
+  return r * 64 + ((ks ^ ((r >> 2) & 3)) << 4) + 8 * (lane >> 5);
+}
+
+template <class CFG, int ROWS_A, int ROWS_B, int EPI>
+__global__ __launch_bounds__(256) void igemm_fp8_kernel(FKC<ROWS_A> la, FKC<ROWS_B> lb, Epilogue ep, RowMap rm, const float* sa_scales, const float* sb_scales,
+                                                        int M, int N, int ktiles) {
+  typedef FKC<ROWS_A> LA;
+  typedef FKC<ROWS_B> LB;
+  constexpr int BM = CFG::BM, BN = CFG::BN;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int NSTAGE = 3, KSTEPS = 4;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int SMEM = (NSTAGE * STAGE > CFG::EPI_BYTES) ? NSTAGE * STAGE : CFG::EPI_BYTES;
+  constexpr int LOADS_PER_TILE = LA::NI + LB::NI;
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int tm = wg / tiles_n, tn = wg - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  ep.alpha *= sa_scales[1] * sb_scales[1];                 // de-quantisation: 1/scale of both operands
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, wave, lane, 0);
+  lb.init(sb, n0, wave, lane, 0);
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int aoff[RM][KSTEPS], boff[RN][KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i) aoff[i][ks] = fp8_frag_off(wm0 + i * 32, ks, lane);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) boff[j][ks] = fp8_frag_off(wn0 + j * 32, ks, lane);
+  }
+#pragma unroll
+  for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+    if (pz < ktiles) {
+      la.issue(sa, smem + pz * STAGE, wave);
+      lb.issue(sb, smem + pz * STAGE + LA::BYTES, wave);
+    }
+  }
+  int buf = 0;
+  for (int t = 0; t < ktiles; ++t) {
+    if (ktiles - 1 - t >= 1) wait_vmcnt<LOADS_PER_TILE>();
+    else wait_vmcnt<0>();
+    barrier_raw();
+    const char* abuf = smem + buf * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+    uint64_t af0[RM], bf0[RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) af0[i] = *(const uint64_t*)(abuf + aoff[i][0]);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) bf0[j] = *(const uint64_t*)(bbuf + boff[j][0]);
+    if (t + NSTAGE - 1 < ktiles) {
+      int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+      la.issue(sa, smem + nb * STAGE, wave);
+      lb.issue(sb, smem + nb * STAGE + LA::BYTES, wave);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      uint64_t af[RM], bfr[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : *(const uint64_t*)(abuf + aoff[i][ks]);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : *(const uint64_t*)(bbuf + boff[j][ks]);
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_fp8(af[i], bfr[j], acc[i][j]);
+    }
+    if (++buf == NSTAGE) buf = 0;
+  }
+  barrier_raw();
+  if constexpr (EPI == 2) igemm_epilogue_plain<bf16, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  else igemm_epilogue<bf16, CFG, false>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+}
+
+FastDiv fastdiv_make(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.mul = 0; f.shift = 0; f.d = 1; return f; }
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = l;
+  f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  return f;
+}
+ConvGeom geom_dense(int rows, int K, int ld) {
+  ConvGeom g;
+  g.H = 1; g.W = 1; g.C = K;
+  g.sN = ld; g.sH = 0; g.sW = 0;
+  g.RH = 1; g.RW = 1; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.padw = 0;
+  g.rows = rows;
+  g.div_hw = fastdiv_make(1);
+  g.div_w = fastdiv_make(1);
+  return g;
+}
+ConvGeom geom_fwd(const clite_conv& c) {
+  ConvGeom g;
+  g.H = c.H; g.W = c.W; g.C = c.C;
+  g.sN = c.H * c.W * c.C; g.sH = c.W * c.C; g.sW = c.C;
+  g.RH = c.Ho; g.RW = c.Wo; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
+  g.rows = c.N * c.Ho * c.Wo;
+  g.div_hw = fastdiv_make(c.Ho * c.Wo);
+  g.div_w = fastdiv_make(c.Wo);
+  return g;
+}
+
+typedef TileCfg<128, 128, 64, 64, 64> F128;       // BK = 64 fp8 elements = 64 bytes per row
+typedef TileCfg<256, 64, 64, 64, 64> F256x64;
+
+bool plain(const clite_epilogue& ep) {
+  return !ep.out_f32 && !ep.preact && ep.act == CLITE_ACT_NONE && !ep.dact_aux && ep.drop_p <= 0.f && !ep.residual;
+}
+int check_ep8(const clite_epilogue* ep, int N) {
+  if (!ep || !ep->out || ep->atomic || ep->bn_y || ep->mask_after_residual || ep->splitk_ws) return -1;
+  if (N % 8 || ep->ldc % 8) return -1;
+  return 0;
+}
+
+int launch8(const void* A, uint32_t ab, const ConvGeom& ga, const void* B, uint32_t bb, const ConvGeom& gb, const clite_epilogue& ep, const float* sa,
+            const float* sb, int M, int N, int Ktot, hipStream_t st) {
+  const int ktiles = (Ktot + 63) / 64;
+  RowMap rm{};
+  if (N <= 64) {
+    const int tiles = ((M + 255) / 256) * ((N + 63) / 64);
+    FKC<256> la{A, ab, ga};
+    FKC<64> lb{B, bb, gb};
+    if (plain(ep)) hipLaunchKernelGGL((igemm_fp8_kernel<F256x64, 256, 64, 2>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
+    else hipLaunchKernelGGL((igemm_fp8_kernel<F256x64, 256, 64, 0>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
+  } else {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    FKC<128> la{A, ab, ga};
+    FKC<128> lb{B, bb, gb};
+    if (plain(ep)) hipLaunchKernelGGL((igemm_fp8_kernel<F128, 128, 128, 2>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
+    else hipLaunchKernelGGL((igemm_fp8_kernel<F128, 128, 128, 0>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int clite_fp8_quantize(int dtype, const void* x, uint64_t n, float* amax, float* scales, void* out_fp8, void* stream) {
+  if (!x || !amax || !scales || !out_fp8 || n == 0 || n % 8) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n8 = n / 8;
+  size_t g = (n8 + 255) / 256;
+  const int grid = (int)(g < 1024 ? g : 1024);
+  if (dtype == CLITE_BF16) {
+    hipLaunchKernelGGL(amax_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, n8, amax);
+    hipLaunchKernelGGL(to_fp8_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)x, n8, (const float*)amax, (fp8*)out_fp8, scales);
+  } else if (dtype == CLITE_F32) {
+    hipLaunchKernelGGL(amax_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, n8, amax);
+    hipLaunchKernelGGL(to_fp8_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, n8, (const float*)amax, (fp8*)out_fp8, scales);
+  } else {
+    return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* a_scales, const float* b_scales,
+                                 const clite_epilogue* ep, void* stream) {
+  if (!A || !B || !a_scales || !b_scales || M <= 0 || N <= 0 || K <= 0 || K % 16 || lda % 16 || ldb % 16 || lda < K || ldb < K || check_ep8(ep, N)) return -1;
+  if ((size_t)M * lda >= 0xF0000000ull || (size_t)N * ldb >= 0xF0000000ull) return -1;
+  const uint32_t ab = (uint32_t)((size_t)(M - 1) * lda + K), bb = (uint32_t)((size_t)(N - 1) * ldb + K);
+  return launch8(A, ab, geom_dense(M, K, lda), B, bb, geom_dense(N, K, ldb), *ep, a_scales, b_scales, M, N, K, (hipStream_t)stream);
+}
+
+extern "C" int clite_conv_fwd_fp8(const void* x8, const void* w8, const clite_conv* cv, const float* x_scales, const float* w_scales,
+                                  const clite_epilogue* ep, void* stream) {
+  if (!x8 || !w8 || !cv || !x_scales || !w_scales || check_ep8(ep, cv ? cv->K : 0)) return -1;
+  const clite_conv& c = *cv;
+  if (c.C % 16 || c.K % 8 || (c.R * c.S > 1 && c.C % 64)) return -1;            // a 64-element K slab must stay inside one (r, s)
+  if (c.Ho != (c.H + 2 * c.pad - c.R) / c.stride + 1 || c.Wo != (c.W + 2 * c.pad - c.S) / c.stride + 1) return -1;
+  if ((size_t)c.N * c.H * c.W * c.C >= 0xF0000000ull || (size_t)c.N * c.Ho * c.Wo * c.K * 2 >= 0xF0000000ull) return -1;
+  const int M = c.N * c.Ho * c.Wo, Ktot = c.R * c.S * c.C;
+  const uint32_t xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C), wb = (uint32_t)((size_t)c.K * Ktot);
+  return launch8(x8, xb, geom_fwd(c), w8, wb, geom_dense(c.K, Ktot, Ktot), *ep, x_scales, w_scales, M, c.K, Ktot, (hipStream_t)stream);
+}

@@ -15,6 +15,7 @@
 #include "igemm_dma.h"
 #include "det.h"
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 using namespace clite;
@@ -22,7 +23,7 @@ using namespace clite;
 namespace {
 
 constexpr int GBK = 32;                 // K tile (bf16)
-constexpr int KCHUNK = 128;             // K tiles per workgroup at most
+constexpr int KCHUNK = 256;             // K tiles per workgroup at most (8192 pixels / tokens)
 
 template <class LA, class LB>
 struct GroupItem {
@@ -131,6 +132,18 @@ __global__ __launch_bounds__(256) void igemm_group_kernel(const GroupItem<LA, LB
     }
 }
 
+struct Plan { int M, N, Ktot, ktiles, chunk, nchunks, tm, tn; };
+Plan plan(int M, int N, int Ktot, int BM, int BN) {
+  Plan p;
+  p.M = M; p.N = N; p.Ktot = Ktot;
+  p.ktiles = (Ktot + GBK - 1) / GBK;
+  p.nchunks = (p.ktiles + KCHUNK - 1) / KCHUNK;
+  p.chunk = (p.ktiles + p.nchunks - 1) / p.nchunks;
+  p.nchunks = (p.ktiles + p.chunk - 1) / p.chunk;
+  p.tm = (M + BM - 1) / BM; p.tn = (N + BN - 1) / BN;
+  return p;
+}
+
 FastDiv fastdiv_make(uint32_t d) {
   FastDiv f;
   f.d = d;
@@ -160,37 +173,43 @@ typedef DmaXCStrided<bf16, 64, GBK> XS64;
 typedef DmaXCGather<bf16, 128, GBK> XG128;
 typedef DmaXCGather<bf16, 64, GBK> XG64;
 
-struct Plan { int M, N, Ktot, ktiles, chunk, nchunks, tm, tn; };
-Plan plan(int M, int N, int Ktot, int BM, int BN) {
-  Plan p;
-  p.M = M; p.N = N; p.Ktot = Ktot;
-  p.ktiles = (Ktot + GBK - 1) / GBK;
-  p.nchunks = (p.ktiles + KCHUNK - 1) / KCHUNK;
-  p.chunk = (p.ktiles + p.nchunks - 1) / p.nchunks;
-  p.nchunks = (p.ktiles + p.chunk - 1) / p.chunk;
-  p.tm = (M + BM - 1) / BM; p.tn = (N + BN - 1) / BN;
-  return p;
-}
-
 // one bucket = one kernel instantiation; items and map entries are appended to the host staging image
 template <class CFG, class LA, class LB>
 struct Bucket {
   std::vector<GroupItem<LA, LB>> items;
+  std::vector<Plan> plans;
   std::vector<WgEntry> map;
   void add(const LA& la, const LB& lb, float* out, int ldc, const Plan& p) {
     GroupItem<LA, LB> it;
     it.la = la; it.lb = lb; it.out = out; it.ldc = ldc; it.M = p.M; it.N = p.N; it.ktiles = p.ktiles; it.chunk = p.chunk;
-    const uint32_t idx = (uint32_t)items.size();
     items.push_back(it);
-    // all tiles of one k-chunk are neighbours in the grid: they read the same operand rows
-    for (int c = 0; c < p.nchunks; ++c)
-      for (int a = 0; a < p.tm; ++a)
-        for (int b = 0; b < p.tn; ++b) map.push_back(WgEntry{idx, (uint32_t)a, (uint32_t)b, (uint32_t)c});
+    plans.push_back(p);
+  }
+  // Workgroup order = dispatch order: members with the longest K chunk first (longest-processing-time-first keeps the tail of the launch
+  // short: a layer4 workgroup runs 196 K tiles, a BERT one 120, a k-chunked layer1 one 256); inside a member all tiles of one k-chunk are
+  // neighbours in the grid (they read the same operand rows).
+  void build_map() {
+    std::vector<uint32_t> order(items.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return plans[a].chunk > plans[b].chunk; });
+    map.clear();
+    for (uint32_t idx : order) {
+      const Plan& p = plans[idx];
+      for (int c = 0; c < p.nchunks; ++c)
+        for (int a = 0; a < p.tm; ++a)
+          for (int b = 0; b < p.tn; ++b) map.push_back(WgEntry{idx, (uint32_t)a, (uint32_t)b, (uint32_t)c});
+    }
+  }
+  size_t n_wgs() const {
+    size_t n = 0;
+    for (const Plan& p : plans) n += (size_t)p.nchunks * p.tm * p.tn;
+    return n;
   }
   size_t item_bytes() const { return (items.size() * sizeof(GroupItem<LA, LB>) + 255) / 256 * 256; }
-  size_t bytes() const { return item_bytes() + (map.size() * sizeof(WgEntry) + 255) / 256 * 256; }
-  void stage(char* host, size_t off) const {
+  size_t bytes() const { return item_bytes() + (n_wgs() * sizeof(WgEntry) + 255) / 256 * 256; }
+  void stage(char* host, size_t off) {
     if (items.empty()) return;
+    build_map();
     memcpy(host + off, items.data(), items.size() * sizeof(GroupItem<LA, LB>));
     memcpy(host + off + item_bytes(), map.data(), map.size() * sizeof(WgEntry));
   }

@@ -67,6 +67,14 @@ DEV f32x16 mfma32_f32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, f32 accumulate; the bf16 MFMA rate at half the operand bytes): lane l holds 8 consecutive
+// k of A[row l&31] / B[col l&31] (k = 8*(l>>5) + j) in one 64-bit register pair, byte j = element j; C/D as the bf16 form.
+DEV f32x16 mfma32_fp8(uint64_t a, uint64_t b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8((long)a, (long)b, c, 0, 0, 0);
+}
+// v_cvt_pk_fp8_f32: two f32 -> two OCP e4m3 bytes (round to nearest even), low byte = a. The caller clamps to +-448 first.
+DEV uint32_t cvt2_fp8(float a, float b) { return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xFFFFu; }
+
 // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies the address of row q,
 // columns 4p..4p+3 of a 4x16 block of 16-bit elements; lane i receives column i
 // (rows 0..3 in elements 0..3). Address must be 8-byte aligned, EXEC all ones.
@@ -97,6 +105,8 @@ DEV float wave_max(float v) {
 }
 
 DEV void atomic_add_f32(float* p, float v) { atomicAdd(p, v); }
+DEV void atomic_max_u32(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+DEV uint32_t f32_bits(float f) { return __float_as_uint(f); }
 
 DEV uint32_t umulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 

@@ -69,6 +69,9 @@ _SIGNATURES = {
     "clite_conv_dgrad_s2class": [_V, _V, _V, _I, _I, _V, _V],
     "clite_conv_wgrad": [_V, _V, _V, _V, _V],
     "clite_wgrad_group": [_I, _V, _I, _V, _V, _U64, _V],
+    "clite_fp8_quantize": [_I, _V, _U64, _V, _V, _V, _V],
+    "clite_gemm_nt_fp8": [_V, _I, _V, _I, _I, _I, _I, _V, _V, _V, _V],
+    "clite_conv_fwd_fp8": [_V, _V, _V, _V, _V, _V, _V],
     "clite_wgrad_group_workspace": [_I, C.c_int64, _V],
     "clite_stem_fwd": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
     "clite_stem_wgrad": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
@@ -333,6 +336,25 @@ class WgradGroup:
                 _inflight_groups.append((ev, self))
         for fn in self.extra:
             fn()
+
+
+class Fp8Tensor:
+    """An e4m3 copy of a tensor with its per-tensor scales (clite_fp8_quantize): q (uint8, same shape), scales = device f32 {scale, 1/scale}."""
+    __slots__ = ("q", "scales", "amax")
+
+    def __init__(self, x, dt):
+        self.q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        self.amax = torch.zeros(1, dtype=torch.float32, device=x.device)
+        self.scales = torch.empty(2, dtype=torch.float32, device=x.device)
+        check(lib().clite_fp8_quantize(dt, p(x), x.numel(), p(self.amax), p(self.scales), p(self.q), stream_ptr(x)), "fp8_quantize")
+
+
+def gemm_nt_fp8(A8, B8, M, N, K, ep, lda=None, ldb=None):
+    check(lib().clite_gemm_nt_fp8(p(A8.q), lda or K, p(B8.q), ldb or K, M, N, K, p(A8.scales), p(B8.scales), C.byref(ep), stream_ptr(A8.q)), "gemm_nt_fp8")
+
+
+def conv_fwd_fp8(x8, w8, cv, ep):
+    check(lib().clite_conv_fwd_fp8(p(x8.q), p(w8.q), C.byref(cv), p(x8.scales), p(w8.scales), C.byref(ep), stream_ptr(x8.q)), "conv_fwd_fp8")
 
 
 def stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, ep):

@@ -130,7 +130,11 @@ def _conv(rt, x, N, H, W, conv, training):
     M = N * cv.Ho * cv.Wo
     y = _alloc(rt, M, conv.out_channels)
     stats = rt.new_stats(conv.out_channels) if training else None
-    hip.conv_fwd(x, rt.arena.w(conv.weight), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
+    if rt.fp8 and rt.lowp and conv.in_channels % (64 if conv.k > 1 else 16) == 0:
+        # OCP e4m3 operands with per-tensor current scaling (include/clite.h: clite_conv_fwd_fp8); y, the statistics and everything backward stay as they are
+        hip.conv_fwd_fp8(hip.Fp8Tensor(x, rt.dt), hip.Fp8Tensor(rt.arena.w(conv.weight), rt.dt), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
+    else:
+        hip.conv_fwd(x, rt.arena.w(conv.weight), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
     if training and rt.precise_bn:
         hip.bn_centered_var(rt.dt, y, stats, M, conv.out_channels)
     u = _Unit()

@@ -109,8 +109,8 @@ class TrainStep:
     # (measured: 84 % of a one-graph step had exactly one kernel in flight), so real concurrency between the two encoders needs
     # separate graphs on separate streams:
     #
-    #   main : [image fwd] ------------> [heads fwd + bwd] --> [image bwd: layer4,3 | layer2,1,stem chain] [wgrads 2,1,stem] --> [norm + update]
-    #   side : [text  fwd] --(join)--^          (fork)-----> [text  bwd] ------(after layer3's chain)--> [wgrads of layer4,3] --(join)--^
+    #   main : [image fwd] ------------> [heads fwd + bwd] --> [image bwd chain: layer4,3 | layer2 | layer1,stem] [wgrads 1,stem] --> [norm + update]
+    #   side : [text  fwd] --(join)--^          (fork)-----> [text  bwd + its grouped wgrads] [wgrads 4,3] [wgrads 2] ---------(join)--^
     #   comm :                                     all-reduce(heads)                     all-reduce(text)  all-reduce(image)     (data parallel)
     #
     # Graphs that replay on the same stream share a memory pool (they run in capture order); the two streams use different pools,
@@ -165,28 +165,22 @@ class TrainStep:
             keep["result"] = {"loss": out[0].clone(), "loss_components": {"total_loss": out[0].clone(), "cross_modal_loss": out[1].clone(),
                                                                           "visual_loss": out[3].clone(), "textual_loss": out[4].clone()}}
 
-        # image backward in two chain segments with the weight gradients collected instead of launched (resnet_backward's `defer`): those of
-        # the late stages (layer3, layer4 — compute-bound, small tensors) replay on the text encoder's stream after BERT's backward, beside
-        # the HBM-bound BatchNorm chain of layer2 / layer1; the rest follow the chain on the main stream
+        # image backward in three chain segments with the weight gradients collected instead of launched (resnet_backward's `defer`): those of
+        # [layer4, layer3] and of [layer2] replay as grouped launches on the text encoder's stream — after BERT's backward, beside the HBM-bound
+        # BatchNorm chain of the earlier stages on the main stream; the last segment's follow the chain on the main stream
         inet = m.image_encoder.img_encoder
-        split = len(inet.layer1) + len(inet.layer2)
-
+        cut_a, cut_b = len(inet.layer1) + len(inet.layer2), len(inet.layer1)      # chain segments: [layer4, layer3] [layer2] [layer1, stem]
         from . import hip
-        ws = {k: hip.WgradGroup.alloc_workspace(rt.device) for k in ("a", "b", "t")}      # pinned staging cannot be allocated inside a capture
+        ws = {k: hip.WgradGroup.alloc_workspace(rt.device) for k in ("a", "b", "c", "t")}      # pinned staging cannot be allocated inside a capture
 
-        def image_bwd_a():
-            keep["wg_a"] = hip.WgradGroup(rt.dt, ws["a"])
-            resnet_backward(rt, inet, keep["ctx_i"], keep["dimg"].contiguous(), defer=keep["wg_a"], stop_block=split)
+        def image_bwd(seg, **kw):
+            def fn():
+                keep["wg_" + seg] = hip.WgradGroup(rt.dt, ws[seg])
+                resnet_backward(rt, inet, keep["ctx_i"], keep["dimg"].contiguous() if seg == "a" else None, defer=keep["wg_" + seg], **kw)
+            return fn
 
-        def image_bwd_b():
-            keep["wg_b"] = hip.WgradGroup(rt.dt, ws["b"])
-            resnet_backward(rt, inet, keep["ctx_i"], None, defer=keep["wg_b"], resume=True)
-
-        def wgrad_a():
-            keep["wg_a"].launch()
-
-        def wgrad_b():
-            keep["wg_b"].launch()
+        def wgrad(seg):
+            return lambda: keep["wg_" + seg].launch()
 
         def text_bwd():
             keep["wg_t"] = hip.WgradGroup(rt.dt, ws["t"])          # BERT's 49 linear weight gradients: one grouped launch at the end of its backward
@@ -204,10 +198,12 @@ class TrainStep:
                 capture("text_fwd", pool_side, text_fwd)
                 capture("heads", pool_main, heads)
                 capture("text_bwd", pool_side, text_bwd)
-                capture("image_bwd_a", pool_main, image_bwd_a)
-                capture("wgrad_a", pool_side, wgrad_a)
-                capture("image_bwd_b", pool_main, image_bwd_b)
-                capture("wgrad_b", pool_main, wgrad_b)
+                capture("image_bwd_a", pool_main, image_bwd("a", stop_block=cut_a))
+                capture("wgrad_a", pool_side, wgrad("a"))
+                capture("image_bwd_b", pool_main, image_bwd("b", resume=True, stop_block=cut_b))
+                capture("wgrad_b", pool_side, wgrad("b"))
+                capture("image_bwd_c", pool_main, image_bwd("c", resume=True))
+                capture("wgrad_c", pool_main, wgrad("c"))
                 capture("update", pool_main, update)
         except BaseException:
             rt.abort_capture()
@@ -234,12 +230,13 @@ class TrainStep:
             G["text_bwd"].replay()
         if ex is not None:
             ex.reduce_span(*self._regions["text_encoder"], after=side)          # ordered after BERT's backward only (the event is taken now)
-        G["image_bwd_a"].replay()
-        side.wait_stream(main)                     # the late stages' dy are final
-        with torch.cuda.stream(side):
-            G["wgrad_a"].replay()
-        G["image_bwd_b"].replay()
-        G["wgrad_b"].replay()
+        for seg in ("a", "b"):                     # a stage's weight gradients go to the side stream as soon as its chain segment is enqueued
+            G["image_bwd_" + seg].replay()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                G["wgrad_" + seg].replay()
+        G["image_bwd_c"].replay()
+        G["wgrad_c"].replay()
         if ex is not None:
             main.wait_stream(side)
             ex.reduce_span(*self._regions["image_encoder"], after=main)

@@ -140,6 +140,19 @@ typedef struct clite_wgrad_item {
 int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n, void* ws_dev, void* ws_host, uint64_t ws_bytes, void* stream);
 int clite_wgrad_group_workspace(int n_items, int64_t total_workgroups, uint64_t* bytes);
 
+/* ---- OCP e4m3 forward path (BASELINE.json configs[4]; the reference has no fp8 code — the policy is this library's).
+ * Per-tensor current scaling: amax = max|x| (ZERO on entry), scale = 448 / amax, q = e4m3(clamp(x * scale, +-448)) rounded to nearest even;
+ * scales (device f32[2]) <- {scale, 1 / scale}. n % 8 == 0. dtype of x: CLITE_BF16 or CLITE_F32. */
+int clite_fp8_quantize(int dtype, const void* x, uint64_t n, float* amax, float* scales, void* out_fp8, void* stream);
+/* C[M,N] = (A8[M,K] * B8[N,K]^T) * a_scales[1] * b_scales[1] through the fused epilogue (bf16 / f32 output; no split-K, no BatchNorm-backward
+ * form): nn.Linear forward on e4m3 operands, v_mfma_f32_32x32x16_fp8_fp8 with f32 accumulation. K, lda, ldb multiples of 16. */
+int clite_gemm_nt_fp8(const void* A8, int lda, const void* B8, int ldb, int M, int N, int K, const float* a_scales, const float* b_scales,
+                      const clite_epilogue* ep, void* stream);
+/* y = conv(x8, w8) * x_scales[1] * w_scales[1]: clite_conv_fwd on e4m3 operands (x8 [N][H][W][C], w8 [K][R][S][C]); C % 16 == 0, and
+ * C % 64 == 0 for windowed convs. */
+int clite_conv_fwd_fp8(const void* x8, const void* w8, const clite_conv* cv, const float* x_scales, const float* w_scales,
+                       const clite_epilogue* ep, void* stream);
+
 /* ResNet stem conv1 = nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (torchvision, reference encoder.py:36-38) on the
  * pre-padded NHWC4 image from clite_image_to_nhwc4 (Hp >= 2*(Ho-1)+7, Wp >= 2*(Wo-1)+8, Wp even). wv is the weight packed
  * as [64][7][8][4] (clite_stem_pack from f32 [64][7][7][3]); clite_stem_unpack_grad folds the packed gradient back (+=). */

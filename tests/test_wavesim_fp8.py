@@ -1,0 +1,118 @@
+"""CPU-side (wave simulator) check of the OCP e4m3 forward path: the quantiser against a numpy restatement of e4m3 round-to-nearest-even
+with per-tensor scaling, and the fp8 GEMM / conv index math (64-byte K slabs of 64 elements, ds_read_b64 fragments, v_mfma_f32_32x32x16_fp8_fp8
+emulated lane-accurately) against numpy on the de-quantised operands — which the kernel must reproduce up to f32 summation order, because
+products of two e4m3 values are exact in f32. Runs without a GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from simlib import Conv, bf16_round, from_bf16, lib, make_ep, ptr, to_bf16
+
+BF16, F32 = 0, 1
+
+
+def e4m3_values():
+    v = np.zeros(256, np.float32)
+    for b in range(256):
+        s, e, m = b >> 7, (b >> 3) & 15, b & 7
+        if e == 15 and m == 7:
+            r = np.nan
+        elif e == 0:
+            r = m * 2.0 ** -9
+        else:
+            r = (1 + m / 8) * 2.0 ** (e - 7)
+        v[b] = -r if s else r
+    return v
+
+
+E4M3 = e4m3_values()
+
+
+def quantize_ref(x):
+    """numpy restatement: scale = 448 / amax; nearest e4m3 value (ties to even mantissa) of clamp(x * scale)."""
+    amax = np.abs(x).max()
+    scale = np.float32(448.0) / amax if amax > 0 else np.float32(1)
+    y = np.clip(x.astype(np.float32) * scale, -448, 448).astype(np.float32)
+    pos = E4M3[:127]                                          # 0 .. 448 ascending (0x00..0x7e)
+    idx = np.searchsorted(pos, np.abs(y), side="left").clip(1, 126)
+    lo, hi = pos[idx - 1], pos[idx]
+    dl, dh = np.abs(y) - lo, hi - np.abs(y)
+    pick_hi = (dh < dl) | ((dh == dl) & (idx % 2 == 0))       # ties -> even code
+    code = np.where(pick_hi, idx, idx - 1).astype(np.uint8)
+    code = np.where(np.abs(y) == 0, 0, code).astype(np.uint8)
+    return (code | np.where(np.signbit(y), 0x80, 0).astype(np.uint8)), scale
+
+
+def _quant(L, x, dtype):
+    buf = to_bf16(x) if dtype == BF16 else np.ascontiguousarray(x, np.float32)
+    q = np.zeros(x.shape, np.uint8)
+    amax, scales = np.zeros(1, np.float32), np.zeros(2, np.float32)
+    assert L.clite_fp8_quantize(dtype, ptr(buf), x.size, ptr(amax), ptr(scales), ptr(q), None) == 0
+    return q, scales, amax
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_quantizer_matches_e4m3_round_to_nearest_even(dtype):
+    L = lib()
+    L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((37, 64)) * np.exp(rng.standard_normal((37, 64)) * 3)).astype(np.float32)
+    x[0, :8] = [0.0, -0.0, 1e-30, -1e-30, 1.0, -1.0, 0.5, 3.0]
+    if dtype == BF16:
+        x = bf16_round(x)
+    q, scales, amax = _quant(L, x, dtype)
+    ref, scale = quantize_ref(x)
+    assert amax[0] == np.abs(x).max() and np.isclose(scales[0], scale, rtol=1e-6) and np.isclose(scales[1], 1 / scale, rtol=1e-6)
+    assert np.array_equal(q & 0x7f, ref & 0x7f) and np.array_equal((q >> 7)[np.abs(x) > 1e-20], (ref >> 7)[np.abs(x) > 1e-20])
+    assert np.abs(E4M3[q]).max() == 448.0                      # the largest element lands exactly on the format's maximum
+    z = np.zeros((8, 16), np.float32)                          # all-zero tensor: scale 1, zeros
+    qz, sz, _ = _quant(L, z, F32)
+    assert not qz.any() and sz[0] == 1.0 and sz[1] == 1.0
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 208), (300, 64, 96), (70, 1000, 64)])
+def test_gemm_nt_fp8(M, N, K):
+    L = lib()
+    L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.clite_gemm_nt_fp8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(M + N + K)
+    A, B = rng.standard_normal((M, K)).astype(np.float32), (rng.standard_normal((N, K)) * 0.1).astype(np.float32)
+    qa, sa, _ = _quant(L, A, F32)
+    qb, sb, _ = _quant(L, B, F32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    out = np.zeros((M, N), np.float32)
+    ep = make_ep(out, N, out_f32=True, bias=bias, act=1)
+    assert L.clite_gemm_nt_fp8(ptr(qa), K, ptr(qb), K, M, N, K, ptr(sa), ptr(sb), C.byref(ep), None) == 0
+    ref = np.maximum((E4M3[qa].astype(np.float64) @ E4M3[qb].astype(np.float64).T) * (sa[1] * sb[1]) + bias, 0)
+    assert np.abs(out - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-6)
+    # and the quantisation itself costs what e4m3 costs: a few percent of the f32 product's scale
+    exact = np.maximum(A.astype(np.float64) @ B.astype(np.float64).T + bias, 0)
+    assert np.abs(out - exact).max() <= 0.08 * np.abs(exact).max()
+    # plain epilogue (bf16 store + column statistics)
+    o16 = np.zeros((M, N), np.uint16)
+    cs = np.zeros((2, N), np.float32)
+    assert L.clite_gemm_nt_fp8(ptr(qa), K, ptr(qb), K, M, N, K, ptr(sa), ptr(sb), C.byref(make_ep(o16, N, colsum=cs)), None) == 0
+    ref2 = (E4M3[qa].astype(np.float64) @ E4M3[qb].astype(np.float64).T) * (sa[1] * sb[1])
+    got = from_bf16(o16)
+    assert np.abs(got - ref2).max() <= 6e-3 * np.abs(ref2).max()
+    assert np.abs(cs[0] - got.sum(0)).max() <= 1e-4 * max(np.abs(got.sum(0)).max(), 1e-6)
+
+
+@pytest.mark.parametrize("N,H,W,Cc,K,R,st,pad", [(2, 8, 8, 64, 64, 3, 1, 1), (3, 6, 6, 48, 136, 1, 1, 0), (2, 9, 7, 128, 32, 3, 2, 1)])
+def test_conv_fwd_fp8(N, H, W, Cc, K, R, st, pad):
+    from test_wavesim_igemm import conv_ref
+    L = lib()
+    L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.clite_conv_fwd_fp8.argtypes = [C.c_void_p] * 7
+    rng = np.random.default_rng(H * W + K)
+    Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+    cv = Conv(BF16, N, H, W, Cc, K, R, R, st, pad, Ho, Wo)
+    x = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
+    w = (rng.standard_normal((K, R, R, Cc)) * 0.1).astype(np.float32)
+    qx, sx, _ = _quant(L, x, F32)
+    qw, sw, _ = _quant(L, w, F32)
+    y = np.zeros((N, Ho, Wo, K), np.float32)
+    assert L.clite_conv_fwd_fp8(ptr(qx), ptr(qw), C.byref(cv), ptr(sx), ptr(sw), C.byref(make_ep(y, K, out_f32=True)), None) == 0
+    ref = conv_ref(E4M3[qx], E4M3[qw], st, pad) * (sx[1] * sw[1])
+    assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()

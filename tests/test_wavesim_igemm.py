@@ -276,7 +276,7 @@ def test_stem_conv7x7(dtype):
 def test_grouped_weight_gradients():
     """clite_wgrad_group: conv weight gradients of all three tile families (<= 64 output channels, <= 64 (r, s, ci) columns, general) and a
     linear weight gradient with a strided operand, as ONE grouped launch set, accumulate (+=) the same values as the per-member entry points
-    compute — including a member whose K range is cut into several k-chunks (> 128 K tiles)."""
+    compute — including a member whose K range is cut into several k-chunks (> 256 K tiles)."""
     from simlib import Conv
 
     class Item(C.Structure):
@@ -288,7 +288,7 @@ def test_grouped_weight_gradients():
     L.clite_wgrad_group.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.clite_wgrad_group_workspace.argtypes = [C.c_int, C.c_int64, C.c_void_p]
     items, refs, outs, hold = [], [], [], []
-    for (N, H, W, Cc, K, R, st, pad) in [(2, 8, 8, 32, 64, 3, 1, 1), (3, 6, 6, 64, 136, 1, 1, 0), (2, 9, 7, 128, 160, 1, 2, 0), (9, 24, 24, 32, 64, 1, 1, 0)]:
+    for (N, H, W, Cc, K, R, st, pad) in [(2, 8, 8, 32, 64, 3, 1, 1), (3, 6, 6, 64, 136, 1, 1, 0), (2, 9, 7, 128, 160, 1, 2, 0), (9, 32, 32, 32, 64, 1, 1, 0)]:      # last: 9216 pixels = 288 K tiles -> two k-chunks
         Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
         cv = Conv(BF16, N, H, W, Cc, K, R, R, st, pad, Ho, Wo)
         x, xb = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), BF16)

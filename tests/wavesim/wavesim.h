@@ -246,6 +246,55 @@ inline f32x16 mfma32_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
   wave_barrier_();
   return c;
 }
+// OCP e4m3fn: 1 sign, 4 exponent (bias 7), 3 mantissa bits; no infinities, 0x7f / 0xff = NaN, max 448
+inline float fp8_e4m3_to_f32(uint8_t v) {
+  int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+  float r;
+  if (e == 15 && m == 7) r = NAN;
+  else if (e == 0) r = ldexpf((float)m, -9);               // subnormal: m/8 * 2^-6
+  else r = ldexpf(1.0f + m / 8.0f, e - 7);
+  return s ? -r : r;
+}
+inline uint8_t f32_to_fp8_e4m3(float f) {                  // round to nearest even, saturating at +-448 (callers clamp anyway)
+  if (f != f) return 0x7f;
+  uint8_t s = std::signbit(f) ? 0x80 : 0;
+  float a = fabsf(f);
+  if (a >= 464.f) return s | 0x7e;                         // beyond the midpoint to the next (non-existent) value: saturate
+  if (a < ldexpf(1.f, -10)) return s;                      // below half the smallest subnormal
+  int e;
+  float m = frexpf(a, &e);                                 // a = m * 2^e, m in [0.5, 1)
+  int E = e - 1 + 7;                                       // biased exponent if normal
+  float q;
+  if (E >= 1) q = rintf((m * 2.f - 1.f) * 8.f);            // mantissa steps of 1/8 above 1.0
+  else { q = rintf(ldexpf(a, 9)); E = 0; }                 // subnormal: multiples of 2^-9
+  int mi = (int)q;
+  if (E >= 1 && mi == 8) { mi = 0; ++E; }
+  if (E == 0 && mi == 8) { mi = 0; E = 1; }
+  if (E > 15 || (E == 15 && mi == 7)) return s | 0x7e;
+  return s | (uint8_t)(E << 3) | (uint8_t)mi;
+}
+inline uint32_t cvt2_fp8(float a, float b) { return (uint32_t)f32_to_fp8_e4m3(a) | ((uint32_t)f32_to_fp8_e4m3(b) << 8); }
+// v_mfma_f32_32x32x16_fp8_fp8: operand maps as the bf16 form, one byte per element
+inline f32x16 mfma32_fp8(uint64_t a, uint64_t b, f32x16 c) {
+  auto& w = wavesim::g_block->waves[wavesim::g_wave];
+  int l = wavesim::g_lane;
+  w.slot[l][0] = a;
+  w.slot[l][1] = b;
+  wave_barrier_();
+  int col = l & 31;
+  for (int i = 0; i < 16; ++i) {
+    int row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+    float acc = c[i];
+    for (int k = 0; k < 16; ++k) {
+      uint8_t av = (uint8_t)(w.slot[row + 32 * (k >> 3)][0] >> (8 * (k & 7)));
+      uint8_t bv = (uint8_t)(w.slot[col + 32 * (k >> 3)][1] >> (8 * (k & 7)));
+      acc = fmaf(fp8_e4m3_to_f32(av), fp8_e4m3_to_f32(bv), acc);
+    }
+    c[i] = acc;
+  }
+  wave_barrier_();
+  return c;
+}
 // v_mfma_f32_32x32x2_f32
 inline f32x16 mfma32_f32(float a, float b, f32x16 c) {
   auto& w = wavesim::g_block->waves[wavesim::g_wave];
@@ -290,6 +339,17 @@ inline s16x4 lds_read_tr16(const void* p) {
   return r;
 }
 
+inline void atomic_max_u32(uint32_t* p, uint32_t v) {
+  std::atomic_ref<uint32_t> a(*p);
+  uint32_t old = a.load();
+  while (old < v && !a.compare_exchange_weak(old, v)) {
+  }
+}
+inline uint32_t f32_bits(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
 inline void atomic_add_f32(float* p, float v) {
   std::atomic_ref<float> a(*p);
   float old = a.load();
