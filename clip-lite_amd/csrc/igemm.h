@@ -560,20 +560,29 @@ DEV void igemm_epilogue_plain(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& e
   }
 }
 
-// BatchNorm-backward epilogue (conv dgrad inside the ResNet backward; see HEAVY above) in its own, register-light form (92 VGPRs + 64
-// accumulators: three waves per SIMD). The tile goes through LDS one wave row (WM rows) at a time, so the staging image (34 KB) stays below
-// the operand ring (48 KB) and THREE workgroups fit a CU — round 1 staged the whole 128 x 128 f32 tile (68 KB: two workgroups per CU, with
-// a third of the register file idle). Within a pass every thread walks its WM/RPSE rows with the three extra operands (mask source,
-// BatchNorm input, residual) of the next two rows already in flight.
+// BatchNorm-backward epilogue (conv dgrad inside the ResNet backward; see HEAVY above) in its own layout: the kernel runs at two
+// workgroups per CU anyway (registers), so the whole BM x BN accumulator tile is staged in LDS at once (one barrier instead of two per
+// wave row) and every thread then walks its BM/RPSE rows with the three extra operands (mask source, BatchNorm input, residual) of the
+// next rows already in flight: their latency is paid once per tile, not once per row.
 template <typename T, class CFG>
 DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
                            int tid, int lane, int wave, int wm0, int wn0) {
-  constexpr int BN = CFG::BN;
+  constexpr int BM = CFG::BM, BN = CFG::BN;
   constexpr int RM = CFG::RM, RN = CFG::RN;
-  constexpr int CPRE = BN / 8, RPSE = 256 / CPRE, ROWS_PT = CFG::WM / RPSE;
+  constexpr int CPRE = BN / 8, RPSE = 256 / CPRE, ROWS_PT = BM / RPSE;
   const int ecol = (tid % CPRE) * 8, erow0 = tid / CPRE;
   const int gcol = n0 + ecol;
   const bool colok = gcol < N;
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int col = wn0 + j * 32 + (lane & 31);
+        *(float*)(smem + row * CFG::EPI_PITCH + col * 4) = acc[i][j][r];
+      }
   float bn_mean[8], csum[8], csq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { bn_mean[e] = 0.f; csum[e] = 0.f; csq[e] = 0.f; }
@@ -584,84 +593,75 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
 #pragma unroll
     for (int e = 0; e < 8; ++e) bn_mean[e] *= ep.bn_inv_count;
   }
-  constexpr int AHEAD = ROWS_PT < 2 ? ROWS_PT : 2;       // rows whose operands are in flight ahead of the row being written
-  for (int pass = 0; pass < CFG::WAVES_M; ++pass) {
-    Raw8<T> pa[ROWS_PT], py[ROWS_PT], pr[ROWS_PT];
-    uint32_t gix[ROWS_PT];
-    bool okr[ROWS_PT];
-    auto request = [&](int q) {
-      int grow = m0 + pass * CFG::WM + erow0 + q * RPSE;
-      okr[q] = colok && grow < M;
-      gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
-      if (okr[q]) {
-        if (ep.dact_aux) pa[q].ld((const T*)ep.dact_aux + gix[q]);
-        if (ep.bn_y) py[q].ld((const T*)ep.bn_y + gix[q]);
-        if (ep.residual) pr[q].ld((const T*)ep.residual + gix[q]);
-      }
-    };
-#pragma unroll
-    for (int q = 0; q < AHEAD; ++q) request(q);
-    if (wave / CFG::WAVES_N == pass) {
-#pragma unroll
-      for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int j = 0; j < RN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            int col = wn0 + j * 32 + (lane & 31);
-            *(float*)(smem + row * CFG::EPI_PITCH + col * 4) = acc[i][j][r];
-          }
+  // Rows whose operands are in flight ahead of the row being written. Measured alternatives (round 2, MI355X, in-step per-launch times):
+  //  * all ROWS_PT rows ahead (the registers are there: the whole-tile staging holds the kernel at two workgroups per CU anyway):
+  //    no faster — 1024 -> 256 1x1 dgrad 80.7 vs 82.5 us, 256 -> 64 191 vs 217;
+  //  * staging one wave row at a time (34 KB, under the operand ring) + __launch_bounds__(256, 3) for three workgroups per CU: the
+  //    allocator then spills 20 registers and the launches get slower — 256 -> 64 191 -> 267 us, 64 -> 256 97 -> 116, step 18.7 -> 19.2 ms.
+  constexpr int AHEAD = 2;
+  Raw8<T> pa[ROWS_PT], py[ROWS_PT], pr[ROWS_PT];
+  uint32_t gix[ROWS_PT];
+  bool okr[ROWS_PT];
+  auto request = [&](int q) {
+    int grow = m0 + erow0 + q * RPSE;
+    okr[q] = colok && grow < M;
+    gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
+    if (okr[q]) {
+      if (ep.dact_aux) pa[q].ld((const T*)ep.dact_aux + gix[q]);
+      if (ep.bn_y) py[q].ld((const T*)ep.bn_y + gix[q]);
+      if (ep.residual) pr[q].ld((const T*)ep.residual + gix[q]);
     }
-    lds_barrier();
+  };
 #pragma unroll
-    for (int q = 0; q < ROWS_PT; ++q) {
-      if (q + AHEAD < ROWS_PT) request(q + AHEAD);
-      if (!okr[q]) continue;
-      const float* src = (const float*)(smem + (erow0 + q * RPSE) * CFG::EPI_PITCH + ecol * 4);
-      f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
-      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      float msk[8];
+  for (int q = 0; q < AHEAD && q < ROWS_PT; ++q) request(q);
+  lds_barrier();
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v[e] *= ep.alpha; msk[e] = 1.f; }
-      if (ep.dact_aux) {
-        float av[8];
-        pa[q].get(av);
+  for (int q = 0; q < ROWS_PT; ++q) {
+    if (q + AHEAD < ROWS_PT) request(q + AHEAD);
+    if (!okr[q]) continue;
+    const float* src = (const float*)(smem + (erow0 + q * RPSE) * CFG::EPI_PITCH + ecol * 4);
+    f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    float msk[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) msk[e] = av[e] > 0.f ? 1.f : 0.f;       // ReLU' only (check_ep enforces dact == 1 here)
-      }
-      if (!ep.mask_after_residual) {
+    for (int e = 0; e < 8; ++e) { v[e] *= ep.alpha; msk[e] = 1.f; }
+    if (ep.dact_aux) {
+      float av[8];
+      pa[q].get(av);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= msk[e];
-      }
-      if (ep.residual) {
-        float rv[8];
-        pr[q].get(rv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
-      }
-      if (ep.mask_after_residual) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= msk[e];
-      }
-      if (ep.out_f32 || sizeof(T) == 4) {
-        store8((float*)ep.out + gix[q], v);
-      } else {
-        store8((bf16*)ep.out + gix[q], v);
-        round8_bf16(v);   // statistics of what was stored
-      }
-      if (ep.bn_y) {
-        float yv[8];
-        py[q].get(yv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * (yv[e] - bn_mean[e]); }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
-      }
+      for (int e = 0; e < 8; ++e) msk[e] = av[e] > 0.f ? 1.f : 0.f;       // ReLU' only (check_ep enforces dact == 1 here)
     }
-    lds_barrier();
+    if (!ep.mask_after_residual) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= msk[e];
+    }
+    if (ep.residual) {
+      float rv[8];
+      pr[q].get(rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    if (ep.mask_after_residual) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= msk[e];
+    }
+    if (ep.out_f32 || sizeof(T) == 4) {
+      store8((float*)ep.out + gix[q], v);
+    } else {
+      store8((bf16*)ep.out + gix[q], v);
+      round8_bf16(v);   // statistics of what was stored
+    }
+    if (ep.bn_y) {
+      float yv[8];
+      py[q].get(yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * (yv[e] - bn_mean[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+    }
   }
+  lds_barrier();
   if (ep.colsum) {
     float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
     float* red = (float*)smem;                      // [RPSE][CPRE*16]

@@ -269,14 +269,12 @@ template <typename T, int ROWS, int BK, bool D> struct DmaIssue<DmaKC<T, ROWS, B
 };
 
 // EPI: 0 = generic fused epilogue, 1 = BatchNorm-backward epilogue (igemm_epilogue_bn), 2 = plain bf16 store (+ bias, + column statistics)
-// (the BatchNorm-backward instantiation asks for three waves per SIMD: its LDS allows three workgroups per CU, and without the hint the
-// register allocator settles at 182 registers = two)
 template <typename T, class CFG, class LA, class LB, int NSTAGE, int EPI = 0>
-__global__ __launch_bounds__(256, (EPI == 1 && sizeof(T) == 2) ? 3 : 1) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split, int xsplits) {
+__global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split, int xsplits) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
-  constexpr int EPIB = CFG::EPI_BYTES;      // every epilogue stages one wave row (WM rows) of the f32 tile at a time
+  constexpr int EPIB = EPI == 1 ? CFG::BM * CFG::EPI_PITCH : CFG::EPI_BYTES;      // the BatchNorm-backward epilogue stages the whole tile
   constexpr int SMEM = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
   constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];

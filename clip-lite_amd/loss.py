@@ -324,6 +324,67 @@ def jsd_backward(rt, mod, saved, gout):
     return dimg, dtxt
 
 
+# ---- the same heads cut along the modality boundary (captured step only: train_loop.TrainStep) --------------------------------------------
+# Everything but the critic touches one modality only — the MI projection block and the prior discriminator of the image features, and
+# those of the text features — and the prior terms' gradients need nothing but their own forward (dL/d total is the constant 1). So the
+# text half runs on the text encoder's stream: its forward (and the prior's backward) right behind BERT's forward, hidden under the tail of
+# the ResNet forward; its block backward right behind the critic, beside the image half. Only the critic sits on the join.
+def jsd_half_forward(rt, mod, feat, which, step, site, acc, gout):
+    """which: "image" | "text". Prior discriminator forward + backward and MI-block forward of one modality. acc: the step's 8 zeroed
+    accumulators (slot 2 / 3 = this prior's term). Returns the state jsd_join / jsd_half_backward need."""
+    feat = feat.to(rt.tdtype).contiguous()
+    img = which == "image"
+    pd = mod.prior_d if img else mod.text_prior_d
+    use_prior = mod.image_prior if img else mod.text_prior
+    dprior = None
+    if use_prior:
+        noise = (mod._noise or (None, None))[0 if img else 1]
+        pctx = prior_forward(rt, pd, feat, noise, acc[2:3] if img else acc[3:4], step, site)
+        dprior = prior_backward(rt, pd, pctx, gout, mod.prior_weight, None)
+    blk = mod.global_d.img_block if img else mod.global_d.text_block
+    f, c = mi_block_forward(rt, blk, feat, step.training)
+    return {"f": f, "c": c, "dprior": dprior, "blk": blk}
+
+
+def jsd_join(rt, mod, hi, ht, acc, gout):
+    """Critic forward, the total, critic backward (JSD estimator, or the InfoNCE all-pairs variant). Returns (out f32[8], df_image, df_text)."""
+    dt, A = rt.dt, rt.arena
+    gd = mod.global_d
+    f1, f2 = hi["f"], ht["f"]
+    B, U = f1.shape[0], gd.img_block.units
+    out = torch.empty(8, device=rt.device, dtype=torch.float32)
+    df1, df2 = _alloc(rt, B, U), _alloc(rt, B, U)
+    if getattr(mod, "estimator", "jsd") == "infonce":
+        if B % 8:
+            raise RuntimeError("InfoNCELoss needs a batch that is a multiple of 8 (GEMM column granularity)")
+        a, b = _alloc(rt, B, U), _alloc(rt, B, U)
+        hip.l2_normalize(dt, f1, a, B, U)
+        hip.l2_normalize(dt, f2, b, B, U)
+        Cm = torch.empty(B, B, device=rt.device, dtype=torch.float32)
+        hip.gemm_nt(dt, a, b, B, B, U, hip.epilogue(Cm, B, out_f32=True))
+        lse = torch.empty(2, B, device=rt.device, dtype=torch.float32)
+        hip.infonce_fwd(Cm, B, B, gd.temperature, lse[0], lse[1], acc)
+        hip.loss_finalize(acc, mod.prior_weight, out)
+        dC = _alloc(rt, B, B)
+        hip.infonce_bwd(dt, Cm, B, B, gd.temperature, lse[0], lse[1], gout, 1.0 - mod.prior_weight, dC, B, A.g(gd.temperature).view(1))
+        da, db = _alloc(rt, B, U), _alloc(rt, B, U)
+        hip.gemm_nn(dt, dC, b, B, U, B, hip.epilogue(da, U))
+        hip.gemm_tn(dt, dC, a, B, U, B, hip.epilogue(db, U))
+        hip.l2_normalize_bwd(dt, f1, a, da, df1, B, U)
+        hip.l2_normalize_bwd(dt, f2, b, db, df2, B, U)
+    else:
+        work = torch.empty(B, 8, device=rt.device, dtype=torch.float32)
+        hip.critic_jsd_fwd(dt, f1, f2, gd.temperature, B, U, work, acc)
+        hip.loss_finalize(acc, mod.prior_weight, out)
+        hip.critic_jsd_bwd(dt, f1, f2, gd.temperature, work, gout, 1.0 - mod.prior_weight, B, U, df1, df2, A.g(gd.temperature).view(1))
+    return out, df1, df2
+
+
+def jsd_half_backward(rt, half, df):
+    """MI-block backward of one modality; returns the gradient of its features (prior part included)."""
+    return mi_block_backward(rt, half["blk"], half["c"], df, half["dprior"])
+
+
 class _JSDLossFn(torch.autograd.Function):
     """image/text features -> (total, [total, cross, prior, 0]); backward drives the head kernels and returns feature grads."""
 

@@ -311,8 +311,10 @@ class DeviceRuntime:
         return StepState(self.base_seed * 1000003 + self.steps, training)
 
     def new_side_stream(self):
-        """The text encoder's stream (default priority; a high-priority side stream measured no better)."""
-        import os
+        """The text encoder's stream. Measured and rejected (round 2, MI355X, 18.5 ms step): a high-priority side stream, a high-priority main
+        stream (18.5 / 18.6 ms: HIP stream priorities do not change which stream's workgroups get the CUs), and a CU-masked side stream
+        (hipExtStreamCreateWithCUMask with 64-160 CUs wrapped as an ExternalStream: 21.6 ms for every mask size — graph replays on it no
+        longer overlapped the main stream at all)."""
         return torch.cuda.Stream(device=self.device)
 
     def begin_capture(self):

@@ -157,30 +157,53 @@ class TrainStep:
             keep["step_t"] = rt.next_step(True)
             keep["txt"], keep["ctx_t"] = bert_forward(rt, m.text_encoder.strans, sb["input_ids"], sb["attention_mask"], keep["step_t"])
 
-        def heads():
-            out, saved = jsd_forward(rt, m.loss, keep["img"], keep["txt"], rt.next_step(True))
-            keep["out"], keep["gout"] = out, torch.ones(1, device=rt.device, dtype=torch.float32)
-            keep["dimg"], keep["dtxt"] = jsd_backward(rt, m.loss, saved, keep["gout"])
-            keep["loss_saved"] = saved
+        # the heads, cut along the modality boundary (loss.jsd_half_forward): the text half on the side stream right behind BERT, the image half
+        # and the critic (the only joint piece) on the main stream
+        from .loss import jsd_half_backward, jsd_half_forward, jsd_join
+
+        def heads_t1():
+            keep["step_h"] = st = rt.next_step(True)
+            keep["sites"] = (st.site(), st.site())            # image prior noise, text prior noise: the eager draw order (reference loss.py:189,196)
+            keep["acc"] = torch.zeros(8, device=rt.device, dtype=torch.float32)
+            keep["gout"] = torch.ones(1, device=rt.device, dtype=torch.float32)
+            keep["ht"] = jsd_half_forward(rt, m.loss, keep["txt"], "text", st, keep["sites"][1], keep["acc"], keep["gout"])
+
+        def heads_m1():
+            keep["hi"] = jsd_half_forward(rt, m.loss, keep["img"], "image", keep["step_h"], keep["sites"][0], keep["acc"], keep["gout"])
+            rt.bump_counters("loss", 2)
+            out, keep["df1"], keep["df2"] = jsd_join(rt, m.loss, keep["hi"], keep["ht"], keep["acc"], keep["gout"])
+            keep["out"] = out
             keep["result"] = {"loss": out[0].clone(), "loss_components": {"total_loss": out[0].clone(), "cross_modal_loss": out[1].clone(),
                                                                           "visual_loss": out[3].clone(), "textual_loss": out[4].clone()}}
 
-        # image backward in three chain segments with the weight gradients collected instead of launched (resnet_backward's `defer`): those of
-        # [layer4, layer3] and of [layer2] replay as grouped launches on the text encoder's stream — after BERT's backward, beside the HBM-bound
-        # BatchNorm chain of the earlier stages on the main stream; the last segment's follow the chain on the main stream
-        inet = m.image_encoder.img_encoder
-        cut_a, cut_b = len(inet.layer1) + len(inet.layer2), len(inet.layer1)      # chain segments: [layer4, layer3] [layer2] [layer1, stem]
-        from . import hip
-        ws = {k: hip.WgradGroup.alloc_workspace(rt.device) for k in ("a", "b", "c", "t")}      # pinned staging cannot be allocated inside a capture
+        def heads_m2():
+            keep["dimg"] = jsd_half_backward(rt, keep["hi"], keep["df1"])
 
-        def image_bwd(seg, **kw):
+        def heads_t2():
+            keep["dtxt"] = jsd_half_backward(rt, keep["ht"], keep["df2"])
+
+        # image backward in chain segments with the weight gradients collected instead of launched (resnet_backward's `defer`): each segment's
+        # replay as one grouped launch on the text encoder's stream — after BERT's backward, beside the HBM-bound BatchNorm chain of the
+        # earlier stages on the main stream; only the last segment's (first block + stem) follow the chain on the main stream
+        inet = m.image_encoder.img_encoder
+        n1, n2 = len(inet.layer1), len(inet.layer2)
+        # chain segments (first block index of each, walked backwards): [layer4, layer3] [layer2] [layer1, stem]. (Cutting layer1 per block so that
+        # more of its weight gradients overlap the chain was measured slower, 18.9 vs 18.6 ms: a group of one block's four weight gradients
+        # takes as long — 0.8 ms — as the group of all three blocks', which is the point of grouping.)
+        cuts = [n1 + n2, n1, 0]
+        segs = [f"s{i}" for i in range(len(cuts))]
+        from . import hip
+        ws = {k: hip.WgradGroup.alloc_workspace(rt.device) for k in segs + ["t"]}      # pinned staging cannot be allocated inside a capture
+
+        def image_bwd(i):
             def fn():
-                keep["wg_" + seg] = hip.WgradGroup(rt.dt, ws[seg])
-                resnet_backward(rt, inet, keep["ctx_i"], keep["dimg"].contiguous() if seg == "a" else None, defer=keep["wg_" + seg], **kw)
+                keep["wg_" + segs[i]] = hip.WgradGroup(rt.dt, ws[segs[i]])
+                resnet_backward(rt, inet, keep["ctx_i"], keep["dimg"].contiguous() if i == 0 else None, defer=keep["wg_" + segs[i]],
+                                stop_block=cuts[i], resume=i > 0)
             return fn
 
-        def wgrad(seg):
-            return lambda: keep["wg_" + seg].launch()
+        def wgrad(i):
+            return lambda: keep["wg_" + segs[i]].launch()
 
         def text_bwd():
             keep["wg_t"] = hip.WgradGroup(rt.dt, ws["t"])          # BERT's 49 linear weight gradients: one grouped launch at the end of its backward
@@ -196,14 +219,14 @@ class TrainStep:
             with torch.no_grad():
                 capture("image_fwd", pool_main, image_fwd)
                 capture("text_fwd", pool_side, text_fwd)
-                capture("heads", pool_main, heads)
+                capture("heads_t1", pool_side, heads_t1)
+                capture("heads_m1", pool_main, heads_m1)
+                capture("heads_t2", pool_side, heads_t2)
+                capture("heads_m2", pool_main, heads_m2)
                 capture("text_bwd", pool_side, text_bwd)
-                capture("image_bwd_a", pool_main, image_bwd("a", stop_block=cut_a))
-                capture("wgrad_a", pool_side, wgrad("a"))
-                capture("image_bwd_b", pool_main, image_bwd("b", resume=True, stop_block=cut_b))
-                capture("wgrad_b", pool_side, wgrad("b"))
-                capture("image_bwd_c", pool_main, image_bwd("c", resume=True))
-                capture("wgrad_c", pool_main, wgrad("c"))
+                for i, sg in enumerate(segs):       # every segment's weight gradients but the last one's replay on the side stream
+                    capture("image_bwd_" + sg, pool_main, image_bwd(i))
+                    capture("wgrad_" + sg, pool_side if i < len(segs) - 1 else pool_main, wgrad(i))
                 capture("update", pool_main, update)
         except BaseException:
             rt.abort_capture()
@@ -213,6 +236,7 @@ class TrainStep:
         A = rt.arena
         self._regions = {k: A.region(k + ".") for k in ("text_encoder", "image_encoder", "loss")}
         self._g, self._graphs, self._keep, self._static_out = graphs["update"], graphs, keep, keep["result"]
+        self._segs = segs
 
     def _replay_direct(self):
         rt, G, ex = self.model.runtime, self._graphs, self.exchange
@@ -221,22 +245,28 @@ class TrainStep:
         G["image_fwd"].replay()
         with torch.cuda.stream(side):
             G["text_fwd"].replay()
+            G["heads_t1"].replay()                 # text half of the heads: hidden under the tail of the image forward
         main.wait_stream(side)
-        G["heads"].replay()
+        G["heads_m1"].replay()                     # image half forward, critic forward + backward
         side.wait_stream(main)
-        if ex is not None:
-            ex.reduce_span(*self._regions["loss"], after=main)
         with torch.cuda.stream(side):
-            G["text_bwd"].replay()
+            G["heads_t2"].replay()                 # text block backward ...
+            if ex is not None:
+                ev_t2 = torch.cuda.Event()
+                ev_t2.record(side)
+            G["text_bwd"].replay()                 # ... straight into BERT's backward
+        G["heads_m2"].replay()                     # image block backward, beside it
         if ex is not None:
+            main.wait_event(ev_t2)                 # the heads' gradients are final once both halves' backward ran
+            ex.reduce_span(*self._regions["loss"], after=main)
             ex.reduce_span(*self._regions["text_encoder"], after=side)          # ordered after BERT's backward only (the event is taken now)
-        for seg in ("a", "b"):                     # a stage's weight gradients go to the side stream as soon as its chain segment is enqueued
-            G["image_bwd_" + seg].replay()
+        for sg in self._segs[:-1]:                 # a segment's weight gradients go to the side stream as soon as its chain is enqueued
+            G["image_bwd_" + sg].replay()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                G["wgrad_" + seg].replay()
-        G["image_bwd_c"].replay()
-        G["wgrad_c"].replay()
+                G["wgrad_" + sg].replay()
+        G["image_bwd_" + self._segs[-1]].replay()
+        G["wgrad_" + self._segs[-1]].replay()
         if ex is not None:
             main.wait_stream(side)
             ex.reduce_span(*self._regions["image_encoder"], after=main)
