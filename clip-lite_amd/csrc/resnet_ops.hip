@@ -396,6 +396,193 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* dout, T* dx, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused stem: BN + ReLU + max-pool
+// The ResNet stem is conv7x7 -> BatchNorm -> ReLU -> maxpool3x3/2 (torchvision, reference encoder.py:36-38). Its post-BN activation a0 is the
+// largest tensor of the step (N x 112 x 112 x 64: 205 MB in bf16 at batch 128) and has exactly one consumer forward (the pool) and one
+// backward (the ReLU mask). These three kernels never materialise it, nor the un-pooled gradient da0:
+//   forward : pooled = maxpool(relu(bn(y0))) straight from y0                      (reads 205 MB, writes 51 + 26 MB; was 205 r + 205 w + 205 r + 77 w)
+//   backward: dz0 = maxpool_bwd(dpool)[pixel] * (bn(y0) > 0) is re-formed per input pixel from dpool / idx / y0, once for the two BatchNorm
+//             reductions and once for dy0                                          (282 + 487 MB instead of 282 + 615 + 820 MB)
+// Values are rounded to the storage type exactly where the unfused kernels stored them (a0 before the max, da0 before the mask), so the
+// results are bit-identical to bn_apply -> maxpool / maxpool_bwd -> bn_bwd_reduce -> bn_bwd_apply.
+template <typename T> DEV void round_store_type(float (&v)[8]) { if constexpr (sizeof(T) == 2) round8_bf16(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bn_pool_fwd_kernel(clite_bn p, const T* __restrict__ y, T* __restrict__ out, uint8_t* __restrict__ idx,
+                                                               int N, int H, int W, int Ho, int Wo, int rows_per_block) {
+  const int CPR = p.C / 8, RPS = 256 / CPR;
+  const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
+  BnCoef k;
+  float mean[8], var[8];
+  bn_coef(p.stats, p.replicas, p.rstride, p.gamma, p.beta, p.running_mean, p.running_var, p.training, p.centered, 1.0f / (float)p.M, p.eps, p.C, c0, k, mean, var);
+  if (blockIdx.x == 0 && r0 == 0 && p.training && p.update_running) {
+    float unb = p.M > 1 ? (float)p.M / (float)(p.M - 1) : 1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      p.running_mean[c0 + e] = (1.f - p.momentum) * p.running_mean[c0 + e] + p.momentum * mean[e];
+      p.running_var[c0 + e] = (1.f - p.momentum) * p.running_var[c0 + e] + p.momentum * var[e] * unb;
+    }
+  }
+  const int P = N * Ho * Wo;
+  int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
+  if (row_end > P) row_end = P;
+  for (int pix = row_begin + r0; pix < row_end; pix += RPS) {
+    const int wo = pix % Wo, ho = (pix / Wo) % Ho, n = pix / (Wo * Ho);
+    // all nine taps are requested before any is used (clamped address + validity flag instead of a branch around the load)
+    float tap[9][8];
+    bool ok[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s;
+        ok[r * 3 + s] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
+        load8(y + (((size_t)n * H + hc) * W + wc) * p.C + c0, tap[r * 3 + s]);
+      }
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf((tap[t][e] - mean[e]) * k.a[e] + k.b[e], 0.f);
+      round_store_type<T>(v);                      // a0 as bn_apply would have stored it
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ok[t] && (v[e] > best[e] || bi[e] < 0)) { best[e] = v[e]; bi[e] = t; }   // first maximum in scan order wins
+    }
+    store8(out + (size_t)pix * p.C + c0, best);
+    uint32_t lo = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+    uint32_t hi4 = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
+    *(u32x2*)(idx + (size_t)pix * p.C + c0) = u32x2{lo, hi4};
+  }
+}
+
+// dz0 of one input pixel (8 channels): the pooled gradients of the <= 4 windows whose argmax is this pixel, rounded to the storage type,
+// masked by relu'(bn(y0)); also returns y0 - mean
+template <typename T>
+DEV void stem_dz(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ y, int n, int hi, int wi, int H, int W, int Ho, int Wo,
+                 int C, int c0, const float (&mean)[8], const BnCoef& k, float (&dz)[8], float (&yc)[8]) {
+  // an input pixel lies in at most 2 x 2 pooling windows: odd coordinate -> taps 0 and 2 of windows (c+1)/2 and (c-1)/2, even -> tap 1 of
+  // window c/2. All candidates are requested before any is used (clamped address + validity flag); accumulation order r-major, s-minor as in
+  // maxpool_bwd.
+  int hoc[2], woc[2], rr[2], ss[2];
+  bool hv[2], wv[2];
+  if (hi & 1) { hoc[0] = (hi + 1) >> 1; rr[0] = 0; hv[0] = hoc[0] < Ho; hoc[1] = (hi - 1) >> 1; rr[1] = 2; hv[1] = true; }
+  else        { hoc[0] = hi >> 1;       rr[0] = 1; hv[0] = hoc[0] < Ho; hoc[1] = 0;             rr[1] = 0; hv[1] = false; }
+  if (wi & 1) { woc[0] = (wi + 1) >> 1; ss[0] = 0; wv[0] = woc[0] < Wo; woc[1] = (wi - 1) >> 1; ss[1] = 2; wv[1] = true; }
+  else        { woc[0] = wi >> 1;       ss[0] = 1; wv[0] = woc[0] < Wo; woc[1] = 0;             ss[1] = 0; wv[1] = false; }
+  float d[4][8];
+  u32x2 ib[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ho = hv[a] ? hoc[a] : 0, wo = wv[b] ? woc[b] : 0;
+      const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c0;
+      ib[a * 2 + b] = *(const u32x2*)(idx + o);
+      load8(dpool + o, d[a * 2 + b]);
+    }
+  float acc[8];
+  zero8(acc);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const uint32_t code = (uint32_t)(rr[a] * 3 + ss[b]);
+      const bool valid = hv[a] && wv[b];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t t = ((e < 4 ? ib[a * 2 + b][0] : ib[a * 2 + b][1]) >> (8 * (e & 3))) & 0xFFu;
+        if (valid && t == code) acc[e] += d[a * 2 + b][e];
+      }
+    }
+  round_store_type<T>(acc);                          // da0 as maxpool_bwd would have stored it
+  float yv[8], a[8];
+  load8(y + (((size_t)n * H + hi) * W + wi) * C + c0, yv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { yc[e] = yv[e] - mean[e]; a[e] = fmaxf(yc[e] * k.a[e] + k.b[e], 0.f); }
+  round_store_type<T>(a);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dz[e] = a[e] > 0.f ? acc[e] : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bn_pool_bwd_reduce_kernel(clite_bn p, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ y,
+                                                                      float* dstats, int N, int H, int W, int Ho, int Wo, int rows_per_block) {
+  __shared__ float red[256 * 16];
+  const int C = p.C, CPR = C / 8, RPS = 256 / CPR;
+  const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
+  BnCoef k;
+  float mean[8], var[8], s1[8], s2[8];
+  bn_coef(p.stats, p.replicas, p.rstride, p.gamma, p.beta, p.running_mean, p.running_var, 1, p.centered, 1.0f / (float)p.M, p.eps, C, c0, k, mean, var);
+  zero8(s1); zero8(s2);
+  const int Q = N * H * W;
+  int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
+  if (row_end > Q) row_end = Q;
+  for (int q = row_begin + r0; q < row_end; q += RPS) {
+    const int wi = q % W, hi = (q / W) % H, n = q / (W * H);
+    float dz[8], yc[8];
+    stem_dz(dpool, idx, y, n, hi, wi, H, W, Ho, Wo, C, c0, mean, k, dz, yc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] += dz[e]; s2[e] += dz[e] * yc[e]; }
+  }
+  float v[16];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { v[e] = s1[e]; v[8 + e] = s2[e]; }
+  const bool owner = chunk_fold<16>(v, CPR, red);
+  __syncthreads();
+  if (owner) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[c0 + e] = v[e]; red[C + c0 + e] = v[8 + e]; }
+  }
+  __syncthreads();
+  float* dst = dstats + (size_t)(blockIdx.x % p.replicas) * p.rstride;
+  for (int i = tid; i < 2 * C; i += 256) atomic_add_f32(dst + i, red[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bn_pool_bwd_apply_kernel(clite_bn p, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ y,
+                                                                     const float* dstats, T* __restrict__ dy, float* dgamma, float* dbeta,
+                                                                     int N, int H, int W, int Ho, int Wo, int rows_per_block) {
+  const int C = p.C, CPR = C / 8, RPS = 256 / CPR;
+  const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
+  const float inv_count = 1.0f / (float)p.M;
+  BnCoef k;
+  float mean[8], var[8], ka[8], kb[8], kc[8], S1[8], S2[8];
+  bn_coef(p.stats, p.replicas, p.rstride, p.gamma, p.beta, p.running_mean, p.running_var, 1, p.centered, inv_count, p.eps, C, c0, k, mean, var);
+  rsum8(dstats + c0, p.replicas, p.rstride, S1);
+  rsum8(dstats + C + c0, p.replicas, p.rstride, S2);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    const float rstd = rsqrtf(var[e] + p.eps);
+    const float G = rstd * S2[e];
+    const float a = p.gamma[c] * rstd;
+    ka[e] = a;
+    kc[e] = -a * rstd * G * inv_count;
+    kb[e] = -a * S1[e] * inv_count;
+    if (blockIdx.x == 0 && r0 == 0) {
+      if (dgamma) dgamma[c] += G;
+      if (dbeta) dbeta[c] += S1[e];
+    }
+  }
+  const int Q = N * H * W;
+  int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
+  if (row_end > Q) row_end = Q;
+  for (int q = row_begin + r0; q < row_end; q += RPS) {
+    const int wi = q % W, hi = (q / W) % H, n = q / (W * H);
+    float dz[8], yc[8];
+    stem_dz(dpool, idx, y, n, hi, wi, H, W, Ho, Wo, C, c0, mean, k, dz, yc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dz[e] = ka[e] * dz[e] + kb[e] + kc[e] * yc[e];
+    store8(dy + (size_t)q * C + c0, dz);
+  }
+}
+
 // image f32 NCHW [N][3][H][W] -> T [N][H+2*pad][Wp][4], zero padded (channel 3 = 0)
 template <typename T>
 __global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* img, T* out, int N, int H, int W, int pad, int Hp, int Wp) {
@@ -551,6 +738,35 @@ extern "C" int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t
   DISPATCH(dtype,
            hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dout, idx, (bf16*)dx, N, H, W, C, Ho, Wo),
            hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dout, idx, (float*)dx, N, H, W, C, Ho, Wo));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_stem_bn_pool_fwd(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, int N, int H, int W, void* stream) {
+  if (!p || !y || !pooled || !idx || N <= 0 || p->M != N * H * W || !bn_ok(p->M, p->C) || p->replicas < 1) return -1;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  int rpb;
+  int grid = bn_grid(N * Ho * Wo, p->C, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(stem_bn_pool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (bf16*)pooled, idx, N, H, W, Ho, Wo, rpb),
+           hipLaunchKernelGGL(stem_bn_pool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, *p, (const float*)y, (float*)pooled, idx, N, H, W, Ho, Wo, rpb));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_stem_bn_pool_bwd(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, float* dstats, void* dy,
+                                      float* dgamma, float* dbeta, int N, int H, int W, void* stream) {
+  if (!p || !dpool || !idx || !y || !dstats || !dy || N <= 0 || p->M != N * H * W || !bn_ok(p->M, p->C) || p->replicas < 1) return -1;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  int rpb_r, rpb_a;
+  const int grid_r = bn_grid_reduce(p->M, p->C, p->replicas, &rpb_r);
+  const int grid_a = bn_grid(p->M, p->C, &rpb_a);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(stem_bn_pool_bwd_reduce_kernel<bf16>, dim3(grid_r), dim3(256), 0, st, *p, (const bf16*)dpool, idx, (const bf16*)y, dstats, N, H, W, Ho, Wo, rpb_r),
+           hipLaunchKernelGGL(stem_bn_pool_bwd_reduce_kernel<float>, dim3(grid_r), dim3(256), 0, st, *p, (const float*)dpool, idx, (const float*)y, dstats, N, H, W, Ho, Wo, rpb_r));
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<bf16>, dim3(grid_a), dim3(256), 0, st, *p, (const bf16*)dpool, idx, (const bf16*)y, (const float*)dstats, (bf16*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a),
+           hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<float>, dim3(grid_a), dim3(256), 0, st, *p, (const float*)dpool, idx, (const float*)y, (const float*)dstats, (float*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a));
   return (int)hipGetLastError();
 }
 

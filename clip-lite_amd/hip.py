@@ -83,6 +83,8 @@ _SIGNATURES = {
     "clite_bn_bwd_apply": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V],
     "clite_maxpool3x3s2_fwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_maxpool3x3s2_bwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
+    "clite_stem_bn_pool_fwd": [_V, _I, _V, _V, _V, _I, _I, _I, _V],
+    "clite_stem_bn_pool_bwd": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V],
     "clite_avgpool_fwd": [_I, _V, _V, _I, _I, _I, _V],
     "clite_avgpool_bwd": [_I, _V, _V, _I, _I, _I, _V],
     "clite_image_to_nhwc4": [_I, _V, _V, _I, _I, _I, _I, _I, _I, _V],
@@ -414,6 +416,14 @@ def maxpool_fwd(dt, x, out, idx, N, H, W, Cc):
 
 def maxpool_bwd(dt, dout, idx, dx, N, H, W, Cc):
     check(lib().clite_maxpool3x3s2_bwd(dt, p(dout), p(idx), p(dx), N, H, W, Cc, stream_ptr(dout)), "maxpool_bwd")
+
+
+def stem_bn_pool_fwd(dt, bn, y, pooled, idx, N, H, W):
+    check(lib().clite_stem_bn_pool_fwd(C.byref(bn), dt, p(y), p(pooled), p(idx), N, H, W, stream_ptr(y)), "stem_bn_pool_fwd")
+
+
+def stem_bn_pool_bwd(dt, bn, dpool, idx, y, dstats, dy, dgamma, dbeta, N, H, W):
+    check(lib().clite_stem_bn_pool_bwd(C.byref(bn), dt, p(dpool), p(idx), p(y), p(dstats.t), p(dy), p(dgamma), p(dbeta), N, H, W, stream_ptr(y)), "stem_bn_pool_bwd")
 
 
 def avgpool_fwd(dt, x, out, N, HW, Cc):

@@ -160,13 +160,12 @@ def resnet_forward(rt, net, image, training):
     hip.stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, hip.epilogue(y0, 64, colsum=st0))
     if training and rt.precise_bn:
         hip.bn_centered_var(dt, y0, st0, N * Ho * Wo, 64)
-    a0 = _alloc(rt, N * Ho * Wo, 64)
-    hip.bn_apply(dt, _bn_desc(rt, net.bn1, N * Ho * Wo, st0, True, training), y0, None, a0)
+    # BatchNorm + ReLU + max-pool in one pass: the post-BN stem activation (the largest tensor of the step) is never stored
     Hq, Wq = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
     p0 = _alloc(rt, N * Hq * Wq, 64)
     idx = torch.empty(N * Hq * Wq, 64, device=rt.device, dtype=torch.uint8)
-    hip.maxpool_fwd(dt, a0, p0, idx, N, Ho, Wo, 64)
-    ctx["stem"] = (xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq)
+    hip.stem_bn_pool_fwd(dt, _bn_desc(rt, net.bn1, N * Ho * Wo, st0, True, training), y0, p0, idx, N, Ho, Wo)
+    ctx["stem"] = (xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq)
 
     x, Hc, Wc = p0, Hq, Wq
     recs = []
@@ -325,12 +324,15 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         assert own_group is None
         ctx["bwd_state"] = (dout, pre, stop_block - 1)
         return
-    xpad, Hp, Wp, Ho, Wo, y0, st0, a0, idx, Hq, Wq = ctx["stem"]
-    da0 = _alloc(rt, N * Ho * Wo, 64)
-    hip.maxpool_bwd(dt, dout, idx, da0, N, Ho, Wo, 64)
-    u0 = _Unit()
-    u0.y, u0.stats, u0.bn = y0, st0, net.bn1
-    dy0, _ = _bn_backward(rt, u0, da0, a0, N)
+    xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq = ctx["stem"]
+    # max-pool backward + ReLU mask + BatchNorm backward straight from (dpool, idx, y0): neither the un-pooled gradient nor the mask is stored
+    bn1 = net.bn1
+    dst0 = rt.new_stats(64)
+    dy0 = _alloc(rt, N * Ho * Wo, 64)
+    desc0 = hip.bn_desc(N * Ho * Wo, 64, st0, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, True, False, bn1.momentum, bn1.eps, False,
+                        centered=rt.precise_bn)
+    hip.stem_bn_pool_bwd(dt, desc0, dout, idx, y0, dst0, dy0, rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None,
+                         rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None, N, Ho, Wo)
     if net.conv1.weight.requires_grad:
         def stem_wgrad(dy0=dy0):
             dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)

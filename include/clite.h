@@ -203,6 +203,14 @@ int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const voi
 /* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem; idx holds the window position (0..8) of the first maximum. */
 int clite_maxpool3x3s2_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream);
+/* The stem's BatchNorm + ReLU + max-pool in one pass each way (torchvision ResNet conv1 -> bn1 -> relu -> maxpool, reference encoder.py:36-38):
+ * pooled / idx = clite_maxpool3x3s2_fwd(clite_bn_apply(y)) without the post-BN tensor ever being stored (p->M = N*H*W, p->relu ignored: ReLU is
+ * part of the stem; running statistics updated as in clite_bn_apply); and dy = clite_bn_bwd_apply(clite_bn_bwd_reduce(clite_maxpool3x3s2_bwd(dpool)
+ * masked by relu'(bn(y)))) with neither the un-pooled gradient nor the mask stored: dstats (replicated like p->stats, ZERO on entry) receives the
+ * two reductions, dgamma / dbeta (optional) +=. Bit-identical to the unfused sequence. */
+int clite_stem_bn_pool_fwd(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, int N, int H, int W, void* stream);
+int clite_stem_bn_pool_bwd(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, float* dstats, void* dy,
+                           float* dgamma, float* dbeta, int N, int H, int W, void* stream);
 /* nn.AdaptiveAvgPool2d((1,1)) + view (reference encoder.py:63-65): [N][HW][C] -> [N][C] */
 int clite_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream);
 int clite_avgpool_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, void* stream);

@@ -126,6 +126,54 @@ def test_pools_and_image(dtype):
     _close(cs, 1 + x.reshape(-1, Cc).sum(0), 1e-4)
 
 
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("N,H,W", [(2, 9, 8), (1, 12, 13)])
+def test_fused_stem_bn_pool_equals_unfused_sequence(dtype, N, H, W):
+    """clite_stem_bn_pool_fwd / _bwd must be BIT-identical to bn_apply -> maxpool and maxpool_bwd -> bn_bwd_reduce -> bn_bwd_apply."""
+    rng = np.random.default_rng(H)
+    Cc, M, R = 64, N * H * W, 3
+    # coarse values and a plain gamma so that post-BN ties (and exact zeros at the ReLU) occur
+    y, yb = prep(np.round(rng.standard_normal((M, Cc), dtype=np.float32) * 2) / 2, dtype)
+    gamma = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32); gamma[:8] = 1.0
+    beta = (0.1 * rng.standard_normal(Cc)).astype(np.float32); beta[:8] = 0.0
+    stats = np.zeros((R, 3, Cc), np.float32)
+    s = np.stack([y.sum(0), (y * y).sum(0)]).astype(np.float32)
+    stats[0, :2] = 0.25 * s; stats[1, :2] = 0.5 * s; stats[2, :2] = s - stats[0, :2] - stats[1, :2]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+
+    def desc(rm, rv, update):
+        return Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, update, 0.1, 1e-5, 1, R, 3 * Cc, 0, None, None, None, None, None)
+    rm_a, rv_a = np.zeros(Cc, np.float32), np.ones(Cc, np.float32)
+    rm_b, rv_b = np.zeros(Cc, np.float32), np.ones(Cc, np.float32)
+    L = lib()
+    a0 = outbuf((M, Cc), dtype)
+    assert L.clite_bn_apply(C.byref(desc(rm_a, rv_a, 1)), dtype, ptr(yb), None, ptr(a0), None) == 0
+    p_ref = outbuf((N * Ho * Wo, Cc), dtype); i_ref = np.zeros((N * Ho * Wo, Cc), np.uint8)
+    assert L.clite_maxpool3x3s2_fwd(dtype, ptr(a0), ptr(p_ref), ptr(i_ref), N, H, W, Cc, None) == 0
+    p_f = outbuf((N * Ho * Wo, Cc), dtype); i_f = np.full((N * Ho * Wo, Cc), 255, np.uint8)
+    assert L.clite_stem_bn_pool_fwd(C.byref(desc(rm_b, rv_b, 1)), dtype, ptr(yb), ptr(p_f), ptr(i_f), N, H, W, None) == 0
+    assert np.array_equal(np.asarray(p_f), np.asarray(p_ref))
+    assert np.array_equal(i_f, i_ref)
+    assert np.array_equal(rm_a, rm_b) and np.array_equal(rv_a, rv_b)
+    assert (val(p_ref, dtype) == 0).any()                 # the ReLU boundary is exercised
+
+    dpool, dpoolb = prep(rng.standard_normal((N * Ho * Wo, Cc), dtype=np.float32), dtype)
+    da0 = outbuf((M, Cc), dtype)
+    assert L.clite_maxpool3x3s2_bwd(dtype, ptr(dpoolb), ptr(i_ref), ptr(da0), N, H, W, Cc, None) == 0
+    ds_ref = np.zeros((R, 3, Cc), np.float32)
+    assert L.clite_bn_bwd_reduce(dtype, ptr(da0), ptr(a0), ptr(yb), ptr(stats), ptr(ds_ref), R, 3 * Cc, M, Cc, None) == 0
+    dy_ref = outbuf((M, Cc), dtype); dg_ref = np.ones(Cc, np.float32); db_ref = np.ones(Cc, np.float32)
+    d = desc(rm_a, rv_a, 0)
+    assert L.clite_bn_bwd_apply(C.byref(d), dtype, ptr(da0), ptr(a0), ptr(yb), ptr(ds_ref), ptr(dy_ref), None, ptr(dg_ref), ptr(db_ref), None) == 0
+    ds_f = np.zeros((R, 3, Cc), np.float32)
+    dy_f = outbuf((M, Cc), dtype); dg_f = np.ones(Cc, np.float32); db_f = np.ones(Cc, np.float32)
+    assert L.clite_stem_bn_pool_bwd(C.byref(d), dtype, ptr(dpoolb), ptr(i_f), ptr(yb), ptr(ds_f), ptr(dy_f), ptr(dg_f), ptr(db_f), N, H, W, None) == 0
+    _close(ds_f.sum(0), ds_ref.sum(0), 1e-5)              # same terms; the split over replicas / summation order may differ
+    _close(val(dy_f, dtype), val(dy_ref, dtype), 1e-2 if dtype == BF16 else 1e-5)
+    _close(dg_f, dg_ref, 1e-4); _close(db_f, db_ref, 1e-4)
+    assert L.clite_stem_bn_pool_fwd(C.byref(d), dtype, ptr(yb), ptr(p_f), ptr(i_f), N, H + 1, W, None) == -1     # p->M must be N*H*W
+
+
 def _ln_ref(x, g, b, eps):
     mean = x.mean(1, keepdims=True); var = x.var(1, keepdims=True)
     xh = (x - mean) / np.sqrt(var + eps)
