@@ -142,17 +142,33 @@ def _conv(rt, x, N, H, W, conv, training):
     return u
 
 
-def resnet_forward(rt, net, image, training):
-    """image: f32 NCHW [N][3][H][W] on the device. Returns (features [N][C] in compute dtype, ctx for backward)."""
+def stage_image(rt, image, out=None):
+    """f32 NCHW [N][3][H][W] on the device -> the stem's input form: zero-padded NHWC4 in the compute dtype (pad 3, row pitch rounded up).
+    `out` re-uses an earlier result's storage: the captured train step (train_loop.TrainStep) stages every batch into the one buffer its
+    graphs read, straight from the caller's tensor — the only per-step copy of the image."""
     N, _, H, W = image.shape
+    Hp, Wp = H + 6, W + 6 + 2
+    Wp += Wp % 2
+    xpad = _alloc(rt, N, Hp, Wp, 4) if out is None else out
+    assert tuple(xpad.shape) == (N, Hp, Wp, 4) and xpad.dtype == rt.tdtype
+    hip.image_to_nhwc4(rt.dt, image, xpad, N, H, W, 3, Hp, Wp)
+    return xpad
+
+
+def resnet_forward(rt, net, image, training, staged=None):
+    """image: f32 NCHW [N][3][H][W] on the device, or None with `staged` = (stage_image(...) result, H, W).
+    Returns (features [N][C] in compute dtype, ctx for backward)."""
     dt = rt.dt
+    if staged is None:
+        N, _, H, W = image.shape
+        xpad = stage_image(rt, image)
+    else:
+        xpad, H, W = staged
+        N = xpad.shape[0]
     ctx = {"N": N}
     # stem: 7x7/2 pad 3 on the pre-padded NHWC4 image
     Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    Hp, Wp = H + 6, W + 6 + 2
-    Wp += Wp % 2
-    xpad = _alloc(rt, N, Hp, Wp, 4)
-    hip.image_to_nhwc4(dt, image, xpad, N, H, W, 3, Hp, Wp)
+    Hp, Wp = xpad.shape[1], xpad.shape[2]
     wv = _alloc(rt, 64, 7, 8, 4)
     hip.stem_pack(dt, rt.arena.w32(net.conv1.weight), wv)
     y0 = _alloc(rt, N * Ho * Wo, 64)

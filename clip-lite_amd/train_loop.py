@@ -149,8 +149,15 @@ class TrainStep:
                 fn()
             graphs[name] = g
 
+        # the image is staged (NCHW f32 -> padded NHWC4, one kernel) OUTSIDE the graphs, straight from the caller's tensor into the buffer the
+        # captured stem reads: a replay then never copies the 77 MB batch into a static input first
+        from .resnet import stage_image
+        img0 = sb["image"].to(torch.float32).contiguous()
+        self._staged = (stage_image(rt, img0), img0.shape[2], img0.shape[3])
+        sb["image"] = torch.empty(img0.shape, dtype=sb["image"].dtype, device="meta")      # shape / dtype witness for _fits only
+
         def image_fwd():
-            keep["img"], keep["ctx_i"] = resnet_forward(rt, m.image_encoder.img_encoder, sb["image"].to(torch.float32).contiguous(), True)
+            keep["img"], keep["ctx_i"] = resnet_forward(rt, m.image_encoder.img_encoder, None, True, staged=self._staged)
             rt.bump_counters("image_encoder", 1)
 
         def text_fwd():
@@ -346,7 +353,10 @@ class TrainStep:
         for k, v in batch.items():
             if torch.is_tensor(v):
                 dst = self._static_batch[k]
-                if dst.shape == v.shape:
+                if dst.device.type == "meta":           # the image: staged by one kernel into the buffer the captured stem reads
+                    from .resnet import stage_image
+                    stage_image(rt, v.to(torch.float32).contiguous(), out=self._staged[0])
+                elif dst.shape == v.shape:
                     dst.copy_(v, non_blocking=True)
                 else:                                   # a batch whose longest caption is shorter than the captured length
                     dst.zero_()
