@@ -51,7 +51,15 @@ def main():
                 d = (f"group of {len(ms)} wgrads", sum(m[1] for m in ms), 1, 1, sum(m[4] for m in ms))
                 recs.append((name, d + (sum(2.0 * m[1] * m[2] * m[3] for m in ms),), e0, e1))
             else:
-                recs.append((name, bench.describe_launch(name, a, 4 if args.f32 else 2) + (None,), e0, e1))
+                d = bench.describe_launch(name, a, 4 if args.f32 else 2)
+                # + the fused epilogue's own operands (ReLU-mask source, BatchNorm input, residual: one M x N read each; saved pre-activation:
+                # one write), which SURVEY §8(d)'s per-launch figure leaves out but which bound the HBM-limited launches
+                extra = 0
+                for x in a:
+                    ep = getattr(x, "_obj", None)
+                    if isinstance(ep, hip.Epilogue):
+                        extra = sum(1 for f in ("dact_aux", "bn_y", "residual", "preact") if getattr(ep, f)) * d[1] * d[2] * (4 if args.f32 else 2)
+                recs.append((name, d[:4] + (d[4] + extra, None), e0, e1))
             return rc
         return timed
     wrapped = {n: wrap(n) for n in names}
@@ -73,12 +81,15 @@ def main():
     for (name, (lab, M, N, K, nbytes, flops)), ts in agg.items():
         n = len(ts) // REP
         us = sum(ts) / len(ts) * 1e3
-        rows.append((name[6:], lab, M, N, K, n, us, (flops if flops is not None else 2.0 * M * N * K) / us / 1e6, nbytes / us / 1e3))
+        fl = flops if flops is not None else 2.0 * M * N * K
+        # "ideal": the larger of the traffic at 5.5 TB/s (what the BatchNorm streaming kernels reach) and the MACs at 1.6 PFLOP/s (65 % of the dense peak)
+        ideal = max(nbytes / 5.5e12, fl / 1.6e15) * 1e6
+        rows.append((name[6:], lab, M, N, K, n, us, fl / us / 1e6, nbytes / us / 1e3, ideal))
     tot = sum(r[5] * r[6] for r in rows)
-    print(f"{'op':12s} {'layer':28s} {'M':>8s} {'N':>6s} {'K':>8s} {'n':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s} {'%':>5s}")
-    for r in sorted(rows, key=lambda r: -r[5] * r[6]):
-        print(f"{r[0]:12s} {r[1]:28s} {r[2]:8d} {r[3]:6d} {r[4]:8d} {r[5]:3d} {r[6]:8.1f} {r[7]:7.1f} {r[8]:7.0f} {100 * r[5] * r[6] / tot:5.1f}")
-    print(f"total igemm time per step: {tot / 1e3:.3f} ms over {sum(r[5] for r in rows)} launches")
+    print(f"{'op':12s} {'layer':28s} {'M':>8s} {'N':>6s} {'K':>8s} {'n':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s} {'%':>5s} {'ideal us':>8s} {'lost us/step':>12s}")
+    for r in sorted(rows, key=lambda r: -r[5] * (r[6] - r[9])):
+        print(f"{r[0]:12s} {r[1]:28s} {r[2]:8d} {r[3]:6d} {r[4]:8d} {r[5]:3d} {r[6]:8.1f} {r[7]:7.1f} {r[8]:7.0f} {100 * r[5] * r[6] / tot:5.1f} {r[9]:8.1f} {r[5] * (r[6] - r[9]):12.1f}")
+    print(f"total igemm time per step: {tot / 1e3:.3f} ms over {sum(r[5] for r in rows)} launches; ideal {sum(r[5] * r[9] for r in rows) / 1e3:.3f} ms")
     by = collections.defaultdict(float)
     for r in rows:
         by[r[0]] += r[5] * r[6]
