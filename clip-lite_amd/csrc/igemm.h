@@ -598,7 +598,10 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
   //    no faster — 1024 -> 256 1x1 dgrad 80.7 vs 82.5 us, 256 -> 64 191 vs 217;
   //  * staging one wave row at a time (34 KB, under the operand ring) + __launch_bounds__(256, 3) for three workgroups per CU: the
   //    allocator then spills 20 registers and the launches get slower — 256 -> 64 191 -> 267 us, 64 -> 256 97 -> 116, step 18.7 -> 19.2 ms.
-  constexpr int AHEAD = 2;
+#ifndef CLITE_BN_AHEAD
+#define CLITE_BN_AHEAD 2
+#endif
+  constexpr int AHEAD = CLITE_BN_AHEAD;
   Raw8<T> pa[ROWS_PT], py[ROWS_PT], pr[ROWS_PT];
   uint32_t gix[ROWS_PT];
   bool okr[ROWS_PT];
@@ -615,6 +618,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
 #pragma unroll
   for (int q = 0; q < AHEAD && q < ROWS_PT; ++q) request(q);
   lds_barrier();
+  EPI_STAMP(6);
 #pragma unroll
   for (int q = 0; q < ROWS_PT; ++q) {
     if (q + AHEAD < ROWS_PT) request(q + AHEAD);
@@ -662,6 +666,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
     }
   }
   lds_barrier();
+  EPI_STAMP(7);
   if (ep.colsum) {
     float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
     float* red = (float*)smem;                      // [RPSE][CPRE*16]

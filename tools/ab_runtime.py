@@ -1,0 +1,51 @@
+"""A/B timing of executor switches on the captured train step: python tools/ab_runtime.py [attr=value ...] [--steps 50]
+Each `attr=value` sets an attribute of the model's DeviceRuntime (fuse_bn_backward, s2_classes, group_wgrad, overlap_wgrad ...) before the
+step is captured; prints ms/step (HIP events around `steps` replays). The baseline is the same command without arguments."""
+import argparse
+import contextlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("sets", nargs="*")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--visual", default="resnet50")
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--f32", action="store_true")
+    ap.add_argument("--loss", default="jsd")
+    args = ap.parse_args()
+    from clip_lite_amd.train_loop import TrainStep
+    from clip_lite_amd.utils.common import GradScaler
+    device = torch.device("cuda", 0)
+    with contextlib.redirect_stdout(sys.stderr):
+        model, opt, sched = bench.build(args, device)
+    rt = model.runtime
+    for s in args.sets:
+        k, v = s.split("=")
+        old = getattr(rt, k)
+        setattr(rt, k, type(old)(int(v)) if isinstance(old, (bool, int)) else type(old)(v))
+    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, None, graph=True)
+    batches = bench.synthetic_batches(args, device, 0)
+    for i in range(6):
+        step(batches[i % 2])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(args.steps):
+        step(batches[i % 2])
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{' '.join(args.sets) or 'defaults':40s} {e0.elapsed_time(e1) / args.steps:8.3f} ms/step")
+
+
+if __name__ == "__main__":
+    main()

@@ -19,8 +19,19 @@ if kind.startswith("conv"):
     y = torch.empty(N, cv.Ho, cv.Wo, K, device="cuda", dtype=torch.bfloat16)
     dx = torch.empty_like(x)
     cs = hip.Stats(torch.zeros(8 * 3 * K, device="cuda"), 8, K)
+    # conv_dgrad_bn: the ResNet backward's fused form (ReLU mask + residual + the two BatchNorm-backward reductions in the epilogue)
+    prev_out = torch.randn(N, H, W, Cc, device="cuda").bfloat16()
+    prev_y = torch.randn(N, H, W, Cc, device="cuda").bfloat16()
+    res = torch.randn(N, H, W, Cc, device="cuda").bfloat16()
+    pst = hip.Stats(torch.zeros(8 * 3 * Cc, device="cuda"), 8, Cc)
+    dst = hip.Stats(torch.zeros(8 * 3 * Cc, device="cuda"), 8, Cc)
     fn = {"conv_fwd": lambda: hip.conv_fwd(x, w, cv, hip.epilogue(y, K, colsum=cs)),
-          "conv_dgrad": lambda: hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc))}[kind]
+          "conv_dgrad": lambda: hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc)),
+          "conv_dgrad_bn": lambda: hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc, dact_aux=prev_out, dact=hip.DACT_RELU, colsum=dst,
+                                                                           bn=(prev_y.view(-1, Cc), pst, N * H * W))),
+          "conv_dgrad_bnres": lambda: hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc, residual=res, dact_aux=prev_out, dact=hip.DACT_RELU,
+                                                                              mask_after_residual=True, colsum=dst,
+                                                                              bn=(prev_y.view(-1, Cc), pst, N * H * W)))}[kind]
 else:
     M, N, K = a
     k = kind[-2:]
