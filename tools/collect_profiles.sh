@@ -1,8 +1,18 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r2p && \
-python bench.py > gpurun_out/r2p/bench.json 2> gpurun_out/r2p/bench.err && \
-python tools/diag_launch.py > gpurun_out/r2p/timeline.txt 2>&1 && \
-rocprofv3 --kernel-trace -d gpurun_out/r2p/kt -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r2p/kt.log 2>&1 && \
-python tools/rocpd_stats.py gpurun_out/r2p/kt/kt_results.db gpurun_out/r2p/kernel_stats.csv && \
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/r2p/pmc_f -o f -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > gpurun_out/r2p/pmc_f.log 2>&1 && \
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/r2p/pmc_w -o w -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > gpurun_out/r2p/pmc_w.log 2>&1 && \
-python tools/pmc_traffic.py gpurun_out/r2p/pmc_f/f_results.db gpurun_out/r2p/pmc_w/w_results.db gpurun_out/r2p/r2_hbm_traffic.json && rm -rf gpurun_out/r2p/pmc_f gpurun_out/r2p/pmc_w gpurun_out/r2p/kt
+#!/bin/bash
+# One gpurun call that regenerates what profiles/r2_* is made from (run from the repository root on the GPU box):
+#   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh'   then   cp gpurun_out/r2p/* profiles/   (names below)
+# PMC passes are separate runs with --kernel-trace only (one counter each), as MI355X_MICROARCH.md prescribes.
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r2p
+mkdir -p $O
+python bench.py > $O/r2_bench.json 2> $O/bench.err
+python tools/diag_launch.py > $O/r2_timeline.txt 2>&1
+python tools/layer_profile.py > $O/r2_layers.txt 2> $O/layers.err
+rocprofv3 --kernel-trace -d $O/kt -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/kt.log 2>&1
+python tools/rocpd_stats.py $O/kt/kt_results.db $O/r2_kernel_stats.csv
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o f -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o w -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_w.log 2>&1
+python tools/pmc_traffic.py $O/pmc_f/f_results.db $O/pmc_w/w_results.db $O/r2_hbm_traffic.json
+python tools/pmc_by_kernel.py $O/pmc_f/f_results.db $O/pmc_w/w_results.db 60 > $O/r2_pmc_by_kernel.txt
+rm -rf $O/pmc_f $O/pmc_w $O/kt
