@@ -242,6 +242,12 @@ class TrainStep:
             rt.exchange = saved_exchange      # eager steps (a batch of another shape, eval) keep the overlapped exchange
         A = rt.arena
         self._regions = {k: A.region(k + ".") for k in ("text_encoder", "image_encoder", "loss")}
+        # data parallel: the image encoder's gradients are exchanged per chain segment — stages 4 + 3 hold 22 M of its 23.5 M parameters and
+        # are final 4 ms before the step ends (after the first weight-gradient group), so only stage 1 + stem (0.2 M) is exchanged exposed
+        pre = "image_encoder.img_encoder."
+        l2, l3, l4, img = A.region(pre + "layer2."), A.region(pre + "layer3."), A.region(pre + "layer4."), self._regions["image_encoder"]
+        assert img[0] <= l2[0] <= l2[1] <= l3[0] <= l3[1] <= l4[0] <= l4[1] <= img[1]
+        self._seg_spans = [(l3[0], img[1]), (l2[0], l3[0]), (img[0], l2[0])]          # s0 = [layer4, layer3], s1 = layer2, s2 = layer1 + stem
         self._g, self._graphs, self._keep, self._static_out = graphs["update"], graphs, keep, keep["result"]
         self._segs = segs
 
@@ -267,16 +273,18 @@ class TrainStep:
             main.wait_event(ev_t2)                 # the heads' gradients are final once both halves' backward ran
             ex.reduce_span(*self._regions["loss"], after=main)
             ex.reduce_span(*self._regions["text_encoder"], after=side)          # ordered after BERT's backward only (the event is taken now)
-        for sg in self._segs[:-1]:                 # a segment's weight gradients go to the side stream as soon as its chain is enqueued
+        for i, sg in enumerate(self._segs[:-1]):   # a segment's weight gradients go to the side stream as soon as its chain is enqueued
             G["image_bwd_" + sg].replay()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 G["wgrad_" + sg].replay()
+            if ex is not None:                     # BatchNorm gradients came with the chain (main), weight gradients with the group (side, which waited for main)
+                ex.reduce_span(*self._seg_spans[i], after=side)
         G["image_bwd_" + self._segs[-1]].replay()
         G["wgrad_" + self._segs[-1]].replay()
         if ex is not None:
+            ex.reduce_span(*self._seg_spans[-1], after=main)
             main.wait_stream(side)
-            ex.reduce_span(*self._regions["image_encoder"], after=main)
             covered = sorted(self._regions.values())
             pos = 0
             for lo, hi in covered:                 # anything outside the three top-level modules (nothing, for VLInfoModel)
