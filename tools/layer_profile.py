@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--f32", action="store_true")
     ap.add_argument("--loss", default="jsd", choices=["jsd", "infonce"])
+    ap.add_argument("--back-to-back", action="store_true", help="issue every launch twice and time the second (profiling only: accumulating outputs double)")
     args = ap.parse_args()
     from clip_lite_amd import hip
     from clip_lite_amd.train_loop import TrainStep
@@ -43,6 +44,8 @@ def main():
 
         def timed(*a):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if args.back_to_back:       # the same launch once more right in front of the timed one: no idle gap, warm caches (upper bound of what host gaps cost)
+                fn(*a)
             e0.record()
             rc = fn(*a)
             e1.record()

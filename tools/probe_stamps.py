@@ -33,12 +33,27 @@ if kind.startswith("conv"):
                                                                               mask_after_residual=True, colsum=dst,
                                                                               bn=(prev_y.view(-1, Cc), pst, N * H * W)))}[kind]
 else:
-    M, N, K = a
-    k = kind[-2:]
+    M, N, K = a[:3]
+    k = kind.partition(":")[0][-2:]
     A = torch.randn(M, K, device="cuda").bfloat16()
     B = torch.randn(N, K, device="cuda").bfloat16() if k == "nt" else torch.randn(K, N, device="cuda").bfloat16()
     out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-    ep = hip.epilogue(out, N)
+    # epilogue form after the layout: gemm_nt, gemm_nt:gelu (bias + GELU + pre-activation store), gemm_nt:bdr (bias + dropout + residual),
+    # gemm_nn:dgelu (x GELU'(pre-activation)), gemm_nn:res (+ residual)
+    kind, _, form = kind.partition(":")
+    k = kind[-2:]
+    bias = torch.randn(N, device="cuda")
+    pre = torch.randn(M, N, device="cuda").bfloat16()
+    res = torch.randn(M, N, device="cuda").bfloat16()
+    ep = {"": lambda: hip.epilogue(out, N),
+          "bias": lambda: hip.epilogue(out, N, bias=bias),
+          "gelu": lambda: hip.epilogue(out, N, bias=bias, act=hip.ACT_GELU, preact=pre),
+          "bdr": lambda: hip.epilogue(out, N, bias=bias, drop=(0.1, 1234, 7), residual=res),
+          "dgelu": lambda: hip.epilogue(out, N, dact_aux=pre, dact=hip.DACT_GELU),
+          "res": lambda: hip.epilogue(out, N, residual=res)}[form]()
+    if len(sys.argv) > 5:
+        hip.set_tile_policy(int(sys.argv[5]))
+        a = a[:3]
     f = getattr(hip, kind)
     fn = lambda: f(hip.BF16, A, B, M, N, K, ep)
 os.environ.setdefault("CLITE_IGEMM_G2", "0")
