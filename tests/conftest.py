@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "policy_independent: wave-simulator case that does not depend on the GEMM tile policy (runs once)")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -18,6 +18,8 @@ def tile_policy(request):
     dtype = request.node.callspec.params.get("dtype", BF16) if hasattr(request.node, "callspec") else BF16
     if dtype == F32 and request.param != 1:
         pytest.skip("f32 launches do not depend on the tile policy")
+    if request.node.get_closest_marker("policy_independent") and request.param != 1:
+        pytest.skip("this launch does not depend on the tile policy")
     assert lib().clite_set_tile_policy(request.param) == 0
     yield request.param
     lib().clite_set_tile_policy(0)
@@ -273,6 +275,7 @@ def test_stem_conv7x7(dtype):
     _close(dw, 1 + conv_wgrad_ref(dy, imgr.transpose(0, 2, 3, 1), w.shape, 2, 3))
 
 
+@pytest.mark.policy_independent
 def test_grouped_weight_gradients():
     """clite_wgrad_group: conv weight gradients of all three tile families (<= 64 output channels, <= 64 (r, s, ci) columns, general) and a
     linear weight gradient with a strided operand, as ONE grouped launch set, accumulate (+=) the same values as the per-member entry points
