@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       } else if (ep.act == CLITE_ACT_GELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
       } else if (ep.act == CLITE_ACT_TANH) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         float a[8];
         load8((const T*)ep.dact_aux + o, a);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= ep.dact == 1 ? (a[e] > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_f(a[e]) : (1.f - a[e] * a[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= ep.dact == 1 ? (a[e] > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_t<T>(a[e]) : (1.f - a[e] * a[e]);
       }
       if (ep.residual) {
         float rv[8];

@@ -272,7 +272,7 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
           for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         } else if (ep.act == ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
         } else if (ep.act == ACT_TANH) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
@@ -287,7 +287,7 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float a = av[e];
-          dfac[e] = (EPI == 1 || ep.dact == 1) ? (a > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_f(a) : (1.f - a * a);
+          dfac[e] = (EPI == 1 || ep.dact == 1) ? (a > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_t<T>(a) : (1.f - a * a);
         }
         if (EPI == 0 || !ep.mask_after_residual) {
 #pragma unroll

@@ -366,6 +366,7 @@ inline float atomicAdd(float* p, float v) {
 inline uint32_t umulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __expf(float x) { return expf(x); }
+inline float __frcp_rn(float x) { return 1.0f / x; }
 inline float __logf(float x) { return logf(x); }
 
 #endif  // CLITE_WAVESIM_H
