@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="logic test only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--host-input", action="store_true", help="batches start in pinned host memory and cross PCIe every step through the train loop's "
                     "copy-stream prefetcher (utils/common.cycle): the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "mesh"], help="gradient exchange: RCCL all-reduce per region (default), or the "
+                    "direct mesh form for a fully connected xGMI node: all-to-all, local sum, all-gather (utils/distributed.py)")
     ap.add_argument("--force-exchange", action="store_true", help="run the gradient exchange (process group, RCCL all-reduces between the graphs) even with "
                     "one rank: exercises the data-parallel launch path on a one-GPU box (launch under torch.distributed.run)")
     args = ap.parse_args()
@@ -262,7 +264,7 @@ def main():
     model.runtime.fp8 = bool(args.fp8)
     exchange = None
     if dist_on:
-        exchange = cdist.GradientExchange(model.runtime.arena)
+        exchange = cdist.GradientExchange(model.runtime.arena, algorithm=args.exchange)
         model.runtime.exchange = exchange
     step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange, graph=not args.no_graph)
     eager_step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange)      # per-launch timing needs eager launches

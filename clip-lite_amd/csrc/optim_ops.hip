@@ -94,7 +94,36 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16* 
     for (size_t i = n8 * 8; i < n; ++i) dst[i] = f2bf(src[i]);
 }
 
+// dst[i] = src[i] + src[stride + i] + ... + src[(slices - 1) * stride + i], summed in slice order (every rank of a data-parallel job reduces
+// ITS chunk of the gradient arena this way, so the order is fixed by construction)
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ src, int slices, size_t stride, size_t n, float* __restrict__ dst) {
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 a = *(const f32x4*)(src + i * 4);
+    for (int s = 1; s < slices; ++s) {
+      const f32x4 b = *(const f32x4*)(src + (size_t)s * stride + i * 4);
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    *(f32x4*)(dst + i * 4) = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    float a = src[i];
+    for (int s = 1; s < slices; ++s) a += src[(size_t)s * stride + i];
+    dst[i] = a;
+  }
+}
+
 }  // namespace
+
+extern "C" int clite_sum_slices(const float* src, int slices, uint64_t stride, uint64_t n, float* dst, void* stream) {
+  if (!src || !dst || slices < 1 || stride % 4 || ((uintptr_t)src | (uintptr_t)dst) % 16) return -1;
+  if (n == 0) return 0;
+  size_t g = (n / 4 + 255) / 256;
+  int grid = (int)(g < 2048 ? (g ? g : 1) : 2048);
+  hipLaunchKernelGGL(sum_slices_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, slices, (size_t)stride, (size_t)n, dst);
+  return (int)hipGetLastError();
+}
 
 extern "C" int clite_sumsq(const float* x, uint64_t n, float* out, float* partials, int n_partials, void* stream) {
   if (!x || !out || !partials || n_partials < 1) return -1;

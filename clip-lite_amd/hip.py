@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -108,6 +108,7 @@ _SIGNATURES = {
     "clite_add": [_I, _V, _V, _V, _U64, _V],
     "clite_uniform_fill": [_I, _V, _U64, _U64, _U32, _V],
     "clite_sumsq": [_V, _U64, _V, _V, _I, _V],
+    "clite_sum_slices": [_V, _I, _U64, _U64, _V, _V],
     "clite_sgd_step": [_V, _V, _V, _V, _V, _V, _I, _V, _V, _V],
     "clite_cast_bf16": [_V, _V, _U64, _V],
 }
@@ -525,6 +526,10 @@ def uniform_fill(dt, out, n, seed, site):
 
 def sumsq(x, n, out, partials):
     check(lib().clite_sumsq(p(x), n, p(out), p(partials), partials.numel(), stream_ptr(x)), "sumsq")
+
+
+def sum_slices(src, slices, stride, n, dst):
+    check(lib().clite_sum_slices(p(src), slices, stride, n, p(dst), stream_ptr(src)), "sum_slices")
 
 
 def sgd_step(pf, gf, vf, slow, cast, items_ptr, n_items, hp, ss):

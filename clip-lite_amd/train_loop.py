@@ -28,6 +28,8 @@ def build_parser():
     group = parser.add_argument_group("MI355X launch path (not in the reference)")
     group.add_argument("--allow-eager-fallback", action="store_true", help="If the hipGraph capture of the step fails, log an error and continue with "
                        "eager launches instead of stopping.")
+    group.add_argument("--grad-exchange", default="allreduce", choices=["allreduce", "mesh"], help="Gradient mean over ranks: one RCCL all-reduce per "
+                       "region, or the direct mesh form (all-to-all, local sum, all-gather) for a fully connected xGMI node.")
     group.add_argument("--no-hip-graph", action="store_true", help="Launch every kernel of the step from Python instead of replaying the "
                        "captured hipGraphs of the step (TrainStep graph mode; batches of another shape always take the eager path).")
     return parser
@@ -440,7 +442,7 @@ def main(_A: argparse.Namespace):
     exchange = None
     if dist.get_world_size() > 1:
         dist.synchronize()
-        exchange = dist.GradientExchange(model.runtime.arena)
+        exchange = dist.GradientExchange(model.runtime.arena, algorithm=getattr(_A, "grad_exchange", "allreduce"))
         model.runtime.exchange = exchange
 
     timer = Timer(start_from=start_iteration + 1, total_iterations=_C.OPTIM.NUM_ITERATIONS)

@@ -106,9 +106,16 @@ class GradientExchange:
     are coalesced into buckets of at least `bucket_elems` and all-reduced (SUM) asynchronously. `finish()` makes the compute
     stream wait for the exchange and sets the optimizer's gradient pre-scale to 1/world_size."""
 
-    def __init__(self, arena, bucket_elems: int = 16 * 1024 * 1024, group=None):
-        self.arena, self.bucket_elems, self.group = arena, bucket_elems, group
+    def __init__(self, arena, bucket_elems: int = 16 * 1024 * 1024, group=None, algorithm: str = "allreduce"):
+        """algorithm: "allreduce" — one RCCL all-reduce (SUM) per region (RCCL's rings / trees over the xGMI links); "mesh" — the
+        direct form for a fully connected node: all-to-all (rank w receives chunk w of every rank's region: all 7 links of a GPU carry
+        1/8 of the region at once), a local fixed-order sum (clite_sum_slices), all-gather of the reduced chunks. Per link the mesh form
+        moves 2 x region / world instead of a ring's 2 x (world - 1) / world x region over one link direction."""
+        assert algorithm in ("allreduce", "mesh")
+        self.arena, self.bucket_elems, self.group, self.algorithm = arena, bucket_elems, group, algorithm
         self.world = get_world_size()
+        self.rank = get_rank()
+        self._scratch = {}
         self.on_gpu = arena.flat_g.is_cuda
         self.stream = torch.cuda.Stream() if self.on_gpu else None
         self._pending = []      # [lo, hi) regions not yet sent
@@ -116,14 +123,52 @@ class GradientExchange:
         self._covered = []     # [lo, hi) regions already handed to RCCL this step
         self.defer = False     # True: ignore region_ready (modules run several times per step); finish() reduces the whole arena
 
+    def _buffer(self, name, n, like):
+        t = self._scratch.get(name)
+        if t is None or t.numel() < n:
+            t = self._scratch[name] = torch.empty(n, dtype=like.dtype, device=like.device)
+        return t
+
+    def _mesh_sum(self, buf):
+        """buf (a slice of flat_g) <- sum over ranks, by all-to-all / local sum / all-gather. Enqueued on the current stream (RCCL) or run
+        blocking (gloo: the CPU tests)."""
+        W, r, n = self.world, self.rank, buf.numel()
+        chunk = ((n + W - 1) // W + 63) // 64 * 64                       # 256-byte chunks; only the tail chunks are short or empty
+        sizes = [max(0, min(chunk, n - w * chunk)) for w in range(W)]
+        mine = sizes[r]
+        recv = self._buffer("recv", W * chunk, buf)[:W * chunk]
+        dist.all_to_all_single(recv[:W * mine], buf, output_split_sizes=[mine] * W, input_split_sizes=sizes, group=self.group)
+        red = self._buffer("red", chunk, buf)[:chunk]
+        if mine:
+            if self.on_gpu:
+                from .. import hip
+                hip.sum_slices(recv, W, mine, mine, red)
+            else:
+                torch.sum(recv[:W * mine].view(W, mine), dim=0, out=red[:mine])
+        if n == W * chunk:
+            dist.all_gather_into_tensor(buf, red, group=self.group)
+        else:
+            full = self._buffer("full", W * chunk, buf)[:W * chunk]
+            dist.all_gather_into_tensor(full, red, group=self.group)
+            buf.copy_(full[:n])               # chunk w sits at w * chunk in both layouts; only the tail is padding
+
+    def _sum(self, buf):
+        """Start the sum over ranks of `buf` on the current stream; returns a work handle or None."""
+        if self.algorithm == "mesh":
+            self._mesh_sum(buf)
+            return None
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _send(self, lo, hi):
         buf = self.arena.flat_g[lo:hi]
         if self.on_gpu:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                w = self._sum(buf)
         else:
-            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            w = self._sum(buf)
+        if w is not None:
+            self._works.append(w)
         self._covered.append((lo, hi))
 
     def region_ready(self, lo, hi):
@@ -149,9 +194,11 @@ class GradientExchange:
         if self.on_gpu:
             self.stream.wait_stream(after if after is not None else torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                w = self._sum(buf)
         else:
-            self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            w = self._sum(buf)
+        if w is not None:
+            self._works.append(w)
 
     def wait(self):
         for w in self._works:
@@ -168,7 +215,9 @@ class GradientExchange:
             return
         total = self.arena.total
         for lo in range(0, total, chunk_elems):
-            dist.all_reduce(self.arena.flat_g[lo:min(total, lo + chunk_elems)], op=dist.ReduceOp.SUM, group=self.group)
+            w = self._sum(self.arena.flat_g[lo:min(total, lo + chunk_elems)])
+            if w is not None:
+                w.wait()
 
     def finish(self):
         """Flush pending regions, then exchange every part of the arena that was never reported, so each element is reduced

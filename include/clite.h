@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 6
+#define CLITE_ABI_VERSION 7
 int clite_abi_version(void);
 
 /* Deterministic-reduction mode (process-wide, default off; the counterpart of torch.use_deterministic_algorithms for this library).
@@ -303,6 +303,10 @@ typedef struct clite_optim_item {   /* one workgroup's slice of one parameter te
  * (device f32[n_partials], n_partials >= 1; 1024 slots use the whole chip): no float atomics, so the value is a pure function of x and every
  * data-parallel rank derives the same clip factor from the same all-reduced gradients (replicas stay bit-identical). */
 int clite_sumsq(const float* x, uint64_t n, float* out, float* partials, int n_partials, void* stream);
+/* dst[i] = sum over s < slices of src[s * stride + i], i < n, in slice order (stride % 4 == 0, 16-byte aligned pointers). The local step of the
+ * mesh gradient exchange that replaces DDP's ring all-reduce (reference train.py:174-178): after an all-to-all every rank holds its chunk of
+ * the gradients from all `slices` = world_size ranks and sums them before the all-gather. */
+int clite_sum_slices(const float* src, int slices, uint64_t stride, uint64_t n, float* dst, void* stream);
 /* hp (device f32[6]): lr multiplier, momentum, max grad norm (<=0 off), lookahead-sync flag, lookahead alpha, grad pre-scale.
  * g' = g*prescale*clip + wd*p; v = mu*v + g'; p -= lr*mult*v; on sync steps p = alpha*p + (1-alpha)*slow, slow = p.
  * g is zeroed; cast_bf16 (optional) receives the bf16 copy of p at the same offsets. */

@@ -70,6 +70,49 @@ def test_gradient_exchange_world2_gloo(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def _mesh_worker(rank, world, port, tmp):
+    """The mesh form of the exchange (all-to-all, local sum, all-gather) must give what the all-reduce gives — on spans that do not divide
+    by the world size, on a span shorter than one chunk per rank (some ranks own nothing), through region_ready / reduce_span / reduce_all."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from clip_lite_amd.runtime import Arena
+    from clip_lite_amd.utils import distributed as D
+    net = torch.nn.Sequential(torch.nn.Linear(37, 19), torch.nn.Conv2d(3, 8, 3), torch.nn.Linear(5, 301))
+    arena = Arena(net.named_parameters(), torch.device("cpu"), lowp=False)
+    g = torch.Generator().manual_seed(70 + rank)
+    mine = torch.randn(arena.total, generator=g)
+    allg = [torch.empty_like(mine) for _ in range(world)]
+    tdist.all_gather(allg, mine)
+    want = sum(allg)
+    ex = D.GradientExchange(arena, bucket_elems=128, algorithm="mesh")
+    arena.flat_g.copy_(mine)
+    for hi, lo in zip([arena.total, arena.total - 101, 701, 299], [arena.total - 101, 701, 299, 0]):
+        ex.region_ready(lo, hi)
+    assert ex.finish() == 1.0 / world
+    assert torch.allclose(arena.flat_g, want, atol=1e-5), (arena.flat_g - want).abs().max()
+    arena.flat_g.copy_(mine)
+    ex.reduce_span(0, 100)                 # shorter than world x 64: the last ranks own no chunk of it
+    ex.reduce_span(100, 1000)
+    ex.reduce_span(1000, arena.total)
+    ex.wait()
+    assert torch.allclose(arena.flat_g, want, atol=1e-5)
+    arena.flat_g.copy_(mine)
+    ex.reduce_all(chunk_elems=777)
+    assert torch.allclose(arena.flat_g, want, atol=1e-5)
+    every = [torch.empty_like(mine) for _ in range(world)]
+    tdist.all_gather(every, arena.flat_g)
+    assert all(torch.equal(every[0], e) for e in every), "ranks hold different sums after the mesh exchange"
+    tdist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_mesh_exchange_equals_allreduce_world3_gloo(tmp_path):
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_mesh_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(3))
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # Two-rank data-parallel TRAIN STEPS, end to end on the product's own update path (reference train.py:174-178,211-226): each rank
 # back-propagates its own shard into the flat gradient arena, GradientExchange sums the arenas (gloo), FusedSGD clips by the global norm

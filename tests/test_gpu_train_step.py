@@ -430,9 +430,11 @@ def test_bench_under_torchrun_with_rccl_exchange_one_rank():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_keep_identical_parameters_through_captured_steps():
+@pytest.mark.parametrize("exchange", ["allreduce", "mesh"])
+def test_bench_two_ranks_keep_identical_parameters_through_captured_steps(exchange):
     """Two ranks (one process each, both on this box's single GPU: `--single-device`, so the process group is gloo — RCCL needs one GPU per
-    rank) run bench.py's captured data-parallel step: per-phase hipGraphs with the three gradient-region all-reduces issued between them
+    rank) run bench.py's captured data-parallel step: per-phase hipGraphs with the gradient-region exchanges (RCCL-style all-reduce, or the
+    mesh form: all-to-all + clite_sum_slices + all-gather) issued between them
     (train_loop.TrainStep._replay_direct), different synthetic shards per rank. After warm-up + 5 replayed steps every rank's parameter
     arena must be bit-identical (bench.py compares a 64-bit checksum across ranks: `replicas_identical`), i.e. each rank applied the same
     mean gradient (reference train.py:174-178)."""
@@ -443,7 +445,7 @@ def test_bench_two_ranks_keep_identical_parameters_through_captured_steps():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "3", "--batch", "16", "--visual", "resnet18", "--layers", "2",
-           "--backend", "gloo", "--single-device", "--no-cpu-baseline"]
+           "--backend", "gloo", "--single-device", "--no-cpu-baseline", "--exchange", exchange]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]

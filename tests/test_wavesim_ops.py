@@ -491,3 +491,19 @@ def test_infonce_terms_and_normalize_backward(dtype):
     assert lib().clite_l2_normalize_bwd(dtype, ptr(xb), ptr(yb), ptr(dyb), ptr(dx), B, D, None) == 0
     ref = (dy - y * (dy * y).sum(1, keepdims=True)) / n
     assert np.abs(val(dx, dtype) - ref).max() < (2e-2 if dtype == BF16 else 1e-5)
+
+
+def test_sum_slices_fixed_order():
+    L = lib()
+    L.clite_sum_slices.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(11)
+    W, n, stride = 5, 1027, 1100
+    src = rng.standard_normal((W, stride)).astype(np.float32)
+    dst = np.zeros(n + 5, np.float32)
+    assert L.clite_sum_slices(ptr(src), W, stride, n, ptr(dst), None) == 0
+    ref = src[0, :n].copy()
+    for s in range(1, W):
+        ref += src[s, :n]                                   # slice order, f32: the kernel's order exactly
+    assert np.array_equal(dst[:n], ref) and not dst[n:].any()
+    assert L.clite_sum_slices(ptr(src), W, stride + 1, n, ptr(dst), None) == -1        # stride must keep the 16-byte alignment of every slice
+
