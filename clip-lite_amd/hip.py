@@ -252,14 +252,21 @@ def conv_dgrad(dy, w, cv, ep):
     check(lib().clite_conv_dgrad(p(dy), p(w), C.byref(cv), C.byref(ep), stream_ptr(dy)), "conv_dgrad")
 
 
-def conv_dgrad_s2(dy, w, cv, make_ep):
+def s2_class_weights(w):
+    """The four tap subsets of a [K][3][3][C] weight that the input-parity classes of a stride-2 dgrad use, class (ph, pw) at index 2 * ph + pw.
+    They depend on the weights only, so a captured step makes them early on its side stream instead of in front of each class's GEMM."""
+    return [w[:, (ph + 1) & 1::2, (pw + 1) & 1::2, :].contiguous() for ph in (0, 1) for pw in (0, 1)]
+
+
+def conv_dgrad_s2(dy, w, cv, make_ep, wsubs=None):
     """dgrad of a 3x3 / stride-2 / pad-1 conv as its four input-parity classes (a quarter of the MACs of the gathered form).
     `make_ep()` builds the epilogue (called once per class: the classes write disjoint rows of the same output)."""
+    if wsubs is None:
+        wsubs = s2_class_weights(w)
     for ph in (0, 1):
         for pw in (0, 1):
-            wsub = w[:, (ph + 1) & 1::2, (pw + 1) & 1::2, :].contiguous()
             ep = make_ep()
-            check(lib().clite_conv_dgrad_s2class(p(dy), p(wsub), C.byref(cv), ph, pw, C.byref(ep), stream_ptr(dy)), "conv_dgrad_s2class")
+            check(lib().clite_conv_dgrad_s2class(p(dy), p(wsubs[2 * ph + pw]), C.byref(cv), ph, pw, C.byref(ep), stream_ptr(dy)), "conv_dgrad_s2class")
 
 
 def s2_classes_ok(cv):

@@ -142,6 +142,19 @@ def _conv(rt, x, N, H, W, conv, training):
     return u
 
 
+def s2_class_weights(rt, net):
+    """{id(conv): the four tap-subset weights} of every conv whose dgrad runs as parity classes (hip.conv_dgrad_s2); put into the forward
+    context as ctx["s2w"] by a caller that wants them made ahead of backward (train_loop.TrainStep: on the side stream, at the start of the step)."""
+    out = {}
+    if not rt.s2_classes:
+        return out
+    for blk in net.blocks():
+        for conv, _ in blk.units()[1:]:           # (a block's first conv takes the block-input path of resnet_backward, not the parity classes)
+            if conv.k == 3 and conv.stride == 2 and conv.pad == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0:
+                out[id(conv)] = hip.s2_class_weights(rt.arena.w(conv.weight))
+    return out
+
+
 def stage_image(rt, image, out=None):
     """f32 NCHW [N][3][H][W] on the device -> the stem's input form: zero-padded NHWC4 in the compute dtype (pad 3, row pitch rounded up).
     `out` re-uses an earlier result's storage: the captured train step (train_loop.TrainStep) stages every batch into the one buffer its
@@ -314,7 +327,8 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 dstats = rt.new_stats(Cin)
                 mk = lambda: hip.epilogue(dx, Cin, dact_aux=prev.out, dact=hip.DACT_RELU, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0]))
                 if rt.s2_classes and hip.s2_classes_ok(u.cv):
-                    hip.conv_dgrad_s2(dy, rt.arena.w(u.conv.weight), u.cv, mk)       # 3x3 / stride 2: four parity classes, no zero taps
+                    hip.conv_dgrad_s2(dy, rt.arena.w(u.conv.weight), u.cv, mk,       # 3x3 / stride 2: four parity classes, no zero taps
+                                      wsubs=(ctx.get("s2w") or {}).get(id(u.conv)))
                 else:
                     hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, mk())
                 dy = _bn_backward_apply(rt, prev, dx, dstats)

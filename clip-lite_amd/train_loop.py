@@ -4,6 +4,7 @@ logging / checkpoint / validation cadence. Differences, all forced by the target
 RCCL exchange of the flat gradient arena overlapped with backward (utils/distributed.py) instead of DistributedDataParallel;
 clipping + SGD + Lookahead run in one fused kernel; wandb/loguru (absent from the image) are replaced by the stdlib logger."""
 import argparse
+import contextlib
 from collections import Counter
 from typing import Any
 
@@ -163,6 +164,10 @@ class TrainStep:
             rt.bump_counters("image_encoder", 1)
 
         def text_fwd():
+            # (first, on this stream: the tap-subset weights of the stride-2 dgrads — they depend on the weights only; in front of each class's
+            # GEMM they were twelve small copies on the critical path of the image backward)
+            from .resnet import s2_class_weights
+            keep["ctx_i"]["s2w"] = keep["s2w"] = s2_class_weights(rt, m.image_encoder.img_encoder)
             keep["step_t"] = rt.next_step(True)
             keep["txt"], keep["ctx_t"] = bert_forward(rt, m.text_encoder.strans, sb["input_ids"], sb["attention_mask"], keep["step_t"])
 
@@ -182,8 +187,9 @@ class TrainStep:
             rt.bump_counters("loss", 2)
             out, keep["df1"], keep["df2"] = jsd_join(rt, m.loss, keep["hi"], keep["ht"], keep["acc"], keep["gout"])
             keep["out"] = out
-            keep["result"] = {"loss": out[0].clone(), "loss_components": {"total_loss": out[0].clone(), "cross_modal_loss": out[1].clone(),
-                                                                          "visual_loss": out[3].clone(), "textual_loss": out[4].clone()}}
+            # views of the finalised accumulator, not copies: five copy nodes fewer between the critic and the image backward
+            keep["result"] = {"loss": out[0], "loss_components": {"total_loss": out[0], "cross_modal_loss": out[1],
+                                                                  "visual_loss": out[3], "textual_loss": out[4]}}
 
         def heads_m2():
             keep["dimg"] = jsd_half_backward(rt, keep["hi"], keep["df1"])
@@ -360,22 +366,33 @@ class TrainStep:
     def _replay(self, batch):
         rt = self.model.runtime
         self.replays += 1
+        sync = self.optimizer.advance() if hasattr(self.optimizer, "advance") else False
+        alpha = getattr(self.optimizer, "alpha", 1.0)
+        if self.exchange is not None:
+            self.inner.grad_prescale = 1.0 / self.exchange.world
+        # per-phase graphs: what only the side stream's graphs (captions) or the last graph (hyper-parameters) read is fed on the side stream,
+        # off the main stream's critical path; the image is staged on the main stream, in front of its forward
+        feed = rt.side_stream if self._graphs is not None else None
+        if feed is not None:
+            feed.wait_stream(torch.cuda.current_stream(rt.device))      # the previous step's update (main) read hp; its text graphs (side) the captions
         for k, v in batch.items():
             if torch.is_tensor(v):
                 dst = self._static_batch[k]
                 if dst.device.type == "meta":           # the image: staged by one kernel into the buffer the captured stem reads
                     from .resnet import stage_image
                     stage_image(rt, v.to(torch.float32).contiguous(), out=self._staged[0])
-                elif dst.shape == v.shape:
-                    dst.copy_(v, non_blocking=True)
-                else:                                   # a batch whose longest caption is shorter than the captured length
-                    dst.zero_()
-                    dst[:, :v.shape[1]].copy_(v, non_blocking=True)
-        sync = self.optimizer.advance() if hasattr(self.optimizer, "advance") else False
-        alpha = getattr(self.optimizer, "alpha", 1.0)
-        if self.exchange is not None:
-            self.inner.grad_prescale = 1.0 / self.exchange.world
-        self.inner.upload_hp(sync, alpha, max_norm=self.clip if self.clip and self.clip > 0 else 0.0)
+                    continue
+                on_side = feed is not None and k in self._CAPTION_KEYS
+                if on_side and v.is_cuda:
+                    v.record_stream(feed)
+                with torch.cuda.stream(feed) if on_side else contextlib.nullcontext():
+                    if dst.shape == v.shape:
+                        dst.copy_(v, non_blocking=True)
+                    else:                               # a batch whose longest caption is shorter than the captured length
+                        dst.zero_()
+                        dst[:, :v.shape[1]].copy_(v, non_blocking=True)
+        with torch.cuda.stream(feed) if feed is not None else contextlib.nullcontext():
+            self.inner.upload_hp(sync, alpha, max_norm=self.clip if self.clip and self.clip > 0 else 0.0)
         rt.sync_graph_seeds()
         if self._graphs is not None:
             self._replay_direct()
