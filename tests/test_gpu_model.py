@@ -59,12 +59,13 @@ def grad_report(M, Mo, Md):
     return rows
 
 
-def run_case(visual, mode, layers, lowp, B, S, Ls, idim, init="det"):
+def run_case(visual, mode, layers, lowp, B, S, Ls, idim, init="det", W=None, ragged=False):
+    """W: image width if not square (S is then the height); ragged: every caption gets its own length (1 .. Ls tokens) instead of one short row."""
     state = default_init_state(visual, mode, layers) if init == "default" else None
     M = build(visual, mode, layers, lowp, idim, state)
     Mo = O.build_oracle_model(visual, mode, max(layers, 1), dropout=0.0).train()
     Mo.load_state_dict(state) if state is not None else det_fill(Mo)
-    batch = {"image": det_tensor("image", (B, 3, S, S), "normal")}
+    batch = {"image": det_tensor("image", (B, 3, S, W or S), "normal")}
     if mode == "sbert":
         batch["caption_encodings"] = det_tensor("cap", (B, 768), "normal")
     else:
@@ -73,6 +74,9 @@ def run_case(visual, mode, layers, lowp, B, S, Ls, idim, init="det"):
         ids[:, -1] = 102
         mask = torch.ones(B, Ls, dtype=torch.long)
         mask[B - 1, Ls - 2:] = 0
+        if ragged:
+            for b in range(B):
+                mask[b, 1 + (b * 5) % Ls:] = 0          # lengths 1, 6, 11, ... (mod Ls): a lone [CLS], short and full captions in one batch
         ids[mask == 0] = 0          # pad token: nn.Embedding(padding_idx=0) accumulates no gradient for it
         batch["input_ids"], batch["attention_mask"] = ids, mask
     u1, u2 = det_tensor("u1", (B, idim), "uniform"), det_tensor("u2", (B, 768), "uniform")
@@ -117,6 +121,18 @@ def test_f32_mode_matches_oracle(visual, mode, layers, B, S, Ls, idim):
             # (observed there: 1.8e-5 absolute on a running mean of magnitude 0.6)
             rt_, at_ = (1e-3, 5e-5) if visual == "resnet101" else (1e-4, 1e-5)
             assert torch.allclose(sd[k].float().cpu(), sdo[k].float(), rtol=rt_, atol=at_), (k, (sd[k].float().cpu() - sdo[k].float()).abs().max().item())
+
+
+def test_f32_mode_ragged_captions_odd_batch_non_square_images():
+    """Edge cases of the input contract in one f32 case against the oracle: batch 6 (not a multiple of any tile), 96 x 160 images (non-square,
+    odd spatial sizes down the stages: 48 x 80 -> 24 x 40 -> 12 x 20 -> 6 x 10 -> 3 x 5), 13-token captions of lengths 1 .. 13 (a caption that
+    is only [CLS]; pad ids 0 receive no embedding gradient). Loss within 1e-4, gradients by the same bar as test_f32_mode_matches_oracle."""
+    M, Mo, Md, out, ref = run_case("resnet18", "train_sbert", 1, False, 6, 96, 13, 512, W=160, ragged=True)
+    assert abs(out["loss"].item() - ref["loss"].item()) < 1e-4, (out["loss"].item(), ref["loss"].item())
+    rows = grad_report(M, Mo, Md)
+    gmax = max(r[2] for r in rows)
+    bad = [(e, eo, sc, k) for e, eo, sc, k in rows if e > max(2e-3 * max(sc, 1e-3 * gmax), 16 * eo)]
+    assert not bad, sorted(bad, reverse=True)[:5]
 
 
 def _bf16_case(visual, mode, layers, B, S, Ls, idim):
