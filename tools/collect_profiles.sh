@@ -15,4 +15,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o f -- python3 bench.py -
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o w -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_w.log 2>&1
 python tools/pmc_traffic.py $O/pmc_f/f_results.db $O/pmc_w/w_results.db $O/r2_hbm_traffic.json
 python tools/pmc_by_kernel.py $O/pmc_f/f_results.db $O/pmc_w/w_results.db 60 > $O/r2_pmc_by_kernel.txt
-rm -rf $O/pmc_f $O/pmc_w $O/kt
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/pmc_m -o m -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_m.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/pmc_g -o g -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_g.log 2>&1
+python tools/pmc_mfma.py $O/pmc_m/m_results.db $O/pmc_g/g_results.db > $O/r2_mfma_busy.txt
+rm -rf $O/pmc_f $O/pmc_w $O/pmc_m $O/pmc_g $O/kt
