@@ -29,11 +29,14 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):
         model, opt, sched = bench.build(args, device)
     rt = model.runtime
-    for s in args.sets:
+    for s in [x for x in args.sets if not x.startswith("step.")]:
         k, v = s.split("=")
         old = getattr(rt, k)
         setattr(rt, k, type(old)(int(v)) if isinstance(old, (bool, int)) else type(old)(v))
     step = TrainStep(model, opt, sched, GradScaler(True), 10.0, None, graph=True)
+    for s_ in [x for x in args.sets if x.startswith("step.")]:
+        k, v = s_[5:].split("=")
+        setattr(step, k, int(v))
     batches = bench.synthetic_batches(args, device, 0)
     for i in range(6):
         step(batches[i % 2])
