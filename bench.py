@@ -136,6 +136,8 @@ def describe_launch(name, a, esz):
         lab = f"{cv.C:4d}->{cv.K:4d} {cv.R}x{cv.S}/{cv.stride} {cv.H:3d}->{cv.Ho:3d}"
         if name == "clite_conv_fwd":
             return lab, P, cv.K, kk, esz * (Q * cv.C + P * cv.K + cv.K * kk)
+        if name == "clite_conv_fwd_fp8":           # e4m3 operands (1 byte), bf16 output
+            return lab + " fp8", P, cv.K, kk, Q * cv.C + cv.K * kk + esz * P * cv.K
         if name == "clite_conv_dgrad_s2class":     # one input-parity class of a 3x3 / stride-2 dgrad: a quarter of the pixels, its own taps
             ph, pw = a[3], a[4]
             taps = (1 if (ph + 1) & 1 else 2) * (1 if (pw + 1) & 1 else 2)
@@ -150,13 +152,15 @@ def describe_launch(name, a, esz):
             return "stem 7x7", P, 64, 224, esz * (N * a[4] * a[5] * 4 + P * 64)
         return "stem 7x7", 64, 224, P, esz * (N * a[4] * a[5] * 4 + P * 64)
     M, N, K = a[4], a[5], a[6]
+    if name == "clite_gemm_nt_fp8":
+        return "linear fp8", M, N, K, M * K + N * K + esz * M * N
     if name == "clite_gemm_tn":
         return "linear", M, N, K, esz * (K * M + K * N) + 4 * M * N
     return "linear", M, N, K, esz * (M * K + N * K + M * N)
 
 
 IGEMM_ENTRY_POINTS = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_dgrad_s2class", "clite_conv_wgrad",
-                      "clite_stem_fwd", "clite_stem_wgrad", "clite_wgrad_group")
+                      "clite_stem_fwd", "clite_stem_wgrad", "clite_wgrad_group", "clite_gemm_nt_fp8", "clite_conv_fwd_fp8")
 
 
 def describe_group(a, esz):
