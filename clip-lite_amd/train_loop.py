@@ -70,7 +70,7 @@ class TrainStep:
         caption (data/dataloader.py:218-236), so L changes from batch to batch; shorter batches are right-padded (id 0 = [PAD], mask 0) into
         the captured buffers. Masked positions receive exactly zero attention weight and feed nothing downstream of the [CLS] pooler, so
         features, loss and gradients are those of the unpadded batch. allow_eager_fallback: continue with eager launches if the capture
-        fails (default: raise — a silently eager run is ~2.5x slower)."""
+        fails (default: raise — an eager step pays ~20 ms of Python launches, several times the replay at small batches)."""
         self.model, self.optimizer, self.scheduler, self.scaler = model, optimizer, scheduler, scaler
         self.pad_to, self.allow_eager_fallback = pad_to, allow_eager_fallback
         self.clip, self.exchange = clip_grad_norm, exchange
@@ -420,7 +420,7 @@ class TrainStep:
                 if not self.allow_eager_fallback:
                     raise RuntimeError(f"hipGraph capture of the train step failed ({type(e).__name__}: {e}). Pass --no-hip-graph (TrainStep(graph=False)) "
                                        "to launch eagerly, or --allow-eager-fallback to continue after a failed capture.") from e
-                logger.error(f"capture of the train step failed ({type(e).__name__}: {e}); continuing with eager launches (~2.5x slower)")
+                logger.error(f"capture of the train step failed ({type(e).__name__}: {e}); continuing with eager launches (host-bound: ~20 ms of Python launches per step)")
                 return self._eager(batch)
         if not self._fits(batch) or not self.model.training:
             return self._eager(batch)             # a batch of another shape (e.g. a ragged last one): same kernels, launched from Python
