@@ -101,6 +101,7 @@ def run_case(visual, mode, layers, lowp, B, S, Ls, idim, init="det", W=None, rag
     ("resnet50", "train_sbert", 1, 8, 128, 30, 2048),
     ("resnet101", "train_sbert", 1, 8, 128, 9, 2048),     # BASELINE configs[4]'s backbone (torchvision resnet101: (3, 4, 23, 3) Bottlenecks)
 ])
+@pytest.mark.usefixtures("deterministic_reductions")
 def test_f32_mode_matches_oracle(visual, mode, layers, B, S, Ls, idim):
     M, Mo, Md, out, ref = run_case(visual, mode, layers, False, B, S, Ls, idim)
     lt, lr = out["loss"].item(), ref["loss"].item()
@@ -123,20 +124,16 @@ def test_f32_mode_matches_oracle(visual, mode, layers, B, S, Ls, idim):
             assert torch.allclose(sd[k].float().cpu(), sdo[k].float(), rtol=rt_, atol=at_), (k, (sd[k].float().cpu() - sdo[k].float()).abs().max().item())
 
 
+@pytest.mark.usefixtures("deterministic_reductions")
 def test_f32_mode_ragged_captions_odd_batch_non_square_images():
     """Edge cases of the input contract in one f32 case against the oracle: batch 6 (not a multiple of any tile), 96 x 160 images (non-square,
     odd spatial sizes down the stages: 48 x 80 -> 24 x 40 -> 12 x 20 -> 6 x 10 -> 3 x 5), 13-token captions of lengths 1 .. 13 (a caption that
     is only [CLS]; pad ids 0 receive no embedding gradient). Loss within 1e-4, gradients by the same bar as test_f32_mode_matches_oracle.
-    Run in the deterministic-reduction mode: this input has one activation of layer3.1 (channel 137) within 1e-5 of its ReLU kink, the size
+    Run in the deterministic-reduction mode (tests/conftest.py: deterministic_reductions): this input has one activation of layer3.1 (channel 137) within 1e-5 of its ReLU kink, the size
     of the float-atomic summation-order noise of the forward (tools/diag_ragged_fwd.py: that one mask element flips in 7 of 11 repeats), and
     when it lands on the other side than in the fp64 evaluation its whole incoming gradient switches (tools/diag_ragged.py: bimodal error,
     4e-5 or 1.3e-1 on exactly that channel; 4.5e-5 in every deterministic run). The case tests shapes, not summation order."""
-    from clip_lite_amd import hip
-    hip.set_deterministic(True)
-    try:
-        M, Mo, Md, out, ref = run_case("resnet18", "train_sbert", 1, False, 6, 96, 13, 512, W=160, ragged=True)
-    finally:
-        hip.set_deterministic(False)
+    M, Mo, Md, out, ref = run_case("resnet18", "train_sbert", 1, False, 6, 96, 13, 512, W=160, ragged=True)
     assert abs(out["loss"].item() - ref["loss"].item()) < 1e-4, (out["loss"].item(), ref["loss"].item())
     rows = grad_report(M, Mo, Md)
     gmax = max(r[2] for r in rows)
@@ -206,6 +203,7 @@ def test_bf16_mode_resnet50_bert_forward():
 
 
 @pytest.mark.parametrize("name,mode,layers", [("model_rn18_sbert_b4", "sbert", 0), ("model_rn18_bert1_b4", "train_sbert", 1)])
+@pytest.mark.usefixtures("deterministic_reductions")
 def test_f32_mode_matches_reference_golden(name, mode, layers):
     """Directly against fixtures produced by the reference's own model.py / loss.py / encoder.TextEncoder."""
     fx = dict(np.load(os.path.join(G, name + ".npz")))
@@ -231,6 +229,7 @@ def test_f32_mode_matches_reference_golden(name, mode, layers):
     assert np.abs(c1 - fx["g_conv1"]).max() <= 2e-3 * np.abs(fx["g_conv1"]).max()
 
 
+@pytest.mark.usefixtures("deterministic_reductions")
 def test_full_size_config2_f32_matches_oracle_fixture():
     """The benchmarked workload itself (BASELINE.json configs[1]: ResNet-50 + BERT-base 12 layers + JSD heads / priors, batch 128, 224 x 224,
     30 tokens) in the exact-f32 mode against the oracle's fp32 CPU forward + backward of the SAME weights (tests/detfill.py) and inputs,

@@ -85,6 +85,7 @@ def _infonce_torch(f1, f2, tau):
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("deterministic_reductions")
 def test_infonce_loss_matches_torch_definition():
     """InfoNCELoss (MFMA similarity GEMM + lse / gradient kernels) against a plain-torch evaluation of the same definition on the
     oracle's modules: loss within 1e-4, every parameter gradient of the heads, the temperature and both encoders' last layers within
