@@ -102,6 +102,9 @@ class Config(object):
         _C.DATA.ROOT = "/bigtemp/as3ek/p/vlinfo/datasets/serialized2/"
         _C.DATA.IMAGE_CROP_SIZE = 224
         _C.DATA.MAX_CAPTION_LENGTH = 30
+        # (not a reference key) path of a BERT WordPiece vocab.txt; "" = the offline hash tokenizer. The reference downloads
+        # 'bert-base-uncased' from the HF hub (data/dataloader.py:139-141), which an air-gapped machine cannot.
+        _C.DATA.TOKENIZER_VOCAB = ""
         _C.DATA.USE_SINGLE_CAPTION = False
         _C.DATA.USE_PERCENTAGE = 100.0
         _C.DATA.IMAGE_TRANSFORM_TRAIN = ["random_resized_crop", "horizontal_flip", "color_jitter", "normalize"]

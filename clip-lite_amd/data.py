@@ -1,17 +1,29 @@
 """Batch sources for the pretraining step. Only the batch-dict CONTRACT of the reference's input pipeline is in scope
 (SURVEY.md §8b): `image` f32 NCHW (ImageNet-normalised), `input_ids` / `attention_mask` int64 right-padded with the pad id 0
 (reference data/dataloader.py:218-236), or `caption_encodings` f32 [B][768] in the frozen-sentence-embedding mode
-(reference model.py:48-50). The LMDB / albumentations / tokenizer stack (reference data/*.py) is CPU-side I/O outside the
-accelerated path and its dependencies are absent from the image.
+(reference model.py:48-50). The LMDB / albumentations stack (reference data/readers.py, data/transforms.py) is CPU-side I/O outside the accelerated path and
+its dependencies are absent from the image.
 
 `RandomDataset` is the counterpart of the reference's synthetic dataset (data/dataloader.py:36-114: random 3x224x224 images and
-four fixed captions, len 118000); captions are mapped to token ids by a deterministic hash because the HF tokenizer files are
-not available offline. `JsonCaptionDataset` reads the reference's json record format ({"image": path, "caption": str},
-data/mock_data.json) for its captions; image files referenced there do not exist on any machine we have, so images are
-synthetic.
+four fixed captions, len 118000). `JsonCaptionDataset` reads the reference's json record format ({"image": path, "caption": str},
+data/mock_data.json; reference data/dataloader.py:115-236, JsonDataset).
+
+Text source: `WordPieceTokenizer(vocab.txt)` is BERT's uncased WordPiece (the reference calls
+`BertTokenizer.from_pretrained('bert-base-uncased')(caption, padding=False, truncation=True, max_length=L)`, data/dataloader.py:139-141,
+196-202) built on the installed `tokenizers` package from a local vocabulary file (`DATA.TOKENIZER_VOCAB`; the HF hub is not reachable
+here, so the file must be supplied). Without a vocabulary the offline default is `hash_tokenize`, a deterministic word -> id hash with the
+same [CLS] ... [SEP] framing.
+
+Image source: when a record's image file exists it is decoded with PIL and put through the reference's transforms by name
+(`DATA.IMAGE_TRANSFORM_{TRAIN,VAL}`; factories.py:112-160): smallest_resize (shorter side -> 256 for DEFAULT_IMAGE_TRANSFORM, else the
+crop size), center_crop, random_resized_crop, horizontal_flip, normalize (ImageNet mean / std on [0, 1] pixels), HWC -> CHW float32
+(data/dataloader.py:186-192). A record whose file is missing gets a seeded synthetic image (the mock json of the reference points at
+files that exist on no machine we have).
 """
 import hashlib
 import json
+import math
+import os
 import re
 import unicodedata
 
@@ -47,9 +59,120 @@ def hash_tokenize(caption: str, max_len: int, vocab: int = 30522):
     return ids
 
 
+class WordPieceTokenizer:
+    """BERT uncased WordPiece over a local vocab.txt: BertNormalizer (clean text, lower-case, strip accents, CJK spacing) ->
+    BertPreTokenizer (whitespace + punctuation) -> greedy longest-match WordPiece ("##" continuation, [UNK] for unmatched words, words
+    over 100 characters -> [UNK]) -> "[CLS] ... [SEP]" -> truncation to max_length INCLUDING the two specials — i.e. what the reference's
+    `BertTokenizer(caption, padding=False, truncation=True, max_length=L)` returns in `input_ids` (data/dataloader.py:196-202)."""
+
+    def __init__(self, vocab_path: str):
+        from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+        if not os.path.isfile(vocab_path):
+            raise FileNotFoundError(f"WordPiece vocabulary {vocab_path!r} not found (DATA.TOKENIZER_VOCAB)")
+        self.vocab_path = vocab_path
+        vocab = {}
+        with open(vocab_path, encoding="utf-8") as fh:
+            for i, line in enumerate(fh):
+                tok = line.rstrip("\n")
+                if tok != "" and tok not in vocab:
+                    vocab[tok] = i
+        for special in ("[PAD]", "[UNK]", "[CLS]", "[SEP]"):
+            if special not in vocab:
+                raise ValueError(f"{vocab_path}: vocabulary lacks {special}")
+        self.pad_token_id, self.cls_token_id, self.sep_token_id = vocab["[PAD]"], vocab["[CLS]"], vocab["[SEP]"]
+        self.vocab_size = max(vocab.values()) + 1
+        tk = Tokenizer(models.WordPiece(vocab, unk_token="[UNK]", max_input_chars_per_word=100))
+        tk.normalizer = normalizers.BertNormalizer(clean_text=True, handle_chinese_chars=True, strip_accents=None, lowercase=True)
+        tk.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+        tk.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", special_tokens=[("[CLS]", self.cls_token_id), ("[SEP]", self.sep_token_id)])
+        self._tk = tk
+
+    def __getstate__(self):          # picklable for DataLoader workers (the reference's tokenizers do the same, data/tokenizers.py:80-92)
+        return {"vocab_path": self.vocab_path}
+
+    def __setstate__(self, st):
+        self.__init__(st["vocab_path"])
+
+    def __call__(self, caption: str, max_length: int):
+        self._tk.enable_truncation(max_length=max_length)
+        return self._tk.encode(caption).ids
+
+
+IMAGENET_COLOR_MEAN = (0.485, 0.456, 0.406)      # reference data/transforms.py:232-235
+IMAGENET_COLOR_STD = (0.229, 0.224, 0.225)
+DEFAULT_IMAGE_TRANSFORM = ("smallest_resize::256", "center_crop", "normalize")     # reference data/transforms.py:238-244
+
+
+def load_image(path: str, transforms, crop_size: int, generator=None) -> torch.Tensor:
+    """PIL decode -> RGB -> the named transforms -> f32 CHW (reference data/dataloader.py:186-192 with the transform table of
+    factories.py:112-160). Names may carry an argument as "name::value" (reference factories.py:213-221 passes the crop size to the
+    resize / crop transforms). Random transforms draw from `generator` (a torch.Generator) so that a dataset index is reproducible."""
+    from PIL import Image
+    import numpy as np
+    img = Image.open(path).convert("RGB")
+
+    def rnd():
+        return float(torch.rand((), generator=generator))
+
+    normalized = False
+    for spec in transforms:
+        name, _, arg = spec.partition("::")
+        size = int(arg) if arg else crop_size
+        if name == "smallest_resize":            # albumentations SmallestMaxSize: shorter side -> size, aspect kept, bilinear
+            w, h = img.size
+            sc = size / min(w, h)
+            img = img.resize((max(1, round(w * sc)), max(1, round(h * sc))), Image.BILINEAR)
+        elif name == "global_resize":
+            img = img.resize((size, size), Image.BILINEAR)
+        elif name == "center_crop":              # reference data/transforms.py CenterSquareCrop
+            w, h = img.size
+            l, t = (w - size) // 2, (h - size) // 2
+            img = img.crop((l, t, l + size, t + size))
+        elif name == "random_resized_crop":      # albumentations RandomResizedCrop(scale=(0.08, 1), ratio=(3/4, 4/3)), 10 tries then centre
+            w, h = img.size
+            box = None
+            for _ in range(10):
+                area = w * h * (0.08 + 0.92 * rnd())
+                logr = math.log(3 / 4) + (math.log(4 / 3) - math.log(3 / 4)) * rnd()
+                ar = math.exp(logr)
+                cw, ch = int(round(math.sqrt(area * ar))), int(round(math.sqrt(area / ar)))
+                if 0 < cw <= w and 0 < ch <= h:
+                    l, t = int(rnd() * (w - cw + 1)), int(rnd() * (h - ch + 1))
+                    box = (l, t, l + cw, t + ch)
+                    break
+            if box is None:
+                s_ = min(w, h)
+                box = ((w - s_) // 2, (h - s_) // 2, (w - s_) // 2 + s_, (h - s_) // 2 + s_)
+            img = img.crop(box).resize((size, size), Image.BILINEAR)
+        elif name == "horizontal_flip":
+            if rnd() < 0.5:
+                img = img.transpose(Image.FLIP_LEFT_RIGHT)
+        elif name == "color_jitter":
+            pass                                 # photometric augmentation: not part of the batch contract; left out
+        elif name == "normalize":
+            normalized = True
+        else:
+            raise KeyError(f"unknown image transform {spec!r}")
+    x = torch.from_numpy(np.asarray(img, dtype=np.float32).copy()) / 255.0          # HWC in [0, 1]
+    if normalized:                               # albumentations Normalize(mean, std, max_pixel_value=255)
+        x = (x - torch.tensor(IMAGENET_COLOR_MEAN)) / torch.tensor(IMAGENET_COLOR_STD)
+    return x.permute(2, 0, 1).contiguous()
+
+
 class _CaptionDataset(Dataset):
-    def __init__(self, mode: str, image_size: int, max_caption_length: int, length: int, seed: int = 0):
+    def __init__(self, mode: str, image_size: int, max_caption_length: int, length: int, seed: int = 0, tokenizer_vocab: str = "",
+                 image_transform=DEFAULT_IMAGE_TRANSFORM):
         self.mode, self.image_size, self.max_len, self.length, self.seed = mode, image_size, max_caption_length, length, seed
+        self.tokenizer = WordPieceTokenizer(tokenizer_vocab) if tokenizer_vocab else None
+        self.image_transform = tuple(image_transform)
+
+    def tokenize(self, caption: str):
+        if self.tokenizer is not None:            # the reference's order: NormalizeCaption, then the BERT tokenizer (data/dataloader.py:194-202)
+            return self.tokenizer(normalize_caption(caption, self.max_len), self.max_len)
+        return hash_tokenize(caption, self.max_len)
+
+    def image_path(self, idx):
+        return None
 
     def __len__(self):
         return self.length
@@ -59,11 +182,16 @@ class _CaptionDataset(Dataset):
 
     def __getitem__(self, idx):
         g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
-        item = {"image_id": torch.tensor(idx, dtype=torch.long), "image": torch.randn(3, self.image_size, self.image_size, generator=g)}
+        path = self.image_path(idx)
+        if path is not None and os.path.isfile(path):
+            image = load_image(path, self.image_transform, self.image_size, g)
+        else:
+            image = torch.randn(3, self.image_size, self.image_size, generator=g)
+        item = {"image_id": torch.tensor(idx, dtype=torch.long), "image": image}
         if self.mode == "sbert":
             item["caption_encodings"] = torch.randn(768, generator=g)
         else:
-            item["caption_tokens"] = torch.tensor(hash_tokenize(self.caption(idx), self.max_len), dtype=torch.long)
+            item["caption_tokens"] = torch.tensor(self.tokenize(self.caption(idx)), dtype=torch.long)
         return item
 
     def collate_fn(self, items):
@@ -83,20 +211,29 @@ class _CaptionDataset(Dataset):
 
 
 class RandomDataset(_CaptionDataset):
-    def __init__(self, mode="train_sbert", image_size=224, max_caption_length=30, length=118000, seed=0):
-        super().__init__(mode, image_size, max_caption_length, length, seed)
+    def __init__(self, mode="train_sbert", image_size=224, max_caption_length=30, length=118000, seed=0, tokenizer_vocab="",
+                 image_transform=DEFAULT_IMAGE_TRANSFORM):
+        super().__init__(mode, image_size, max_caption_length, length, seed, tokenizer_vocab, image_transform)
 
     def caption(self, idx):
         return CAPTIONS[idx % len(CAPTIONS)]
 
 
 class JsonCaptionDataset(_CaptionDataset):
-    def __init__(self, json_files, mode="train_sbert", image_size=224, max_caption_length=30, seed=0):
+    def __init__(self, json_files, mode="train_sbert", image_size=224, max_caption_length=30, seed=0, tokenizer_vocab="",
+                 image_transform=DEFAULT_IMAGE_TRANSFORM, data_root=""):
         self.records = []
         for f in json_files:
             with open(f) as fh:
                 self.records += json.load(fh)
-        super().__init__(mode, image_size, max_caption_length, len(self.records), seed)
+        self.data_root = data_root
+        super().__init__(mode, image_size, max_caption_length, len(self.records), seed, tokenizer_vocab, image_transform)
+
+    def image_path(self, idx):
+        path = self.records[idx].get("image")
+        if not path:
+            return None
+        return path if os.path.isabs(path) or not self.data_root else os.path.join(self.data_root, path)
 
     def caption(self, idx):
         c = self.records[idx]["caption"]

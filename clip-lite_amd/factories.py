@@ -38,9 +38,13 @@ class PretrainingDatasetFactory(Factory):
     @classmethod
     def from_config(cls, config: Config, split: str = "train"):
         _C = config
-        kwargs = {"mode": _C.MODEL.TEXTUAL.NAME, "image_size": _C.DATA.IMAGE_CROP_SIZE, "max_caption_length": _C.DATA.MAX_CAPTION_LENGTH}
+        kwargs = {"mode": _C.MODEL.TEXTUAL.NAME, "image_size": _C.DATA.IMAGE_CROP_SIZE, "max_caption_length": _C.DATA.MAX_CAPTION_LENGTH,
+                  "tokenizer_vocab": _C.DATA.TOKENIZER_VOCAB,
+                  # transform names as configured; resize / crop transforms take IMAGE_CROP_SIZE (reference factories.py:213-224)
+                  "image_transform": tuple(getattr(_C.DATA, f"IMAGE_TRANSFORM_{split.upper()}"))}
         if _C.MODEL.NAME == "json":
             kwargs["json_files"] = list(_C.DATA.JSON_FILES_TRAIN if split == "train" else _C.DATA.JSON_FILES_VAL)
+            kwargs["data_root"] = _C.DATA.ROOT
         elif _C.MODEL.NAME == "random":
             kwargs["length"] = 118000 if split == "train" else 5000
         else:

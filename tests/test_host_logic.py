@@ -2,6 +2,7 @@
 config semantics, schedulers against the reference-generated fixture, checkpoint layout, data contract, and the product's
 refusal to run without a GPU (no CPU fallback)."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -150,6 +151,65 @@ def test_batch_contract_and_factories():
         from clip_lite_amd.data import JsonCaptionDataset
         j = JsonCaptionDataset([ref_json], image_size=16)
         assert len(j) == 41 and j.collate_fn([j[0], j[1]])["input_ids"].shape[0] == 2
+
+
+def test_wordpiece_vocab_and_image_file_source(tmp_path):
+    """N3: a real text / image source (reference data/dataloader.py:162-236). A 30-entry toy vocab.txt and a generated PNG against
+    expectations worked by hand from BERT's WordPiece rules (greedy longest match, "##" continuations, [UNK] for unmatched words,
+    [CLS] ... [SEP], truncation counts the specials) and from the transform definitions (shorter side -> 256, centre 224 crop,
+    (pixel / 255 - mean) / std, CHW)."""
+    import numpy as np
+    from PIL import Image
+    from clip_lite_amd.config import Config
+    from clip_lite_amd.data import IMAGENET_COLOR_MEAN, IMAGENET_COLOR_STD, JsonCaptionDataset, WordPieceTokenizer, load_image
+    from clip_lite_amd.factories import PretrainingDatasetFactory
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]", "a", "cat", "dog", "sit", "##ting", "##s", "on", "the", "couch", "skate", "board",
+             "man", "rid", "##ing", "cafe", "person", "and", "two", "bike", "play", "##ed", "!", ",", "it", "un"]
+    vp = tmp_path / "vocab.txt"
+    vp.write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    tk = WordPieceTokenizer(str(vp))
+    ix = {w: i for i, w in enumerate(vocab)}
+    assert (tk.pad_token_id, tk.cls_token_id, tk.sep_token_id, tk.vocab_size) == (0, 2, 3, 30)
+    want = [ix[w] for w in ["[CLS]", "a", "cat", "sit", "##ting", "on", "the", "couch", "[SEP]"]]
+    assert tk("A cat sitting on the couch", 30) == want
+    # unmatched word -> [UNK]; punctuation is split off; accents stripped by the normaliser; "dogs" = dog + ##s
+    assert tk("two dogs, zebra at Caf\u00e9!", 30) == [ix[w] for w in ["[CLS]", "two", "dog", "##s", ",", "[UNK]", "[UNK]", "cafe", "!", "[SEP]"]]
+    # truncation to max_length including [CLS] and [SEP]
+    assert tk("a cat " * 20, 8) == [2, 5, 6, 5, 6, 5, 6, 3]
+    # an image file: 300 x 400 (w x h) gradient; shorter side 300 -> 256, so 256 x 341; centre crop 224
+    H, W = 400, 300
+    arr = np.zeros((H, W, 3), dtype=np.uint8)
+    arr[..., 0] = np.linspace(0, 255, W, dtype=np.uint8)[None, :]
+    arr[..., 1] = np.linspace(0, 255, H, dtype=np.uint8)[:, None]
+    arr[..., 2] = 77
+    ip = tmp_path / "img.png"
+    Image.fromarray(arr).save(ip)
+    x = load_image(str(ip), ("smallest_resize::256", "center_crop", "normalize"), 224)
+    assert x.shape == (3, 224, 224) and x.dtype == torch.float32
+    ref = Image.fromarray(arr).resize((256, round(400 * 256 / 300)), Image.BILINEAR)
+    l, t = (256 - 224) // 2, (ref.size[1] - 224) // 2
+    ref = np.asarray(ref.crop((l, t, l + 224, t + 224)), dtype=np.float32) / 255.0
+    ref = (ref - np.array(IMAGENET_COLOR_MEAN, dtype=np.float32)) / np.array(IMAGENET_COLOR_STD, dtype=np.float32)
+    assert np.allclose(x.numpy(), ref.transpose(2, 0, 1), atol=1e-6)
+    assert abs(float(x[2].mean()) - (77 / 255 - 0.406) / 0.225) < 1e-5            # the constant blue channel, by hand
+    assert x[0, 0, 0] < x[0, 0, -1] and x[1, 0, 0] < x[1, -1, 0]                  # red grows along w, green along h: HWC -> CHW kept the axes
+    # the json dataset: record 0 has the file, record 1 does not (synthetic image); captions through NormalizeCaption + WordPiece
+    jp = tmp_path / "ann.json"
+    jp.write_text(json.dumps([{"image": "img.png", "caption": "A man, riding a skate-board!"}, {"image": "missing.jpg", "caption": ["the dog played", "x"]}]))
+    ds = JsonCaptionDataset([str(jp)], image_size=224, tokenizer_vocab=str(vp), data_root=str(tmp_path))
+    b = ds.collate_fn([ds[0], ds[1]])
+    assert torch.equal(b["image"][0], x) and b["image"].shape == (2, 3, 224, 224)
+    row0 = [ix[w] for w in ["[CLS]", "a", "man", "rid", "##ing", "a", "skate", "board", "[SEP]"]]
+    row1 = [ix[w] for w in ["[CLS]", "the", "dog", "play", "##ed", "[SEP]"]]
+    assert b["input_ids"][0].tolist() == row0 and b["input_ids"][1].tolist() == row1 + [0] * 3
+    assert b["attention_mask"].tolist() == [[1] * 9, [1] * 6 + [0] * 3]
+    # through the factory / config keys
+    c = Config(None, ["MODEL.NAME", "json", "DATA.JSON_FILES_TRAIN", [str(jp)], "DATA.TOKENIZER_VOCAB", str(vp), "DATA.ROOT", str(tmp_path),
+                      "DATA.IMAGE_TRANSFORM_TRAIN", ["smallest_resize", "center_crop", "normalize"]])
+    d = PretrainingDatasetFactory.from_config(c, "train")
+    assert d[0]["caption_tokens"].tolist() == row0 and d[0]["image"].shape == (3, 224, 224)
+    with pytest.raises(FileNotFoundError):
+        WordPieceTokenizer(str(tmp_path / "nope.txt"))
 
 
 def test_caption_normalisation_known_answers():
