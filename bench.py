@@ -308,9 +308,10 @@ def main():
     loss = out["loss"].item()
     replicas_identical = None
     if dist_on:
-        # data parallel keeps every rank's parameters bit-identical (same mean gradient, same update): compare a 64-bit checksum of the arena
-        fp = model.runtime.arena.flat_p.double()
-        mine = torch.stack([fp.sum(), (fp * fp).sum(), fp[::97].abs().sum()])
+        # data parallel keeps every rank's parameters bit-identical (same mean gradient, same update). A BITWISE comparison: integer sums of the
+        # parameters' 32-bit patterns (wrapping int64 arithmetic is exact and order-independent), whole arena plus two strided sub-samples
+        bits = model.runtime.arena.flat_p.view(torch.int32).to(torch.int64)
+        mine = torch.stack([bits.sum(), (bits * (1 + torch.arange(bits.numel(), device=bits.device) % 8191)).sum(), bits[::97].sum()])
         every = [torch.empty_like(mine) for _ in range(tdist.get_world_size())]
         tdist.all_gather(every, mine)
         replicas_identical = all(torch.equal(every[0], e) for e in every)

@@ -19,33 +19,47 @@ constexpr float FP8_MAX = 448.f;
 template <typename T>
 __global__ __launch_bounds__(256) void amax_kernel(const T* __restrict__ x, size_t n8, float* amax) {
   float m = 0.f;
+  bool nan = false;       // fmaxf drops a NaN operand: a diverged tensor must not come out as a finite amax (it is carried separately)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     float v[8];
     load8(x + i * 8, v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+    for (int e = 0; e < 8; ++e) { m = fmaxf(m, fabsf(v[e])); nan = nan || v[e] != v[e]; }
   }
-  __shared__ float red[4];
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __shared__ uint32_t red[4];
+  // the quiet-NaN pattern 0x7FC00000 orders above every finite value and above +inf both as a float bit pattern under the integer max
+  // below and in this wave / workgroup fold (done on the bit patterns for that reason)
+  uint32_t mb = nan ? 0x7FC00000u : f32_bits(m);
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)wave_shfl_xor_i((int)mb, sh); mb = o > mb ? o : mb; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mb;
   __syncthreads();
   // non-negative floats order like their bit patterns: an integer max needs no float atomics and is order-independent. One atomic per
   // workgroup: same-address atomics retire at ~90 per microsecond chip-wide, so thousands of them per call would cost more than the pass
-  if (threadIdx.x == 0) atomic_max_u32((uint32_t*)amax, f32_bits(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  if (threadIdx.x == 0) {
+    uint32_t b = red[0];
+    for (int w = 1; w < 4; ++w) b = red[w] > b ? red[w] : b;
+    atomic_max_u32((uint32_t*)amax, b);
+  }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void to_fp8_kernel(const T* __restrict__ x, size_t n8, const float* __restrict__ amax, fp8* __restrict__ out, float* scales) {
   const float a = amax[0];
-  const float scale = a > 0.f ? FP8_MAX / a : 1.f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) { scales[0] = scale; scales[1] = a > 0.f ? a / FP8_MAX : 1.f; }
+  // a non-finite amax (a NaN or an infinity somewhere in the tensor) makes both scales NaN, so every product of the GEMM that consumes them
+  // is NaN: a diverged operand stays visible in the loss instead of being clamped into a finite e4m3 value
+  const bool finite = a == a && a < INFINITY;
+  const float scale = !finite ? bits_f32(0x7FC00000u) : (a > 0.f ? FP8_MAX / a : 1.f);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { scales[0] = scale; scales[1] = !finite ? scale : (a > 0.f ? a / FP8_MAX : 1.f); }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     float v[8];
     load8(x + i * 8, v);
     uint32_t w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float p = fminf(fmaxf(v[2 * e] * scale, -FP8_MAX), FP8_MAX), q = fminf(fmaxf(v[2 * e + 1] * scale, -FP8_MAX), FP8_MAX);
+      // fminf / fmaxf would turn a NaN into -448: a NaN passes the clamp untouched and converts to e4m3's NaN (0x7F / 0xFF)
+      const float p0 = v[2 * e] * scale, q0 = v[2 * e + 1] * scale;
+      const float p = p0 != p0 ? p0 : fminf(fmaxf(p0, -FP8_MAX), FP8_MAX), q = q0 != q0 ? q0 : fminf(fmaxf(q0, -FP8_MAX), FP8_MAX);
       w[e] = cvt2_fp8(p, q);
     }
     *(u32x2*)(out + i * 8) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};

@@ -304,10 +304,13 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
 }
 
 // Workspace bytes that certainly hold the descriptors of `n_items` members with `total_workgroups` workgroups in all (each member contributes
-// ceil(M/BM) * ceil(N/BN) * ceil(ceil(K/32)/128) of them): 512 B per member, 16 B per workgroup, alignment slack.
+// ceil(M/BM) * ceil(N/BN) * ceil(ceil(K/32)/KCHUNK) of them, KCHUNK = 256): 512 B per member, 16 B per map entry, alignment slack.
+// build_map() balances the eight per-XCD lists by WORK (tiles x K length), not by entry count, and pads every list to the longest one: a
+// bucket that mixes long-K and short-K members can hold several times its real entries. The longest list cannot exceed the real entry
+// count, so 8 x total_workgroups entries is a bound that no mix of members breaks; it is 16 B per entry, i.e. about 1 MB for the
+// largest step this build runs.
 extern "C" int clite_wgrad_group_workspace(int n_items, int64_t total_workgroups, uint64_t* bytes) {
   if (n_items < 0 || total_workgroups < 0 || !bytes) return -1;
-  // + the padding of the per-XCD lists: at most 7 bundles of 64 workgroups in each of the four kernel buckets
-  *bytes = (uint64_t)n_items * 512 + (uint64_t)total_workgroups * 16 + 4 * 7 * 64 * 16 + 4096;
+  *bytes = (uint64_t)n_items * 512 + (uint64_t)total_workgroups * 16 * 8 + 4 * 4096;
   return 0;
 }

@@ -107,6 +107,7 @@ DEV float wave_max(float v) {
 DEV void atomic_add_f32(float* p, float v) { atomicAdd(p, v); }
 DEV void atomic_max_u32(uint32_t* p, uint32_t v) { atomicMax(p, v); }
 DEV uint32_t f32_bits(float f) { return __float_as_uint(f); }
+DEV float bits_f32(uint32_t u) { return __uint_as_float(u); }
 
 DEV uint32_t umulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 

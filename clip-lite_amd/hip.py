@@ -289,6 +289,9 @@ _inflight_groups = collections.deque()
 _ws_pool = []          # [(event recorded behind the last launch that used it, device workspace, pinned host workspace)] of uncaptured WgradGroup launches
 
 
+KCHUNK_TILES = 256          # K tiles (of 32) per workgroup of a grouped weight gradient: csrc/gemm_group.hip KCHUNK
+
+
 class WgradGroup:
     """Weight gradients collected during a backward pass and launched together (include/clite.h: clite_wgrad_group). The backward executors
     call conv() / linear() where they would have launched clite_conv_wgrad / clite_gemm_tn, and call() for anything else that only feeds
@@ -303,14 +306,15 @@ class WgradGroup:
         self.ws_dev, self.ws_host = workspace if workspace is not None else (None, None)
 
     @staticmethod
-    def alloc_workspace(device, nbytes=1 << 20):
-        """1 MiB holds ~60 000 workgroups' descriptors: an order of magnitude more than ResNet-101 + BERT-base need."""
+    def alloc_workspace(device, nbytes=4 << 20):
+        """4 MiB holds the descriptors of ~30 000 workgroups under the library's worst-case list padding (clite_wgrad_group_workspace: 8 x 16 B
+        per workgroup); ResNet-101 + BERT-base at batch 256 need about 8 000."""
         return torch.empty(nbytes, dtype=torch.uint8, device=device), torch.empty(nbytes, dtype=torch.uint8).pin_memory()
 
     @staticmethod
     def _wgs(M, N, K, bm=128, bn=128):
         kt = (K + 31) // 32
-        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * ((kt + 127) // 128)
+        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * ((kt + KCHUNK_TILES - 1) // KCHUNK_TILES)
 
     def conv(self, dy, x, cv, dw):
         it = WgradItem()
@@ -347,7 +351,7 @@ class WgradGroup:
                         pooled = _ws_pool.pop(i)
                         break
                 if pooled is None:
-                    n_alloc = max(int(nbytes.value), 1 << 20)
+                    n_alloc = max(int(nbytes.value), 4 << 20)
                     pooled = (None, torch.empty(n_alloc, dtype=torch.uint8, device=first.device), torch.empty(n_alloc, dtype=torch.uint8).pin_memory())
                 self.ws_dev, self.ws_host = pooled[1], pooled[2]
             nb = self.ws_dev.numel() if self.ws_dev is not None else 0

@@ -81,8 +81,15 @@ class WarmupSchedule:
         return list(self._last_lr)
 
     def state_dict(self) -> dict:
-        return {"last_epoch": self.last_epoch, "_step_count": self._step_count, "base_lrs": list(self.base_lrs), "_last_lr": list(self._last_lr),
-                "kind": self.kind, "total_steps": self.total_steps, "warmup_steps": self.warmup_steps, "shape": dict(self.shape)}
+        """torch's LambdaLR layout plus this class's own keys, so that the reference's scheduler (a LambdaLR subclass: optim/lr_scheduler.py:11-202)
+        can resume a checkpoint written here: LambdaLR.load_state_dict pops "lr_lambdas" (one entry per lambda; None = "not a picklable object,
+        keep the constructed one") and copies every other key onto the instance — hence the reference's attribute names tsteps / wsteps
+        (and min_mult / milestones / gamma where the schedule has them) beside ours."""
+        st = {"last_epoch": self.last_epoch, "_step_count": self._step_count, "base_lrs": list(self.base_lrs), "_last_lr": list(self._last_lr),
+              "kind": self.kind, "total_steps": self.total_steps, "warmup_steps": self.warmup_steps, "shape": dict(self.shape),
+              "lr_lambdas": [None], "tsteps": self.total_steps, "wsteps": self.warmup_steps}
+        st.update({k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in self.shape.items()})
+        return st
 
     def load_state_dict(self, state: dict):
         """Accepts this class's own dict and a torch LambdaLR one (a checkpoint written by the reference): the position is `last_epoch`."""

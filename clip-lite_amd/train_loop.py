@@ -177,7 +177,9 @@ class TrainStep:
 
         def heads_t1():
             keep["step_h"] = st = rt.next_step(True)
-            keep["sites"] = (st.site(), st.site())            # image prior noise, text prior noise: the eager draw order (reference loss.py:189,196)
+            # image prior noise, then text prior noise — the eager draw order (reference loss.py:189,196); a site is drawn only for an enabled
+            # prior, exactly as loss.jsd_forward does, so that eager and replayed steps use the same sites whichever priors are on
+            keep["sites"] = (st.site() if m.loss.image_prior else None, st.site() if m.loss.text_prior else None)
             keep["acc"] = torch.zeros(8, device=rt.device, dtype=torch.float32)
             keep["gout"] = torch.ones(1, device=rt.device, dtype=torch.float32)
             keep["ht"] = jsd_half_forward(rt, m.loss, keep["txt"], "text", st, keep["sites"][1], keep["acc"], keep["gout"])

@@ -12,8 +12,12 @@
  *   - activations are NHWC / row-major [rows][features]; weights are [out][...in], inner dim contiguous
  *   - `stream` is a hipStream_t; kernels are only enqueued, nothing synchronises, nothing allocates
  *   - return value: 0 on success, a hipError_t value or -1 (bad argument) otherwise; nothing throws
- *   - entry points are re-entrant and hold no global mutable state (forward runs on the Python main
- *     thread, backward on the autograd engine thread)
+ *   - entry points are re-entrant (forward runs on the Python main thread, backward on the autograd engine
+ *     thread). The library holds exactly two pieces of process-wide state, both plain atomics set through their
+ *     own entry points and never written by a kernel launcher: the deterministic-reduction flag
+ *     (clite_set_deterministic) and the tile policy (clite_set_tile_policy). Both are read once per call, when
+ *     the kernels are ENQUEUED: a captured hipGraph keeps the mode it was recorded in, an eager step follows the
+ *     current value — set them before a step, not during one.
  */
 #ifndef CLITE_H
 #define CLITE_H

@@ -130,6 +130,46 @@ def test_schedulers_match_reference_fixture():
     assert o.param_groups[0]["lr"] == 0.0            # first optimizer step of the reference runs with lr 0
 
 
+def test_scheduler_state_dict_loads_into_a_torch_lambdalr():
+    """the reference's schedulers are torch LambdaLR subclasses (optim/lr_scheduler.py), whose load_state_dict pops "lr_lambdas" —
+    a checkpoint written here must carry it. Round trip: our state_dict -> a LambdaLR subclass with the reference's attribute names and the
+    same multiplier -> identical learning rates from the restored position on."""
+    import math
+    from torch.optim.lr_scheduler import LambdaLR
+    from clip_lite_amd.optim import lr_scheduler as S
+
+    class RefCosine(LambdaLR):            # shape of reference optim/lr_scheduler.py:155-202 (attributes tsteps / wsteps / min_mult)
+        def __init__(self, opt, total_steps, warmup_steps, min_mult=0.0, last_epoch=-1):
+            self.tsteps, self.wsteps, self.min_mult = total_steps, warmup_steps, min_mult
+            super().__init__(opt, self._m, last_epoch)
+
+        def _m(self, step):
+            if step < self.wsteps:
+                return step / float(max(1, self.wsteps))
+            return max(0, math.cos((step - self.wsteps) / (self.tsteps - self.wsteps) * (math.pi / 2)) ** 2 + self.min_mult)
+
+    mk = lambda: torch.optim.SGD([{"params": [torch.nn.Parameter(torch.zeros(1))], "lr": 0.2}, {"params": [torch.nn.Parameter(torch.zeros(1))], "lr": 1e-3}], lr=0.1)
+    ours = S.LinearWarmupCosineAnnealingLR(mk(), total_steps=50, warmup_steps=5)
+    for _ in range(17):
+        ours.step()
+    st = ours.state_dict()
+    assert st["lr_lambdas"] == [None] and st["tsteps"] == 50 and st["wsteps"] == 5 and st["last_epoch"] == 17
+    o2 = mk()
+    ref = RefCosine(o2, total_steps=50, warmup_steps=5)
+    ref.load_state_dict(dict(st))         # raised KeyError('lr_lambdas') before
+    for _ in range(6):
+        ours.step()
+        o2.step()
+        ref.step()
+        assert np.allclose(ref.get_last_lr(), ours.get_last_lr(), rtol=1e-12)
+    # and the other direction: a LambdaLR dict into ours
+    back = S.LinearWarmupCosineAnnealingLR(mk(), total_steps=50, warmup_steps=5)
+    back.load_state_dict(ref.state_dict())
+    assert back.last_epoch == ref.last_epoch and np.allclose(back.get_last_lr(), ref.get_last_lr(), rtol=1e-12)
+    ms = S.LinearWarmupMultiStepLR(mk(), total_steps=100, warmup_steps=10, milestones=[30, 60], gamma=0.1).state_dict()
+    assert ms["milestones"] == [30, 60] and ms["gamma"] == 0.1 and ms["lr_lambdas"] == [None]
+
+
 def test_batch_contract_and_factories():
     from clip_lite_amd.config import Config
     from clip_lite_amd.data import RandomDataset, hash_tokenize

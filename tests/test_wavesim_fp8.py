@@ -71,6 +71,23 @@ def test_quantizer_matches_e4m3_round_to_nearest_even(dtype):
     assert not qz.any() and sz[0] == 1.0 and sz[1] == 1.0
 
 
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_quantizer_keeps_non_finite_inputs_visible(dtype, bad):
+    """fmaxf drops a NaN and the +-448 clamp turned a NaN element into -448, so a diverged tensor quantised to finite e4m3 values and a
+    NaN-loss guard never fired. A NaN or an infinity anywhere in the tensor now makes amax non-finite, both scales NaN (every product of the
+    consuming GEMM is NaN) and every output code e4m3's NaN; n % 8 != 0 is refused."""
+    L = lib()
+    L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    x = np.random.default_rng(5).standard_normal((9, 64)).astype(np.float32)
+    x[4, 17] = bad
+    q, scales, amax = _quant(L, x, dtype)
+    assert not np.isfinite(amax[0]) and np.isnan(scales).all()
+    assert ((q & 0x7f) == 0x7f).all()                           # 0x7F / 0xFF: the two NaN codes of e4m3fn
+    buf = np.zeros(12, np.float32)
+    assert L.clite_fp8_quantize(F32, ptr(buf), 12, ptr(np.zeros(1, np.float32)), ptr(np.zeros(2, np.float32)), ptr(np.zeros(12, np.uint8)), None) == -1
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 208), (300, 64, 96), (70, 1000, 64)])
 def test_gemm_nt_fp8(M, N, K):
     L = lib()

@@ -350,6 +350,11 @@ inline uint32_t f32_bits(float f) {
   memcpy(&u, &f, 4);
   return u;
 }
+inline float bits_f32(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
 inline void atomic_add_f32(float* p, float v) {
   std::atomic_ref<float> a(*p);
   float old = a.load();
