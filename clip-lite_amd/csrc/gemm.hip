@@ -50,6 +50,9 @@ template <typename T> struct Cfg {
 #ifndef CLITE_DIAG
 #define CLITE_DIAG 0
 #endif
+#ifndef CLITE_BN_SLOTS
+#define CLITE_BN_SLOTS 512      // resident workgroups of igemm_dma_bn_kernel on the chip: 2 per CU x 256 CUs (the wave-simulator build of the tests sets 4)
+#endif
 #if CLITE_DIAG
 int diag_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 bool use_dma() { static int v = -1; if (v < 0) v = diag_env("CLITE_IGEMM_LEGACY", 0) ? 0 : 1; return v == 1; }
@@ -191,10 +194,20 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
     constexpr int STAGE = DA::BYTES + DB::BYTES;
     if (ep.bn_y || ep.mask_after_residual) {     // BatchNorm-backward epilogue: its own (register-heavier) instantiation, dgrad loaders only
       // it implements exactly: out = [(alpha*acc) (* relu'(aux))] (+ residual) [(* relu'(aux))], colsum; nothing else
-      if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || splits != 1) return -1;
+      if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || (ep.dact_aux && ep.relu_bits) || splits != 1) return -1;
       if constexpr (IsDgrad<LA>::value) {
-        hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, 1>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
-                           M, N, ktiles, per, xsplits);
+        // row-range persistent form (igemm_dma_bn_kernel) for the short-K (1 x 1) dgrads whose tile count exceeds the 512 resident slots
+        // (2 workgroups per CU); one tile per workgroup otherwise
+        const int tiles_n = (N + CFG::BN - 1) / CFG::BN, tiles_m = (M + CFG::BM - 1) / CFG::BM;
+        int rows_per_wg = CFG::BM, slices = tiles_m;
+        if (la.g.R * la.g.S == 1 && (long)tiles_m * tiles_n > CLITE_BN_SLOTS && tiles_n <= CLITE_BN_SLOTS && !deterministic()) {
+          slices = CLITE_BN_SLOTS / tiles_n;
+          rows_per_wg = ((M + slices - 1) / slices + 7) & ~7;
+          if (rows_per_wg < CFG::BM) rows_per_wg = CFG::BM;
+          slices = (M + rows_per_wg - 1) / rows_per_wg;
+        }
+        hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB>), dim3(slices * tiles_n), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
+                           M, N, ktiles, rows_per_wg);
         return (int)hipGetLastError();
       } else {
         return -1;
@@ -249,6 +262,8 @@ int check_ep(const clite_epilogue* ep, int N) {
   if (!ep || !ep->out) return -1;
   if (!ep->atomic && (N % 8 != 0 || ep->ldc % 8 != 0)) return -1;
   if (ep->atomic && !ep->out_f32) return -1;
+  // packed relu' bits exist in the BatchNorm-backward form only, and exclude the tensor form of the same mask
+  if (ep->relu_bits && (!(ep->bn_y || ep->mask_after_residual) || ep->dact_aux)) return -1;
   return 0;
 }
 

@@ -633,14 +633,17 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
 #endif
   constexpr int AHEAD = CLITE_BN_AHEAD;
   Raw8<T> pa[ROWS_PT], py[ROWS_PT], pr[ROWS_PT];
+  uint32_t pb[ROWS_PT];          // packed relu' bits of the row's 8 columns (clite_epilogue.relu_bits): one byte instead of a 16-byte chunk of dact_aux
   uint32_t gix[ROWS_PT];
   bool okr[ROWS_PT];
   auto request = [&](int q) {
     int grow = m0 + erow0 + q * RPSE;
     okr[q] = colok && grow < M;
     gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
+    pb[q] = 0xFFu;
     if (okr[q]) {
-      if (ep.dact_aux) pa[q].ld((const T*)ep.dact_aux + gix[q]);
+      if (ep.relu_bits) pb[q] = ep.relu_bits[gix[q] >> 3];
+      else if (ep.dact_aux) pa[q].ld((const T*)ep.dact_aux + gix[q]);
       if (ep.bn_y) py[q].ld((const T*)ep.bn_y + gix[q]);
       if (ep.residual) pr[q].ld((const T*)ep.residual + gix[q]);
     }
@@ -659,7 +662,10 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
     float msk[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { v[e] *= ep.alpha; msk[e] = 1.f; }
-    if (ep.dact_aux) {
+    if (ep.relu_bits) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) msk[e] = (pb[q] >> e) & 1u ? 1.f : 0.f;
+    } else if (ep.dact_aux) {
       float av[8];
       pa[q].get(av);
 #pragma unroll

@@ -418,6 +418,130 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
 }
 
 
+// ---- BatchNorm-backward conv dgrad as a ROW-RANGE PERSISTENT kernel ---------------------------------------------------------------
+// The HBM-bound 1x1 dgrads of the ResNet backward (K = 64 ... 512: a handful of K tiles, then an epilogue that reads two or three more tensors
+// and writes one) run at two workgroups per CU, i.e. 512 resident slots, and their tile counts are a little more than a multiple of that
+// (1568 tiles of 128 x 128 for 1024 -> 256 at 14 x 14: 3.06 rounds, the fourth 94 % empty; profiles/r2_layers.txt). Here every workgroup
+// owns `rows_per_wg` consecutive GEMM rows of ONE column tile and walks them in steps of BM; the last step is a partial tile (rows past the
+// range read as zero / are not stored), which costs a short main loop and an epilogue proportional to its rows. With rows_per_wg =
+// ceil(M / (512 / column tiles)) all workgroups are resident at once and finish together. rows_per_wg = BM is the plain one-tile form
+// (windowed convs, whose main loop is long: a partial tile would cost a whole one).
+template <typename T, class CFG, class LA, class LB>
+__global__ __launch_bounds__(256) void igemm_dma_bn_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int rows_per_wg) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int NSTAGE = 3;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int EPIB = CFG::BM * CFG::EPI_PITCH;             // the BatchNorm-backward epilogue stages the whole tile
+  constexpr int SMEM = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
+  constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
+  static_assert(sizeof(T) == 2 || sizeof(T) == 4, "bf16 or f32");
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+  const int tiles_n = (N + BN - 1) / BN;
+  // XCD-aware order (igemm_dma_kernel): each XCD gets a contiguous run of (row range, column tile) pairs, column tiles of one row range adjacent
+  const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int slice = wg / tiles_n;
+  const int n0 = (wg - slice * tiles_n) * BN;
+  const int row_begin = slice * rows_per_wg;
+  int row_end = row_begin + rows_per_wg;
+  if (row_end > M) row_end = M;
+  la.g.rows = row_end;                      // rows past this workgroup's range gather as out of range (zeros)
+
+  int aoff[RM][BK / 16 > 0 ? BK / 16 : 1], boff[RN][BK / 16 > 0 ? BK / 16 : 1];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i) aoff[i][ks] = LA::frag_off(wm0 + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) boff[j][ks] = LB::frag_off(wn0 + j * 32, ks, lane);
+    }
+  }
+
+  for (int m0 = row_begin; m0 < row_end; m0 += BM) {
+    typename LA::State sa;
+    typename LB::State sb;
+    la.init(sa, m0, wave, lane, 0);
+    lb.init(sb, n0, wave, lane, 0);
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+      if (pz < ktiles) {
+        DmaIssue<LA>::go(la, sa, smem + pz * STAGE, wave, lane, m0);
+        DmaIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
+      }
+    }
+    int buf = 0;
+    for (int t = 0; t < ktiles; ++t) {
+      if (ktiles - 1 - t >= 1) wait_vmcnt<LOADS_PER_TILE>();
+      else wait_vmcnt<0>();
+      barrier_raw();
+      const char* abuf = smem + buf * STAGE;
+      const char* bbuf = abuf + LA::BYTES;
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 af0[RM], bf0[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
+#pragma unroll
+        for (int j = 0; j < RN; ++j) bf0[j] = LB::frag_at(bbuf + boff[j][0]);
+        if (t + NSTAGE - 1 < ktiles) {
+          int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+          DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+          DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+          bf16x8 af[RM], bfr[RN];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
+#pragma unroll
+          for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
+#pragma unroll
+          for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+        }
+      } else {
+        if (t + NSTAGE - 1 < ktiles) {
+          int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+          DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+          DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+          float af[RM], bfr[RN];
+#pragma unroll
+          for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
+#pragma unroll
+          for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
+#pragma unroll
+          for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+        }
+      }
+      if (++buf == NSTAGE) buf = 0;
+    }
+    barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
+    igemm_epilogue_bn<T, CFG>(acc, ep, rm, smem, row_end, N, m0, n0, tid, lane, wave, wm0, wn0);
+    lds_barrier();          // ... and past its last read of the epilogue's LDS image before the next tile's operands land in it
+  }
+}
+
+
 // ---- two K-groups per workgroup -------------------------------------------------------------------------------------------
 // Small grids (at most one workgroup per CU: the BERT GEMMs with N = 768, the 7x7-resolution convs) leave each SIMD with a single
 // wave whose DMA issue, LDS reads and MFMAs serialise. Here a workgroup has 8 waves = 2 groups of 4; group g runs the pipeline

@@ -225,6 +225,7 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
   for (int pass = 0; pass < CFG::BM / CFG::PR; ++pass) {
     // the operands of all rows this thread writes in this pass are requested before the accumulators go through LDS
     Raw8<T> pa[ITER], py[ITER], pr[ITER];
+    uint32_t pb[ITER];           // packed relu' bits (clite_epilogue.relu_bits; BatchNorm-backward form only)
     uint32_t gix[ITER];
     bool okr[ITER];
 #pragma unroll
@@ -232,8 +233,10 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
       const int grow = m0 + pass * CFG::PR + erow0 + it * RPSE;
       okr[it] = colok && grow < M;
       gix[it] = okr[it] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
+      pb[it] = 0xFFu;
       if (EPI != 2 && okr[it]) {
-        if (ep.dact_aux) pa[it].ld((const T*)ep.dact_aux + gix[it]);
+        if (EPI == 1 && ep.relu_bits) pb[it] = ep.relu_bits[gix[it] >> 3];
+        else if (ep.dact_aux) pa[it].ld((const T*)ep.dact_aux + gix[it]);
         if (EPI == 1 && ep.bn_y) py[it].ld((const T*)ep.bn_y + gix[it]);
         if (ep.residual) pr[it].ld((const T*)ep.residual + gix[it]);
       }
@@ -281,7 +284,14 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
       float dfac[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) dfac[e] = 1.f;
-      if (EPI != 2 && ep.dact_aux) {
+      if (EPI == 1 && ep.relu_bits) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dfac[e] = (pb[it] >> e) & 1u ? 1.f : 0.f;
+        if (!ep.mask_after_residual) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
+        }
+      } else if (EPI != 2 && ep.dact_aux) {
         float av[8];
         pa[it].get(av);
 #pragma unroll
@@ -306,7 +316,7 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
       }
-      if (EPI == 1 && ep.dact_aux && ep.mask_after_residual) {
+      if (EPI == 1 && (ep.dact_aux || ep.relu_bits) && ep.mask_after_residual) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
       }
@@ -345,6 +355,171 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
       const int chunk = idx / 16, e = idx % 16;
       const int col = n0 + chunk * 8 + (e & 7);
       if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
+    }
+  }
+}
+
+// BatchNorm-backward epilogue of the 8-wave kernels with its operands requested EARLY. One 8-wave workgroup per CU has nothing else on the
+// CU to cover an epilogue that waits on HBM: with the per-pass requests of wide_epilogue<CFG, 1> every 64-row pass paid a cold round trip
+// (3 x 3 256 -> 256 dgrad at 14 x 14: 73.7 us against 45 for the plain store, profiles/r2_layers.txt). Here the first pass's operands
+// (BatchNorm input, residual, packed relu' bits) are requested BEFORE the main loop — their latency hides behind the first K tiles — and all
+// later passes' at the start of the epilogue. Tiles whose rows fit the register budget only (EARLY: passes x rows per thread <= 8).
+template <class CFG>
+struct WideBnOperands {
+  typedef bf16 T;
+  static constexpr int NPASS = CFG::BM / CFG::PR, ITER = CFG::ITER, ROWS = NPASS * ITER;
+  static constexpr bool EARLY = ROWS <= 8;
+  Raw8<T> py[ROWS], pr[ROWS], pa[ROWS];
+  uint32_t pb[ROWS], gix[ROWS];
+  bool okr[ROWS];
+  DEV void request(int pass, const Epilogue& ep, const RowMap& rm, int M, int N, int m0, int n0, int tid) {
+    const int ecol = (tid % CFG::CPRE) * 8, erow0 = tid / CFG::CPRE;
+    const int gcol = n0 + ecol;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = pass * ITER + it;
+      const int grow = m0 + pass * CFG::PR + erow0 + it * CFG::RPSE;
+      okr[q] = gcol < N && grow < M;
+      gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
+      pb[q] = 0xFFu;
+      if (okr[q]) {
+        if (ep.relu_bits) pb[q] = ep.relu_bits[gix[q] >> 3];
+        else if (ep.dact_aux) pa[q].ld((const T*)ep.dact_aux + gix[q]);
+        if (ep.bn_y) py[q].ld((const T*)ep.bn_y + gix[q]);
+        if (ep.residual) pr[q].ld((const T*)ep.residual + gix[q]);
+      }
+    }
+  }
+};
+
+template <class CFG>
+DEV void wide_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], WideBnOperands<CFG>& ops, const Epilogue& ep, const RowMap& rm, char* smem, int M, int N,
+                          int m0, int n0, int tid, int lane, int kg, int wm0, int wn0) {
+  constexpr int RM = CFG::RM, RN = CFG::RN, NPASS = CFG::BM / CFG::PR;
+  typedef bf16 T;
+  if constexpr (CFG::KG == 2) {
+    float* xchg = (float*)smem;
+    const int t = tid & 255;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xchg[((i * RN + j) * 16 + r) * 256 + t] = acc[i][j][r];
+    }
+    lds_barrier();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += xchg[((i * RN + j) * 16 + r) * 256 + t];
+    }
+    lds_barrier();
+  }
+  constexpr int CPRE = CFG::CPRE, RPSE = CFG::RPSE, ITER = CFG::ITER, PITCH = CFG::EPI_PITCH;
+  const int ecol = (tid % CPRE) * 8, erow0 = tid / CPRE;
+  const int gcol = n0 + ecol;
+  const bool colok = gcol < N;
+  float csum[8], csq[8], bn_mean[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; bn_mean[e] = 0.f; }
+  if (colok && ep.bn_y) {
+    for (int r = 0; r < ep.bn_replicas; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bn_mean[e] += ep.bn_stats[(size_t)r * ep.bn_rstride + gcol + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bn_mean[e] *= ep.bn_inv_count;
+  }
+#pragma unroll
+  for (int pass = 1; pass < NPASS; ++pass) ops.request(pass, ep, rm, M, N, m0, n0, tid);       // (pass 0 went out before the main loop)
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+    for (int h = 0; h < RM / 2; ++h) {
+      if (kg == 0 && wm0 + h * 64 == pass * CFG::PR) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+          for (int j = 0; j < RN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              const int col = wn0 + j * 32 + (lane & 31);
+              *(float*)(smem + row * PITCH + col * 4) = acc[h * 2 + ii][j][r];
+            }
+      }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int q = pass * ITER + it;
+      if (!ops.okr[q]) continue;
+      const int rr = erow0 + it * RPSE;
+      const float* src = (const float*)(smem + rr * PITCH + ecol * 4);
+      const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      float msk[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] *= ep.alpha; msk[e] = 1.f; }
+      if (ep.relu_bits) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) msk[e] = (ops.pb[q] >> e) & 1u ? 1.f : 0.f;
+      } else if (ep.dact_aux) {
+        float av[8];
+        ops.pa[q].get(av);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) msk[e] = av[e] > 0.f ? 1.f : 0.f;
+      }
+      if (!ep.mask_after_residual) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= msk[e];
+      }
+      if (ep.residual) {
+        float rv[8];
+        ops.pr[q].get(rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+      }
+      if (ep.mask_after_residual) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= msk[e];
+      }
+      if (ep.out_f32) {
+        store8((float*)ep.out + ops.gix[q], v);
+      } else {
+        store8((T*)ep.out + ops.gix[q], v);
+        round8_bf16(v);   // statistics of what was stored
+      }
+      if (ep.bn_y) {
+        float yv[8];
+        ops.py[q].get(yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * (yv[e] - bn_mean[e]); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+      }
+    }
+    lds_barrier();
+  }
+  if (ep.colsum) {
+    float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
+    float* red = (float*)smem;                      // [RPSE][CPRE*16]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + e] = csum[e];
+      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + 8 + e] = csq[e];
+    }
+    lds_barrier();
+    for (int idx = tid; idx < CPRE * 16; idx += 512) {
+      float sacc = 0.f;
+      for (int r = 0; r < RPSE; ++r) sacc += red[r * (CPRE * 16) + idx];
+      const int chunk = idx / 16, e = idx % 16;
+      const int col = n0 + chunk * 8 + (e & 7);
+      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
     }
   }
 }
@@ -414,6 +589,11 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(LA la, LB lb, Epilogue 
     for (int j = 0; j < RN; ++j) boff[j][ks] = LB::frag_off(wn0 + j * 32, kg * KS + ks, lane);
   }
 
+  // BatchNorm-backward form: the epilogue's first-pass operands are requested now, ahead of the prologue DMA (vmcnt counts in issue order, so
+  // the first K tile's wait also covers them: their HBM latency overlaps the ring fill instead of opening the epilogue)
+  constexpr bool EARLY_BN = EPI == 1 && WideBnOperands<CFG>::EARLY;
+  WideBnOperands<CFG> bnops;
+  if constexpr (EARLY_BN) bnops.request(0, ep, rm, M, N, m0, n0, tid);
 #pragma unroll
   for (int pz = 0; pz < NSTAGE - 1; ++pz) {
     if (t_begin + pz < t_end) {
@@ -456,7 +636,8 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(LA la, LB lb, Epilogue 
     if (++buf == NSTAGE) buf = 0;
   }
   lds_barrier();          // no DMA outstanding; every wave is past its last fragment read: the LDS is free for the epilogue
-  wide_epilogue<CFG, EPI>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, kg, wm0, wn0);
+  if constexpr (EARLY_BN) wide_epilogue_bn<CFG>(acc, bnops, ep, rm, smem, M, N, m0, n0, tid, lane, kg, wm0, wn0);
+  else wide_epilogue<CFG, EPI>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, kg, wm0, wn0);
 }
 
 }  // namespace clite

@@ -115,14 +115,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
   }
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > p.M) row_end = p.M;
+  // four lanes fold their mask bytes into one dword below: that needs the four chunks of a quad in one row (CPR % 4 == 0; C = 8 or 16 keep
+  // byte stores) and every lane of a wave in the loop together, hence the wave-uniform trip count with a per-lane `live` predicate
+  const bool pack = (CPR & 3) == 0;
 #pragma unroll 4
-  for (int r = row_begin + r0; r < row_end; r += RPS) {
-    size_t idx = (size_t)r * p.C + c0;
+  for (int rb = row_begin; rb < row_end; rb += RPS) {
+    const int r = rb + r0;
+    const bool live = r < row_end;
+    size_t idx = live ? (size_t)r * p.C + c0 : 0;
     float v[8];
-    ld8<NT>(y + idx, v);
+    zero8(v);
+    if (live) ld8<NT>(y + idx, v);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[e]) * k.a[e] + k.b[e];
-    if (res) {
+    if (res && live) {
       float rv[8];
       load8(res + idx, rv);
       if (res_affine) {
@@ -136,15 +142,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
     if (p.relu) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      if (p.relu_bits) {
+        // the ReLU mask for the backward pass: one byte per 8 channels; consecutive threads own consecutive bytes (byte index = row * C/8 + chunk
+        // = a workgroup constant + tid). A 64-lane byte store costs the memory pipeline about what the 16-byte data store next to it costs
+        // (bn_apply +4 % in the step), so the four lanes of a quad fold their bytes into one dword (two xor-shuffles) and lane 0 of the quad
+        // stores it. Taken from the value as it is stored: (T)v > 0 and v > 0 agree for bf16 / f32 (same exponent range, no flush on conversion).
+        uint32_t b = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b |= (v[e] > 0.f ? 1u : 0u) << e;
+        if (pack) {
+          b |= (uint32_t)wave_shfl_xor_i((int)b, 1) << 8;
+          b |= (uint32_t)wave_shfl_xor_i((int)b, 2) << 16;
+          if (live && (tid & 3) == 0) *(uint32_t*)(p.relu_bits + (idx >> 3)) = b;
+        } else if (live) {
+          p.relu_bits[idx >> 3] = (uint8_t)b;
+        }
+      }
     }
-    st8<NT>(out + idx, v);
+    if (live) st8<NT>(out + idx, v);
   }
 }
 
 // dstats[0][c] += sum dz, dstats[1][c] += sum dz*(y - mean_c), with dz = dout * (mask > 0) and mean_c = stats[0][c]/M.
 // Centering y here (instead of forming sum dz*y - mean*sum dz afterwards) avoids cancellation on channels with |mean| >> std.
 template <typename T, bool NT>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ mask, const T* __restrict__ y, const float* stats, float* dstats, int R, int RS, int M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ mask, const uint8_t* __restrict__ mbits, const T* __restrict__ y, const float* stats, float* dstats, int R, int RS, int M, int C, int rows_per_block) {
   __shared__ float red[256 * 16];
   const int CPR = C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
@@ -161,7 +183,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     float d[8], yv[8];
     ld8<NT>(dout + idx, d);
     ld8<NT>(y + idx, yv);
-    if (mask) {
+    if (mbits) {
+      const uint32_t b = mbits[idx >> 3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = (b >> e) & 1u ? d[e] : 0.f;
+    } else if (mask) {
       float m[8];
       load8(mask + idx, m);
 #pragma unroll
@@ -213,7 +239,7 @@ __global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* __restric
 
 // dy = gamma*rstd*(dz - S1/M - xhat*G/M), G = sum dz*xhat = rstd*S2 (S2 = sum dz*(y-mean) from the reduce kernel); dgamma += G, dbeta += S1
 template <typename T, bool NT>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* __restrict__ dout, const T* __restrict__ mask, const T* __restrict__ y, const float* dstats,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* __restrict__ dout, const T* __restrict__ mask, const uint8_t* __restrict__ mbits, const T* __restrict__ y, const float* dstats,
                                                            T* __restrict__ dy, T* __restrict__ dz_out, float* dgamma, float* dbeta, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
@@ -249,7 +275,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
     float d[8], yv[8];
     ld8<NT>(dout + idx, d);
     ld8<NT>(y + idx, yv);
-    if (mask) {
+    if (mbits) {
+      const uint32_t b = mbits[idx >> 3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = (b >> e) & 1u ? d[e] : 0.f;
+    } else if (mask) {
       float m[8];
       load8(mask + idx, m);
 #pragma unroll
@@ -681,40 +711,40 @@ extern "C" int clite_bn_centered_var(int dtype, const void* y, float* stats, int
   return (int)hipGetLastError();
 }
 
-extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, const float* stats, float* dstats, int replicas, int rstride,
-                                   int M, int C, void* stream) {
-  if (!bn_ok(M, C) || !dout || !y || !stats || !dstats || replicas < 1) return -1;
+extern "C" int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const uint8_t* mask_bits, const void* y, const float* stats, float* dstats,
+                                   int replicas, int rstride, int M, int C, void* stream) {
+  if (!bn_ok(M, C) || !dout || !y || !stats || !dstats || replicas < 1 || (mask && mask_bits)) return -1;
   int rpb;
   int grid = bn_grid_reduce(M, C, replicas, &rpb);
   hipStream_t st = (hipStream_t)stream;
   const bool nt = (size_t)M * C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
   if (nt) {
     DISPATCH(dtype,
-             hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, stats, dstats, replicas, rstride, M, C, rpb),
-             hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, stats, dstats, replicas, rstride, M, C, rpb));
+             hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, mask_bits, (const bf16*)y, stats, dstats, replicas, rstride, M, C, rpb),
+             hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, mask_bits, (const float*)y, stats, dstats, replicas, rstride, M, C, rpb));
   } else {
     DISPATCH(dtype,
-             hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, stats, dstats, replicas, rstride, M, C, rpb),
-             hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, (const float*)y, stats, dstats, replicas, rstride, M, C, rpb));
+             hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, (const bf16*)dout, (const bf16*)mask, mask_bits, (const bf16*)y, stats, dstats, replicas, rstride, M, C, rpb),
+             hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)dout, (const float*)mask, mask_bits, (const float*)y, stats, dstats, replicas, rstride, M, C, rpb));
   }
   return (int)hipGetLastError();
 }
 
-extern "C" int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const void* y, const float* dstats,
+extern "C" int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const uint8_t* mask_bits, const void* y, const float* dstats,
                                   void* dy, void* dz, float* dgamma, float* dbeta, void* stream) {
-  if (!p || !bn_ok(p->M, p->C) || !dout || !y || !dstats || !dy || p->replicas < 1) return -1;
+  if (!p || !bn_ok(p->M, p->C) || !dout || !y || !dstats || !dy || p->replicas < 1 || (mask && mask_bits)) return -1;
   int rpb;
   int grid = bn_grid(p->M, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
   const bool nt = (size_t)p->M * p->C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
   if (nt) {
     DISPATCH(dtype,
-             hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),
-             hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, *p, (const float*)dout, (const float*)mask, (const float*)y, dstats, (float*)dy, (float*)dz, dgamma, dbeta, rpb));
+             hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, mask_bits, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),
+             hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(grid), dim3(256), 0, st, *p, (const float*)dout, (const float*)mask, mask_bits, (const float*)y, dstats, (float*)dy, (float*)dz, dgamma, dbeta, rpb));
   } else {
     DISPATCH(dtype,
-             hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),
-             hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(grid), dim3(256), 0, st, *p, (const float*)dout, (const float*)mask, (const float*)y, dstats, (float*)dy, (float*)dz, dgamma, dbeta, rpb));
+             hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, false>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, mask_bits, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),
+             hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false>), dim3(grid), dim3(256), 0, st, *p, (const float*)dout, (const float*)mask, mask_bits, (const float*)y, dstats, (float*)dy, (float*)dz, dgamma, dbeta, rpb));
   }
   return (int)hipGetLastError();
 }

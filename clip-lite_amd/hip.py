@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -28,7 +28,7 @@ class Epilogue(C.Structure):
         ("drop_site", C.c_uint32), ("residual", C.c_void_p), ("colsum", C.c_void_p),
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
-        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("splitk_ws", C.c_void_p),
+        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("relu_bits", C.c_void_p), ("splitk_ws", C.c_void_p),
     ]
 
 
@@ -42,7 +42,7 @@ class Bn(C.Structure):
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("training", C.c_int32),
         ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32), ("replicas", C.c_int32), ("rstride", C.c_int32), ("centered", C.c_int32),
         ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
-        ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p),
+        ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p), ("relu_bits", C.c_void_p),
     ]
 
 
@@ -79,8 +79,8 @@ _SIGNATURES = {
     "clite_stem_unpack_grad": [_V, _V, _V],
     "clite_bn_apply": [_V, _I, _V, _V, _V, _V],
     "clite_bn_centered_var": [_I, _V, _V, _I, _I, _I, _I, _V],
-    "clite_bn_bwd_reduce": [_I, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V],
-    "clite_bn_bwd_apply": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V],
+    "clite_bn_bwd_reduce": [_I, _V, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V],
+    "clite_bn_bwd_apply": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _V],
     "clite_maxpool3x3s2_fwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_maxpool3x3s2_bwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_stem_bn_pool_fwd": [_V, _I, _V, _V, _V, _I, _I, _I, _V],
@@ -204,8 +204,9 @@ class Stats:
 
 
 def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
-             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False, ws=None):
-    """bn = (y, stats: Stats, rows): accumulate the BatchNorm-backward reductions (sum v, sum v*(y - mean)) into `colsum`."""
+             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False, ws=None, relu_bits=None):
+    """bn = (y, stats: Stats, rows): accumulate the BatchNorm-backward reductions (sum v, sum v*(y - mean)) into `colsum`.
+    relu_bits: the relu' mask of that form as packed bits (uint8 [M][ldc / 8], written by bn_apply) instead of dact_aux."""
     ep = Epilogue()
     ep.out = p(out)
     ep.ldc = ldc if ldc is not None else out.shape[-1]
@@ -228,6 +229,7 @@ def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, pr
         y, st, rows = bn
         ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = p(y), p(st.t), st.R, st.rstride, 1.0 / rows
     ep.mask_after_residual = int(mask_after_residual)
+    ep.relu_bits = p(relu_bits)
     ep.splitk_ws = p(ws)        # zeroed f32 [M][N] workspace: allows split-K for GEMMs of few output tiles (clite_epilogue.splitk_ws)
     return ep
 
@@ -408,8 +410,8 @@ def stem_unpack_grad(dwv, dw):
 
 
 # ------------------------------------------------------------------------------------------------ BN / pools
-def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, eps, relu, res_bn=None, centered=False):
-    """stats: hip.Stats (training) or None (eval: running statistics)."""
+def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, eps, relu, res_bn=None, centered=False, relu_bits=None):
+    """stats: hip.Stats (training) or None (eval: running statistics). relu_bits: uint8 [M][C / 8] that bn_apply fills with the packed ReLU mask."""
     b = Bn()
     b.M, b.C = M, Cc
     b.centered = int(centered)
@@ -421,6 +423,7 @@ def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, 
         rs, rg, rb, rrm, rrv = res_bn
         b.res_stats = p(rs.t) if rs is not None else None
         b.res_gamma, b.res_beta, b.res_running_mean, b.res_running_var = p(rg), p(rb), p(rrm), p(rrv)
+    b.relu_bits = p(relu_bits)
     return b
 
 
@@ -432,13 +435,22 @@ def bn_apply(dt, bn, y, res, out):
     check(lib().clite_bn_apply(C.byref(bn), dt, p(y), p(res), p(out), stream_ptr(y)), "bn_apply")
 
 
+def _mask_args(mask):
+    """A ReLU mask is either a tensor of the compute dtype (sign test) or packed bits (uint8, as bn_apply's relu_bits writes them)."""
+    if mask is not None and mask.dtype == torch.uint8:
+        return None, p(mask)
+    return p(mask), None
+
+
 def bn_bwd_reduce(dt, dout, mask, y, stats, dstats, M, Cc):
     assert stats.R == dstats.R
-    check(lib().clite_bn_bwd_reduce(dt, p(dout), p(mask), p(y), p(stats.t), p(dstats.t), stats.R, stats.rstride, M, Cc, stream_ptr(y)), "bn_bwd_reduce")
+    mt, mb = _mask_args(mask)
+    check(lib().clite_bn_bwd_reduce(dt, p(dout), mt, mb, p(y), p(stats.t), p(dstats.t), stats.R, stats.rstride, M, Cc, stream_ptr(y)), "bn_bwd_reduce")
 
 
 def bn_bwd_apply(dt, bn, dout, mask, y, dstats, dy, dz, dgamma, dbeta):
-    check(lib().clite_bn_bwd_apply(C.byref(bn), dt, p(dout), p(mask), p(y), p(dstats.t), p(dy), p(dz), p(dgamma), p(dbeta), stream_ptr(y)),
+    mt, mb = _mask_args(mask)
+    check(lib().clite_bn_bwd_apply(C.byref(bn), dt, p(dout), mt, mb, p(y), p(dstats.t), p(dy), p(dz), p(dgamma), p(dbeta), stream_ptr(y)),
           "bn_bwd_apply")
 
 

@@ -109,20 +109,26 @@ class ResNet(nn.Module):
 # ---------------------------------------------------------------------------------------------------- executor
 class _Unit:
     """Saved tensors of one conv->BN unit."""
-    __slots__ = ("conv", "bn", "cv", "x", "y", "stats", "out")
+    __slots__ = ("conv", "bn", "cv", "x", "y", "stats", "out", "bits")
 
 
 def _alloc(rt, *shape):
     return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
 
 
-def _bn_desc(rt, bn, M, stats, relu, training, res=None):
+def _bn_desc(rt, bn, M, stats, relu, training, res=None, bits=None):
     res_bn = None
     if res is not None:
         rbn, rstats = res
         res_bn = (rstats, rbn.weight, rbn.bias, rbn.running_mean, rbn.running_var)
     return hip.bn_desc(M, bn.num_features, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                       training, training, bn.momentum, bn.eps, relu, res_bn, centered=rt.precise_bn)
+                       training, training, bn.momentum, bn.eps, relu, res_bn, centered=rt.precise_bn, relu_bits=bits)
+
+
+def _relu_bits(rt, M, Cc, training):
+    """Packed ReLU mask of a [M][Cc] activation (one bit per element, written by bn_apply): what the backward pass reads instead of the
+    activation itself wherever only its sign matters — the BatchNorm-backward dgrad epilogues and the BN backward kernels."""
+    return torch.empty(M, Cc // 8, device=rt.device, dtype=torch.uint8) if training else None
 
 
 def _conv(rt, x, N, H, W, conv, training):
@@ -210,8 +216,9 @@ def resnet_forward(rt, net, image, training, staged=None):
             M = N * Hh * Wh
             last = i == len(specs) - 1
             u.out = _alloc(rt, M, conv.out_channels)
+            u.bits = _relu_bits(rt, M, conv.out_channels, training)
             if not last:
-                hip.bn_apply(dt, _bn_desc(rt, bn, M, u.stats, True, training), u.y, None, u.out)
+                hip.bn_apply(dt, _bn_desc(rt, bn, M, u.stats, True, training, bits=u.bits), u.y, None, u.out)
             units.append(u)
             h = u.out
         ud = None
@@ -220,9 +227,9 @@ def resnet_forward(rt, net, image, training, staged=None):
         if blk.downsample is not None:
             ud = _conv(rt, xin, N, Hin, Win, blk.downsample[0], training)
             ud.bn = blk.downsample[1]
-            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, res=(ud.bn, ud.stats)), last.y, ud.y, last.out)
+            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, res=(ud.bn, ud.stats), bits=last.bits), last.y, ud.y, last.out)
         else:
-            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training), last.y, xin, last.out)
+            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, bits=last.bits), last.y, xin, last.out)
         recs.append((units, ud, Hin, Win))
         x, Hc, Wc = last.out, Hh, Wh
     Cout = net.out_dim
@@ -233,7 +240,7 @@ def resnet_forward(rt, net, image, training, staged=None):
 
 
 def _bn_backward(rt, u, dout, mask, N, want_dz=False, train_params=True):
-    """BN backward of unit u given dout (gradient w.r.t. the post-BN tensor) and the ReLU mask tensor (or None)."""
+    """BN backward of unit u given dout (gradient w.r.t. the post-BN tensor) and the ReLU mask (packed bits, an activation tensor, or None)."""
     M, Cc = u.y.shape
     dstats = rt.new_stats(Cc)
     hip.bn_bwd_reduce(rt.dt, dout, mask, u.y, u.stats, dstats, M, Cc)
@@ -303,9 +310,9 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         # block output = relu(bn_last(y_last) + shortcut): the mask is the block output itself
         dyd = None
         if pre is None:
-            dy, dz = _bn_backward(rt, last, dout, last.out, N, want_dz=identity)
+            dy, dz = _bn_backward(rt, last, dout, last.bits, N, want_dz=identity)
             if ud is not None:
-                dyd, _ = _bn_backward(rt, ud, dout, last.out, N)
+                dyd, _ = _bn_backward(rt, ud, dout, last.bits, N)
         else:
             dz = dout
             dy = _bn_backward_apply(rt, last, dz, pre)
@@ -321,11 +328,11 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
             if i > 0 and not rt.fuse_bn_backward:
                 hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin))
                 prev = units[i - 1]
-                dy, _ = _bn_backward(rt, prev, dx, prev.out, N)
+                dy, _ = _bn_backward(rt, prev, dx, prev.bits, N)
             elif i > 0:
                 prev = units[i - 1]
                 dstats = rt.new_stats(Cin)
-                mk = lambda: hip.epilogue(dx, Cin, dact_aux=prev.out, dact=hip.DACT_RELU, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0]))
+                mk = lambda: hip.epilogue(dx, Cin, relu_bits=prev.bits, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0]))
                 if rt.s2_classes and hip.s2_classes_ok(u.cv):
                     hip.conv_dgrad_s2(dy, rt.arena.w(u.conv.weight), u.cv, mk,       # 3x3 / stride 2: four parity classes, no zero taps
                                       wsubs=(ctx.get("s2w") or {}).get(id(u.conv)))
@@ -338,7 +345,7 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                     pl = recs[bi - 1][0][-1]          # the previous block's last unit consumes this gradient
                     pre = rt.new_stats(Cin)
                     hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv,
-                                   hip.epilogue(dx, Cin, residual=dz, dact_aux=pl.out, dact=hip.DACT_RELU, mask_after_residual=True, colsum=pre,
+                                   hip.epilogue(dx, Cin, residual=dz, relu_bits=pl.bits, mask_after_residual=True, colsum=pre,
                                                 bn=(pl.y, pl.stats, pl.y.shape[0])))
                 else:
                     hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None))

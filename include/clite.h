@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 7
+#define CLITE_ABI_VERSION 8
 int clite_abi_version(void);
 
 /* Deterministic-reduction mode (process-wide, default off; the counterpart of torch.use_deterministic_algorithms for this library).
@@ -88,6 +88,9 @@ typedef struct clite_epilogue {
   int32_t bn_rstride;
   float bn_inv_count;       /* 1 / rows of the BatchNorm */
   int32_t mask_after_residual;
+  const uint8_t* relu_bits; /* BatchNorm-backward form only (bn_y / mask_after_residual): the relu' mask as PACKED BITS instead of dact_aux — bit (c & 7)
+                             * of byte (row * ldc + c) / 8 is 1 where the forward activation was > 0 (written by clite_bn_apply, clite_bn.relu_bits):
+                             * 1/16 of the bytes of reading the bf16 activation for its sign. NULL: dact_aux (if any) supplies the mask. */
   float* splitk_ws;         /* optional f32 [M][N] workspace, ZERO on entry (left dirty): lets clite_gemm_nt / _nn run a GEMM of few output tiles
                              * (the M = 128/256-row GEMMs of the projection heads and prior discriminators) as split-K over all CUs — partial
                              * sums accumulate here with float atomics and a second small kernel applies this epilogue. NULL: never split. */
@@ -189,6 +192,8 @@ typedef struct clite_bn {
   const float* res_beta;
   float* res_running_mean;
   float* res_running_var;
+  uint8_t* relu_bits;        /* clite_bn_apply with relu = 1: optional [M][C / 8] bytes, bit e of byte (m * C + c) / 8 = (out[m][c + e] > 0): the
+                              * ReLU mask the backward pass needs, at 1/16 of the bytes of re-reading `out` for its sign. NULL: not written. */
 } clite_bn;
 
 /* Second pass of a two-pass variance (used by the exact-f32 parity mode): stats[2][c] += sum_m (y[m][c] - stats[0][c]/M)^2;
@@ -197,11 +202,12 @@ int clite_bn_centered_var(int dtype, const void* y, float* stats, int replicas, 
 /* out = relu?( bn(y) + [res | bn_res(res)] ) */
 int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const void* res, void* out, void* stream);
 /* dstats[0][c] += sum dz, dstats[1][c] += sum dz*(y - mean_c), dz = dout * (mask > 0) (mask NULL: dz = dout), mean_c = stats[0][c]/M.
- * dstats pre-zeroed. */
-int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const void* y, const float* stats, float* dstats, int replicas, int rstride,
-                        int M, int C, void* stream);   /* stats and dstats are both replicated (R, rstride) */
+ * The mask is either a tensor of the call's dtype (`mask`) or packed bits as clite_bn.relu_bits writes them (`mask_bits`); at most one of
+ * the two. dstats pre-zeroed. */
+int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const uint8_t* mask_bits, const void* y, const float* stats, float* dstats,
+                        int replicas, int rstride, int M, int C, void* stream);   /* stats and dstats are both replicated (R, rstride) */
 /* dy = BN backward of dz through batch statistics; dz (optional) <- masked dout; dgamma/dbeta (optional) += . */
-int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const void* y, const float* dstats,
+int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const uint8_t* mask_bits, const void* y, const float* dstats,
                        void* dy, void* dz, float* dgamma, float* dbeta, void* stream);
 
 /* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem; idx holds the window position (0..8) of the first maximum. */

@@ -507,3 +507,39 @@ def train_step(model, optimizer, batch, step, sched=("cosine", 500000, 10000, 0.
     gn = torch.nn.utils.clip_grad_norm_([p for g in optimizer.param_groups for p in g["params"]], clip)
     optimizer.step()
     return out, gn
+
+
+def train_step_shardwise(model, optimizer, shards, step, sched=("cosine", 500000, 10000, 0.0), clip=10.0, noises=None):
+    """One DATA-PARALLEL step of the reference (train.py:174-178: DistributedDataParallel) emulated in one process, SURVEY.md §8(e): every rank
+    runs the model on ITS shard — its own BatchNorm batch statistics, its own roll-by-one negatives (loss.py:214-216), its own prior noise —
+    DDP averages the per-rank gradients, and every rank then clips and steps on that mean. This is NOT a step on the concatenated batch.
+    `shards[r]` is rank r's batch, `noises[r]` its (image, text) prior noise. BatchNorm running statistics are rank-local under DDP and rank 0's
+    are the ones that get checkpointed (utils/checkpointing.py:137-143): the buffers this function leaves in `model` are rank 0's.
+    Returns ([per-rank output dicts], gradient norm before clipping)."""
+    name, total, warm, min_mult = sched
+    mult = lr_multiplier(name, step, total, warm, min_mult)
+    for g in optimizer.param_groups:
+        g["lr"] = g["initial_lr"] * mult
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    mean_grad = [torch.zeros_like(p) for p in params]
+    outs = [None] * len(shards)
+    for r in reversed(range(len(shards))):            # rank 0 last: its buffer updates are the ones that stay
+        saved = {k: v.detach().clone() for k, v in model.named_buffers()}
+        if noises is not None:
+            model.loss.noise = noises[r]
+        optimizer.zero_grad()
+        outs[r] = model(shards[r])
+        outs[r]["loss"].backward()
+        for a, p in zip(mean_grad, params):
+            if p.grad is not None:
+                a += p.grad / len(shards)
+        if r != 0:
+            with torch.no_grad():
+                for k, v in model.named_buffers():
+                    v.copy_(saved[k])
+    for a, p in zip(mean_grad, params):
+        p.grad = a
+    gn = torch.nn.utils.clip_grad_norm_(params, clip)
+    optimizer.step()
+    return outs, gn
+

@@ -22,7 +22,7 @@ class Epilogue(C.Structure):
         ("drop_site", C.c_uint32), ("residual", C.c_void_p), ("colsum", C.c_void_p),
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
-        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("splitk_ws", C.c_void_p),
+        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("relu_bits", C.c_void_p), ("splitk_ws", C.c_void_p),
     ]
 
 
@@ -66,13 +66,18 @@ def ptr(a):
 
 
 def make_ep(out, ldc, out_f32=False, atomic=False, alpha=1.0, bias=None, act=0, preact=None, dact_aux=None,
-            dact=0, drop_p=0.0, drop_seed=0, drop_site=0, residual=None, colsum=None):
+            dact=0, drop_p=0.0, drop_seed=0, drop_site=0, residual=None, colsum=None, relu_bits=None):
     ep = Epilogue()
     ep.out = ptr(out); ep.ldc = ldc; ep.out_f32 = int(out_f32); ep.atomic = int(atomic); ep.alpha = alpha
     ep.bias = ptr(bias); ep.act = act; ep.preact = ptr(preact); ep.dact_aux = ptr(dact_aux); ep.dact = dact
     ep.drop_p = drop_p; ep.drop_seed = drop_seed; ep.drop_site = drop_site
-    ep.residual = ptr(residual); ep.colsum = ptr(colsum)
+    ep.residual = ptr(residual); ep.colsum = ptr(colsum); ep.relu_bits = ptr(relu_bits)
     return ep
+
+
+def pack_relu_bits(a):
+    """[M][C] activations -> uint8 [M][C / 8]: bit e of byte (m, c / 8) = a[m][c + e] > 0 (clite_bn.relu_bits layout)."""
+    return np.packbits(np.asarray(a) > 0, axis=-1, bitorder="little")
 
 
 class Bn(C.Structure):
@@ -81,7 +86,7 @@ class Bn(C.Structure):
         ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("training", C.c_int32),
         ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32), ("replicas", C.c_int32), ("rstride", C.c_int32), ("centered", C.c_int32),
         ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
-        ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p),
+        ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p), ("relu_bits", C.c_void_p),
     ]
 
 

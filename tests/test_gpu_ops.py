@@ -7,6 +7,7 @@ bf16 BACKWARD check of ResNet-50 + BERT at a conditioned size against the fp32 o
 Tolerances (stated per test): fp32 accumulation everywhere, so against an fp32 reference on the same inputs the error is one bf16 rounding of
 the output (2^-9 relative per element) plus the bf16 rounding of intermediate operands the kernel keeps in bf16 (attention probabilities,
 dS): a few 1e-3 of the tensor's max."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -99,8 +100,13 @@ def test_attention_mfma_dropout_masks_regenerate_in_backward():
     assert _rel(dqkv, q32.grad) < 2e-2
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("N,H,W,Cc,K,R,st,pad,after", [(4, 14, 14, 256, 256, 3, 1, 1, 0), (2, 28, 28, 128, 512, 1, 1, 0, 1), (8, 7, 7, 512, 2048, 1, 1, 0, 1), (2, 14, 14, 64, 64, 3, 1, 1, 0)])
+# the last three shapes have more output tiles than the 512 resident slots of igemm_dma_bn_kernel: the row-range persistent form (several
+# tiles per workgroup, the last one partial), at the bench's own sizes — 1024 <- 256 at 14 x 14, 64 <- 256 at 56 x 56 (256-row tiles),
+# 512 <- 128 at 28 x 28 — under the automatic policy
+@pytest.mark.parametrize("policy,N,H,W,Cc,K,R,st,pad,after",
+                         [(p, *shp) for p in (0, 1, 2, 3, 4) for shp in [(4, 14, 14, 256, 256, 3, 1, 1, 0), (2, 28, 28, 128, 512, 1, 1, 0, 1), (8, 7, 7, 512, 2048, 1, 1, 0, 1),
+                                                                          (2, 14, 14, 64, 64, 3, 1, 1, 0)]] +
+                         [(0, 128, 14, 14, 1024, 256, 1, 1, 0, 1), (0, 127, 56, 56, 64, 256, 1, 1, 0, 0), (0, 125, 28, 28, 512, 128, 1, 1, 0, 1)])
 def test_bn_backward_dgrad_epilogue_bf16(policy, N, H, W, Cc, K, R, st, pad, after):
     """conv dgrad with the BatchNorm-backward epilogue in bf16 (every tile family): dz = (dgrad [* relu'(aux)] + residual) [* relu'(aux)] stored
     in bf16, and the two reductions (sum dz, sum dz*(y - mean)) of the stored values. Bound: 4e-3 of max on dz (one bf16 rounding), 5e-3 on the
@@ -133,8 +139,47 @@ def test_bn_backward_dgrad_epilogue_bf16(policy, N, H, W, Cc, K, R, st, pad, aft
         got = dst.t.sum(0)
         stored = dz.float()
         assert _rel(got[0], stored.sum(0)) < 5e-3 and _rel(got[1], (stored * (y.float() - mean)).sum(0)) < 5e-3
+        # the mask as packed bits (what the ResNet executor passes: clite_epilogue.relu_bits, written by bn_apply): bit-identical dz
+        bits = torch.from_numpy(np.packbits((aux.float() > 0).cpu().numpy(), axis=-1, bitorder="little")).cuda()
+        dz2 = torch.empty_like(dz)
+        dst2 = hip.Stats(torch.zeros(8, 3, Cc, device="cuda"), 8, Cc)
+        hip.conv_dgrad(dy, w, cv, hip.epilogue(dz2, Cc, residual=res, relu_bits=bits, mask_after_residual=bool(after), colsum=dst2, bn=(y, fst, M)))
+        assert torch.equal(dz2, dz)
+        assert _rel(dst2.t.sum(0)[:2], got[:2]) < 1e-4
     finally:
         hip.set_tile_policy(0)
+
+
+@pytest.mark.parametrize("dt", [BF16, F32])
+@pytest.mark.parametrize("M,Cc,res", [(6272, 2048, True), (25088, 256, False), (401408, 64, False)])
+def test_bn_apply_writes_packed_relu_bits_and_backward_reads_them(dt, M, Cc, res):
+    """bn_apply's relu_bits (one bit per element: out > 0) and the BatchNorm backward kernels on that mask against the tensor-mask form:
+    the bits equal (out > 0) exactly, reductions agree to summation order, dy / dz are bit-identical."""
+    hip = _hip()
+    td = hip.TORCH_DTYPE[dt]
+    g = torch.Generator(device="cuda").manual_seed(M + Cc)
+    y = (torch.randn(M, Cc, device="cuda", generator=g) * 1.5 + 0.3).to(td)
+    r = torch.randn(M, Cc, device="cuda", generator=g).to(td) if res else None
+    st = hip.Stats(torch.zeros(8, 3, Cc, device="cuda"), 8, Cc)
+    st.t[:, 0] = y.float().sum(0) / 8
+    st.t[:, 1] = (y.float() ** 2).sum(0) / 8
+    gamma, beta = torch.rand(Cc, device="cuda", generator=g) + 0.5, torch.randn(Cc, device="cuda", generator=g) * 0.2
+    rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    out = torch.empty_like(y)
+    bits = torch.full((M, Cc // 8), 0x55, device="cuda", dtype=torch.uint8)
+    hip.bn_apply(dt, hip.bn_desc(M, Cc, st, gamma, beta, rm, rv, True, False, 0.1, 1e-5, True, relu_bits=bits), y, r, out)
+    want = torch.from_numpy(np.packbits((out.float() > 0).cpu().numpy(), axis=-1, bitorder="little")).cuda()
+    assert torch.equal(bits, want)
+    dout = torch.randn(M, Cc, device="cuda", generator=g).to(td)
+    d1, d2 = hip.Stats(torch.zeros(8, 3, Cc, device="cuda"), 8, Cc), hip.Stats(torch.zeros(8, 3, Cc, device="cuda"), 8, Cc)
+    hip.bn_bwd_reduce(dt, dout, out, y, st, d1, M, Cc)
+    hip.bn_bwd_reduce(dt, dout, bits, y, st, d2, M, Cc)
+    assert _rel(d2.t.sum(0)[:2], d1.t.sum(0)[:2]) < 1e-5
+    desc = hip.bn_desc(M, Cc, st, gamma, beta, rm, rv, True, False, 0.1, 1e-5, False)
+    dy1, dz1, dy2, dz2 = (torch.empty_like(y) for _ in range(4))
+    hip.bn_bwd_apply(dt, desc, dout, out, y, d1, dy1, dz1, None, None)
+    hip.bn_bwd_apply(dt, desc, dout, bits, y, d1, dy2, dz2, None, None)
+    assert torch.equal(dy1, dy2) and torch.equal(dz1, dz2)
 
 
 @pytest.mark.parametrize("N,H,W,Cc,K", [(4, 28, 28, 128, 128), (2, 14, 14, 256, 256), (3, 56, 56, 64, 64)])

@@ -20,10 +20,39 @@ def test_c_abi_library_exports_header_symbols():
     declared = sorted(set(re.findall(r"\bint (clite_\w+)\(", hdr)))
     assert declared == hip.exported_symbols()
     lib = hip.lib()                     # dlopen + bind every symbol + ABI version check
-    assert lib.clite_abi_version() == hip.ABI_VERSION == 7
+    assert lib.clite_abi_version() == hip.ABI_VERSION == 8
     raw = C.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
+
+
+def test_ctypes_signatures_match_header_prototypes():
+    """Every prototype of include/clite.h against the ctypes argument list in clip_lite_amd/hip.py: the same number of parameters, pointers bound
+    as pointers, integers / floats as such (a mismatch is a host-side crash or silent garbage on the GPU box, invisible to a CPU run)."""
+    from clip_lite_amd import hip
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "clite.h")).read(), flags=re.S)
+    protos = dict(re.findall(r"\bint (clite_\w+)\(([^;]*?)\);", hdr, flags=re.S))
+    assert set(protos) == set(hip._SIGNATURES)
+    kind = {C.c_void_p: "ptr", C.c_int: "int", C.c_int64: "i64", C.c_uint64: "u64", C.c_uint32: "u32", C.c_float: "float"}
+    for name, args in protos.items():
+        params = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
+        want = []
+        for a in params:
+            if "*" in a:
+                want.append("ptr")
+            elif re.match(r"(const )?uint64_t\b", a):
+                want.append("u64")
+            elif re.match(r"(const )?int64_t\b", a):
+                want.append("i64")
+            elif re.match(r"(const )?uint32_t\b", a):
+                want.append("u32")
+            elif re.match(r"(const )?float\b", a):
+                want.append("float")
+            else:
+                assert re.match(r"(const )?int\b", a), (name, a)
+                want.append("int")
+        got = [kind[t] for t in hip._SIGNATURES[name]]
+        assert got == want, (name, got, want)
 
 
 def test_ctypes_structs_match_header_layout(tmp_path):

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from simlib import Conv, bf16_round, from_bf16, lib, make_ep, ptr, to_bf16
+from simlib import Conv, bf16_round, from_bf16, lib, make_ep, pack_relu_bits, ptr, to_bf16
 
 BF16, F32 = 0, 1
 
@@ -105,10 +105,13 @@ def test_gemm_splitk_workspace_form(kind, M, N, K):
     _close(colsum[1], (got[:, :N] ** 2).sum(0), 1e-4)
 
 
-@pytest.mark.parametrize("dtype,N,H,W,Cc,K,R,S,st,pad", [(BF16, 2, 8, 8, 32, 64, 3, 3, 1, 1), (BF16, 3, 6, 6, 136, 64, 1, 1, 1, 0), (F32, 2, 9, 7, 64, 32, 3, 3, 2, 1)])
+@pytest.mark.parametrize("dtype,N,H,W,Cc,K,R,S,st,pad", [(BF16, 2, 8, 8, 32, 64, 3, 3, 1, 1), (BF16, 3, 6, 6, 136, 64, 1, 1, 1, 0), (F32, 2, 9, 7, 64, 32, 3, 3, 2, 1),
+                                                         (BF16, 5, 10, 10, 136, 64, 1, 1, 1, 0), (F32, 3, 11, 11, 40, 32, 1, 1, 1, 0)])
 def test_conv_dgrad_bn_backward_reductions(dtype, N, H, W, Cc, K, R, S, st, pad):
     """Epilogue form used by the ResNet backward (conv dgrad only): v = (acc + residual) * (aux > 0) stored, and
-    colsum <- (sum v, sum v*(y - mean)) with mean taken from replicated forward statistics (clite_epilogue.bn_y, mask_after_residual)."""
+    colsum <- (sum v, sum v*(y - mean)) with mean taken from replicated forward statistics (clite_epilogue.bn_y, mask_after_residual).
+    The last two cases have more tiles than the simulator build's 4 resident slots (CLITE_BN_SLOTS), i.e. they run the row-range
+    persistent form of igemm_dma_bn_kernel: several tiles per workgroup, the last one partial."""
     rng = np.random.default_rng(H * 3 + K)
     Ho = (H + 2 * pad - R) // st + 1
     Wo = (W + 2 * pad - S) // st + 1
@@ -138,6 +141,18 @@ def test_conv_dgrad_bn_backward_reductions(dtype, N, H, W, Cc, K, R, S, st, pad)
         _close(d[0], v.sum(0), 5e-3)
         _close(d[1], (v * (y - mean)).sum(0), 5e-3)
         assert not d[2].any()
+        # the same launch with the relu' mask as packed bits (clite_epilogue.relu_bits): identical output and reductions
+        out2 = np.zeros((M, Cc), np.float32)
+        dst2 = np.zeros((Rr, 3, Cc), np.float32)
+        bits = pack_relu_bits(aux)
+        ep2 = make_ep(out2, Cc, out_f32=True, residual=resb, colsum=dst2, relu_bits=bits)
+        ep2.colsum_replicas, ep2.colsum_stride = Rr, 3 * Cc
+        ep2.bn_y, ep2.bn_stats, ep2.bn_replicas, ep2.bn_rstride, ep2.bn_inv_count, ep2.mask_after_residual = ptr(yb), ptr(fstats), Rr, 3 * Cc, 1.0 / M, after
+        assert lib().clite_conv_dgrad(ptr(dyb), ptr(wb), C.byref(cv), C.byref(ep2), None) == 0
+        assert np.array_equal(out2, out)
+        _close(dst2.sum(0), d, 1e-5)
+        ep2.dact_aux, ep2.dact = ptr(auxb), 1                  # both forms of the mask at once: refused
+        assert lib().clite_conv_dgrad(ptr(dyb), ptr(wb), C.byref(cv), C.byref(ep2), None) == -1
 
 
 @pytest.mark.parametrize("dtype,M,N,K", [(BF16, 128, 128, 64), (BF16, 72, 136, 300), (BF16, 256, 8, 1000), (F32, 72, 136, 300)])

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from simlib import Bn, lib, outbuf, prep, ptr, val
+from simlib import Bn, lib, outbuf, pack_relu_bits, prep, ptr, val
 
 BF16, F32 = 0, 1
 
@@ -40,7 +40,10 @@ def test_bn_apply_and_backward(dtype, M, Cc, dual):
            ptr(rstats) if dual else None, ptr(g2) if dual else None, ptr(b2) if dual else None,
            ptr(rm2) if dual else None, ptr(rv2) if dual else None)
     out = outbuf((M, Cc), dtype)
+    bits = np.full((M, Cc // 8), 0xAA, np.uint8)            # the packed ReLU mask bn_apply writes for the backward pass (clite_bn.relu_bits)
+    p.relu_bits = ptr(bits)
     assert lib().clite_bn_apply(C.byref(p), dtype, ptr(yb), ptr(rb), ptr(out), None) == 0
+    assert np.array_equal(bits, pack_relu_bits(val(out, dtype)))
     mean, var = y.mean(0), y.var(0)
     xhat = (y - mean) / np.sqrt(var + 1e-5)
     z = xhat * gamma + beta
@@ -57,10 +60,14 @@ def test_bn_apply_and_backward(dtype, M, Cc, dual):
     outv = val(out, dtype)
     dout, doutb = prep(rng.standard_normal((M, Cc), dtype=np.float32), dtype)
     dstats = np.zeros((R, 3, Cc), np.float32)
-    assert lib().clite_bn_bwd_reduce(dtype, ptr(doutb), ptr(out), ptr(yb), ptr(stats), ptr(dstats), R, 3 * Cc, M, Cc, None) == 0
+    assert lib().clite_bn_bwd_reduce(dtype, ptr(doutb), ptr(out), None, ptr(yb), ptr(stats), ptr(dstats), R, 3 * Cc, M, Cc, None) == 0
     dz = dout * (outv > 0)
     _close(dstats.sum(0)[0], dz.sum(0), 1e-4)
     _close(dstats.sum(0)[1], (dz * (y - y.mean(0))).sum(0), 1e-4)
+    dstats_b = np.zeros((R, 3, Cc), np.float32)             # the same reductions with the mask as packed bits: identical sums
+    assert lib().clite_bn_bwd_reduce(dtype, ptr(doutb), None, ptr(bits), ptr(yb), ptr(stats), ptr(dstats_b), R, 3 * Cc, M, Cc, None) == 0
+    _close(dstats_b.sum(0), dstats.sum(0), 1e-6)
+    assert lib().clite_bn_bwd_reduce(dtype, ptr(doutb), ptr(out), ptr(bits), ptr(yb), ptr(stats), ptr(dstats_b), R, 3 * Cc, M, Cc, None) == -1
     # two-pass variance: the centered pass fills row 2; a BN apply with centered=1 must give the same output
     assert lib().clite_bn_centered_var(dtype, ptr(yb), ptr(stats), R, 3 * Cc, M, Cc, None) == 0
     _close(stats.sum(0)[2], ((y - y.mean(0)) ** 2).sum(0), 1e-4)
@@ -72,11 +79,15 @@ def test_bn_apply_and_backward(dtype, M, Cc, dual):
         _close(val(outc, dtype), ref, _tol(dtype))
     dy = outbuf((M, Cc), dtype); dzb = outbuf((M, Cc), dtype)
     dg = np.ones(Cc, np.float32); db = np.ones(Cc, np.float32)
-    assert lib().clite_bn_bwd_apply(C.byref(p), dtype, ptr(doutb), ptr(out), ptr(yb), ptr(dstats), ptr(dy), ptr(dzb), ptr(dg), ptr(db), None) == 0
+    p.relu_bits = None
+    assert lib().clite_bn_bwd_apply(C.byref(p), dtype, ptr(doutb), ptr(out), None, ptr(yb), ptr(dstats), ptr(dy), ptr(dzb), ptr(dg), ptr(db), None) == 0
     rstd = 1 / np.sqrt(var + 1e-5)
     dyref = gamma * rstd * (dz - dz.mean(0) - xhat * (dz * xhat).mean(0))
     _close(val(dy, dtype), dyref, _tol(dtype))
     _close(val(dzb, dtype), dz, _tol(dtype))
+    dy2 = outbuf((M, Cc), dtype); dzb2 = outbuf((M, Cc), dtype)
+    assert lib().clite_bn_bwd_apply(C.byref(p), dtype, ptr(doutb), None, ptr(bits), ptr(yb), ptr(dstats), ptr(dy2), ptr(dzb2), None, None, None) == 0
+    assert np.array_equal(dy2, dy) and np.array_equal(dzb2, dzb)          # bits and tensor masks select the same elements
     _close(dg, 1 + (dz * xhat).sum(0), 1e-3)
     _close(db, 1 + dz.sum(0), 1e-3)
 
@@ -161,10 +172,10 @@ def test_fused_stem_bn_pool_equals_unfused_sequence(dtype, N, H, W):
     da0 = outbuf((M, Cc), dtype)
     assert L.clite_maxpool3x3s2_bwd(dtype, ptr(dpoolb), ptr(i_ref), ptr(da0), N, H, W, Cc, None) == 0
     ds_ref = np.zeros((R, 3, Cc), np.float32)
-    assert L.clite_bn_bwd_reduce(dtype, ptr(da0), ptr(a0), ptr(yb), ptr(stats), ptr(ds_ref), R, 3 * Cc, M, Cc, None) == 0
+    assert L.clite_bn_bwd_reduce(dtype, ptr(da0), ptr(a0), None, ptr(yb), ptr(stats), ptr(ds_ref), R, 3 * Cc, M, Cc, None) == 0
     dy_ref = outbuf((M, Cc), dtype); dg_ref = np.ones(Cc, np.float32); db_ref = np.ones(Cc, np.float32)
     d = desc(rm_a, rv_a, 0)
-    assert L.clite_bn_bwd_apply(C.byref(d), dtype, ptr(da0), ptr(a0), ptr(yb), ptr(ds_ref), ptr(dy_ref), None, ptr(dg_ref), ptr(db_ref), None) == 0
+    assert L.clite_bn_bwd_apply(C.byref(d), dtype, ptr(da0), ptr(a0), None, ptr(yb), ptr(ds_ref), ptr(dy_ref), None, ptr(dg_ref), ptr(db_ref), None) == 0
     ds_f = np.zeros((R, 3, Cc), np.float32)
     dy_f = outbuf((M, Cc), dtype); dg_f = np.ones(Cc, np.float32); db_f = np.ones(Cc, np.float32)
     assert L.clite_stem_bn_pool_bwd(C.byref(d), dtype, ptr(dpoolb), ptr(i_f), ptr(yb), ptr(ds_f), ptr(dy_f), ptr(dg_f), ptr(db_f), N, H, W, None) == 0

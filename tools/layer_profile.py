@@ -62,6 +62,8 @@ def main():
                     ep = getattr(x, "_obj", None)
                     if isinstance(ep, hip.Epilogue):
                         extra = sum(1 for f in ("dact_aux", "bn_y", "residual", "preact") if getattr(ep, f)) * d[1] * d[2] * (4 if args.f32 else 2)
+                        if ep.relu_bits:
+                            extra += d[1] * d[2] // 8
                 recs.append((name, d[:4] + (d[4] + extra, None), e0, e1))
             return rc
         return timed

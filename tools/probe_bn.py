@@ -38,9 +38,15 @@ if __name__ == "__main__":
         d1 = hip.bn_desc(M, C, st, g, b, rm, rv, True, True, 0.1, 1e-5, True)
         d2 = hip.bn_desc(M, C, st, g, b, rm, rv, True, False, 0.1, 1e-5, False)
         t1 = timeit(lambda: hip.bn_apply(hip.BF16, d1, y, res, out))
+        bits = torch.empty(M, C // 8, device="cuda", dtype=torch.uint8)
+        d1b = hip.bn_desc(M, C, st, g, b, rm, rv, True, True, 0.1, 1e-5, True, relu_bits=bits)
+        t1b = timeit(lambda: hip.bn_apply(hip.BF16, d1b, y, res, out))
+        t2b = timeit(lambda: hip.bn_bwd_reduce(hip.BF16, dout, bits, y, st, dst, M, C))
+        t3b = timeit(lambda: hip.bn_bwd_apply(hip.BF16, d2, dout, bits, y, dst, dy, None, dg, db))
         t2 = timeit(lambda: hip.bn_bwd_reduce(hip.BF16, dout, out, y, st, dst, M, C))
         t3 = timeit(lambda: hip.bn_bwd_apply(hip.BF16, d2, dout, out, y, dst, dy, None, dg, db))
         e = M * C * 2
         print(f"M={M:8d} C={C:5d} x{n:2d}: apply(+res) {t1:7.1f} us {3 * e / t1 / 1e3:6.0f} GB/s | bwd_reduce {t2:7.1f} us {3 * e / t2 / 1e3:6.0f} GB/s | bwd_apply {t3:7.1f} us {4 * e / t3 / 1e3:6.0f} GB/s")
+        print(f"                       with packed relu bits: apply {t1b:7.1f} us | bwd_reduce {t2b:7.1f} us | bwd_apply {t3b:7.1f} us")
         tot[0] += n * t1; tot[1] += n * t2; tot[2] += n * t3
     print(f"weighted totals per step: apply {tot[0] / 1e3:.2f} ms, bwd_reduce {tot[1] / 1e3:.2f} ms, bwd_apply {tot[2] / 1e3:.2f} ms")
