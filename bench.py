@@ -138,11 +138,11 @@ def describe_launch(name, a, esz):
             return lab, P, cv.K, kk, esz * (Q * cv.C + P * cv.K + cv.K * kk)
         if name == "clite_conv_fwd_fp8":           # e4m3 operands (1 byte), bf16 output
             return lab + " fp8", P, cv.K, kk, Q * cv.C + cv.K * kk + esz * P * cv.K
-        if name == "clite_conv_dgrad_s2class":     # one input-parity class of a 3x3 / stride-2 dgrad: a quarter of the pixels, its own taps
+        if name in ("clite_conv_dgrad_s2class", "clite_conv_dgrad_s2class_wt"):     # one input-parity class of a 3x3 / stride-2 dgrad: a quarter of the pixels, its own taps
             ph, pw = a[3], a[4]
             taps = (1 if (ph + 1) & 1 else 2) * (1 if (pw + 1) & 1 else 2)
             return lab + f" class {ph}{pw}", Q // 4, cv.C, taps * cv.K, esz * (Q * cv.C // 4 + P * cv.K + cv.K * taps * cv.C)
-        if name == "clite_conv_dgrad":
+        if name in ("clite_conv_dgrad", "clite_conv_dgrad_wt"):
             return lab, Q, cv.C, cv.R * cv.S * cv.K, esz * (Q * cv.C + P * cv.K + cv.K * kk)
         return lab, cv.K, kk, P, esz * (Q * cv.C + P * cv.K) + 4 * cv.K * kk
     if name.startswith("clite_stem"):
@@ -159,7 +159,8 @@ def describe_launch(name, a, esz):
     return "linear", M, N, K, esz * (M * K + N * K + M * N)
 
 
-IGEMM_ENTRY_POINTS = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_dgrad_s2class", "clite_conv_wgrad",
+IGEMM_ENTRY_POINTS = ("clite_gemm_nt", "clite_gemm_nn", "clite_gemm_tn", "clite_conv_fwd", "clite_conv_dgrad", "clite_conv_dgrad_s2class", "clite_conv_dgrad_wt",
+                      "clite_conv_dgrad_s2class_wt", "clite_conv_wgrad",
                       "clite_stem_fwd", "clite_stem_wgrad", "clite_wgrad_group", "clite_gemm_nt_fp8", "clite_conv_fwd_fp8")
 
 

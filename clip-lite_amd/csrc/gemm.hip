@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void colstats_det_kernel(clite_epilogue ep, Ro
 #pragma unroll
     for (int r = 0; r < 8; ++r) s += red[r][j];
     const int e = j & 15, c = (blockIdx.x * 32 + (j >> 4)) * 8 + (e & 7);
-    if (c < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + c, s);      // the only contribution to this address in this launch
+    if (c < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + c, s);      // the only contribution to this address in this launch
   }
 }
 template <typename T>
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     for (int r = 0; r < 32; ++r) s += red[r][c][e];
     const int cc = (blockIdx.x * 8 + c) * 8 + (e & 7);
     float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
-    if (cc < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + cc, s);
+    if (cc < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + cc, s);
   }
 }
 
@@ -465,11 +465,35 @@ int conv_fwd(const void* x, const void* w, const clite_conv& c, const clite_epil
   return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.K, Ktot, 1, st);
 }
 
-template <typename T>
+// WT: the weight is given transposed, [C][R][S][K] — a k-contiguous (KC) operand like the forward's, instead of the k-strided XC image
+template <typename T, bool WT = false>
 int conv_dgrad(const void* dy, const void* w, const clite_conv& c, const clite_epilogue* ep, hipStream_t st) {
   constexpr int BK = Cfg<T>::BK;
   int M = c.N * c.H * c.W, Ktot = c.R * c.S * c.K;
   uint32_t yb = (uint32_t)((size_t)c.N * c.Ho * c.Wo * c.K * sizeof(T)), wb = (uint32_t)((size_t)c.K * c.R * c.S * c.C * sizeof(T));
+  if constexpr (WT) {
+    if (c.R == 1 && c.S == 1 && c.pad == 0 && c.stride > 1 && ep->residual == ep->out && !ep->colsum && !ep->preact && !ep->dact_aux) {
+      int P = c.N * c.Ho * c.Wo;      // strided 1x1 shortcut: dense GEMM over the output pixels, rows scattered (see below)
+      RowMap rm;
+      rm.on = 1; rm.div_hw = fastdiv_make(c.Ho * c.Wo); rm.div_w = fastdiv_make(c.Wo); rm.H = c.H; rm.W = c.W; rm.stride = c.stride; rm.off_h = 0; rm.off_w = 0;
+      if (c.C <= 64) {
+        GatherKC<T, 256, BK, false> la{dy, yb, geom_dense(P, c.K)};
+        GatherKC<T, 64, BK, false> lb{w, wb, geom_dense(c.C, c.K)};
+        return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, P, c.C, c.K, 1, st, rm);
+      }
+      GatherKC<T, 128, BK, false> la{dy, yb, geom_dense(P, c.K)};
+      GatherKC<T, 128, BK, false> lb{w, wb, geom_dense(c.C, c.K)};
+      return launch<T, typename Cfg<T>::C128>(la, lb, *ep, P, c.C, c.K, 1, st, rm);
+    }
+    if (c.C <= 64) {
+      GatherKC<T, 256, BK, true> la{dy, yb, geom_dgrad(c)};
+      GatherKC<T, 64, BK, false> lb{w, wb, geom_dense(c.C, Ktot)};
+      return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, c.C, Ktot, 1, st);
+    }
+    GatherKC<T, 128, BK, true> la{dy, yb, geom_dgrad(c)};
+    GatherKC<T, 128, BK, false> lb{w, wb, geom_dense(c.C, Ktot)};
+    return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.C, Ktot, 1, st);
+  }
   if (c.R == 1 && c.S == 1 && c.pad == 0 && c.stride > 1 && ep->residual == ep->out && !ep->colsum && !ep->preact && !ep->dact_aux) {
     // 1x1 / stride-s shortcut conv accumulated in place (dx += dgrad): only every s-th pixel of dx receives a contribution, so run
     // the dense GEMM dy[P][K] * W[K][C] over the P output pixels and scatter-add its rows (RowMap) instead of gathering a mostly
@@ -501,7 +525,7 @@ int conv_dgrad(const void* dy, const void* w, const clite_conv& c, const clite_e
 // stride-1 dgrad with an na x nb window and padding (ch, cw) over the [N][H/2][W/2] sub-grid, scattered to its pixels by RowMap.
 // `wsub` holds that class's taps packed as [K][na][nb][C]. The four classes together cost 9 taps per output quad instead of the
 // 36 that a gather over all pixels and all taps (3/4 of them structurally zero) performs.
-template <typename T>
+template <typename T, bool WT = false>
 int conv_dgrad_s2class(const void* dy, const void* wsub, const clite_conv& c, int ph, int pw, const clite_epilogue* ep, hipStream_t st) {
   constexpr int BK = Cfg<T>::BK;
   const int r0 = (ph + 1) & 1, s0 = (pw + 1) & 1;
@@ -519,6 +543,16 @@ int conv_dgrad_s2class(const void* dy, const void* wsub, const clite_conv& c, in
   rm.on = 1; rm.div_hw = g.div_hw; rm.div_w = g.div_w; rm.H = c.H; rm.W = c.W; rm.stride = 2; rm.off_h = ph; rm.off_w = pw;
   const int M = g.rows, Ktot = na * nb * c.K;
   uint32_t yb = (uint32_t)((size_t)c.N * c.Ho * c.Wo * c.K * sizeof(T)), wb = (uint32_t)((size_t)c.K * na * nb * c.C * sizeof(T));
+  if constexpr (WT) {            // wsub = [C][na][nb][K]
+    if (c.C <= 64) {
+      GatherKC<T, 256, BK, true> la{dy, yb, g};
+      GatherKC<T, 64, BK, false> lb{wsub, wb, geom_dense(c.C, Ktot)};
+      return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, c.C, Ktot, 1, st, rm);
+    }
+    GatherKC<T, 128, BK, true> la{dy, yb, g};
+    GatherKC<T, 128, BK, false> lb{wsub, wb, geom_dense(c.C, Ktot)};
+    return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.C, Ktot, 1, st, rm);
+  }
   if (c.C <= 64) {
     GatherKC<T, 256, BK, true> la{dy, yb, g};
     StridedXC<T, 64, BK> lb{wsub, wb, na * nb * c.C, c.C, c.K, na * nb};
@@ -649,6 +683,17 @@ extern "C" int clite_conv_dgrad_s2class(const void* dy, const void* wsub, const 
   if (cv->C % 64 || cv->K % 64) return -1;
   return cv->dtype == CLITE_BF16 ? conv_dgrad_s2class<bf16>(dy, wsub, *cv, ph, pw, ep, (hipStream_t)stream)
                                  : conv_dgrad_s2class<float>(dy, wsub, *cv, ph, pw, ep, (hipStream_t)stream);
+}
+extern "C" int clite_conv_dgrad_wt(const void* dy, const void* wt, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
+  if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
+  return cv->dtype == CLITE_BF16 ? conv_dgrad<bf16, true>(dy, wt, *cv, ep, (hipStream_t)stream) : conv_dgrad<float, true>(dy, wt, *cv, ep, (hipStream_t)stream);
+}
+extern "C" int clite_conv_dgrad_s2class_wt(const void* dy, const void* wtsub, const clite_conv* cv, int ph, int pw, const clite_epilogue* ep, void* stream) {
+  if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
+  if (cv->R != 3 || cv->S != 3 || cv->stride != 2 || cv->pad != 1 || (cv->H & 1) || (cv->W & 1) || (unsigned)ph > 1 || (unsigned)pw > 1) return -1;
+  if (cv->C % 64 || cv->K % 64) return -1;
+  return cv->dtype == CLITE_BF16 ? conv_dgrad_s2class<bf16, true>(dy, wtsub, *cv, ph, pw, ep, (hipStream_t)stream)
+                                 : conv_dgrad_s2class<float, true>(dy, wtsub, *cv, ph, pw, ep, (hipStream_t)stream);
 }
 extern "C" int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float* dw, void* stream) {
   if (check_conv(cv) || !dw) return -1;

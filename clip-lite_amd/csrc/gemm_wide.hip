@@ -64,11 +64,13 @@ int dispatch(const WideOperand& a, const WideOperand& b, const clite_epilogue& e
     // BatchNorm-backward epilogue: out = [(alpha*acc) (* relu'(aux))] (+ residual) [(* relu'(aux))], statistics; conv dgrad operands only
     if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || splits != 1) return -1;
     if (a.kind == WOP_KC_DGRAD && b.kind == WOP_XC_STRIDED) return go<CFG, 1>(mk_kcd<BM>(a), mk_xs<BN>(b), ep, rm, M, N, Ktot, 1, st);
+    if (a.kind == WOP_KC_DGRAD && b.kind == WOP_KC) return go<CFG, 1>(mk_kcd<BM>(a), mk_kc<BN>(b), ep, rm, M, N, Ktot, 1, st);      // transposed weights
     return -1;
   }
   if (a.kind == WOP_KC && b.kind == WOP_KC) return go_fwd<CFG>(mk_kc<BM>(a), mk_kc<BN>(b), ep, rm, M, N, Ktot, splits, st);
   if (a.kind == WOP_KC && b.kind == WOP_XC_STRIDED) return go_fwd<CFG>(mk_kc<BM>(a), mk_xs<BN>(b), ep, rm, M, N, Ktot, splits, st);
   if (a.kind == WOP_KC_DGRAD && b.kind == WOP_XC_STRIDED) return go_fwd<CFG>(mk_kcd<BM>(a), mk_xs<BN>(b), ep, rm, M, N, Ktot, splits, st);
+  if (a.kind == WOP_KC_DGRAD && b.kind == WOP_KC) return go_fwd<CFG>(mk_kcd<BM>(a), mk_kc<BN>(b), ep, rm, M, N, Ktot, splits, st);
   return WIDE_NOT_TAKEN;
 }
 

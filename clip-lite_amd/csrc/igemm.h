@@ -514,7 +514,7 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
       for (int r = 0; r < RPSE; ++r) s += red[r * (CPRE * 16) + idx];
       int chunk = idx / 16, e = idx % 16;
       int col = n0 + chunk * 8 + (e & 7);
-      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
+      if (col < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
     }
   }
 }
@@ -585,7 +585,7 @@ DEV void igemm_epilogue_plain(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& e
       for (int r = 0; r < RPSE; ++r) sacc += red[r * (CPRE * 16) + idx];
       int chunk = idx / 16, e = idx % 16;
       int col = n0 + chunk * 8 + (e & 7);
-      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
+      if (col < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
     }
   }
 }
@@ -717,7 +717,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
       for (int r = 0; r < RPSE; ++r) sacc += red[r * (CPRE * 16) + idx];
       int chunk = idx / 16, e = idx % 16;
       int col = n0 + chunk * 8 + (e & 7);
-      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
+      if (col < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
     }
   }
 }

@@ -354,7 +354,7 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
       for (int r = 0; r < RPSE; ++r) s += red[r * (CPRE * 16) + idx];
       const int chunk = idx / 16, e = idx % 16;
       const int col = n0 + chunk * 8 + (e & 7);
-      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
+      if (col < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
     }
   }
 }
@@ -519,7 +519,7 @@ DEV void wide_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], WideBnOperands<CFG>& 
       for (int r = 0; r < RPSE; ++r) sacc += red[r * (CPRE * 16) + idx];
       const int chunk = idx / 16, e = idx % 16;
       const int col = n0 + chunk * 8 + (e & 7);
-      if (col < N) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
+      if (col < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
     }
   }
 }

@@ -94,6 +94,51 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16* 
     for (size_t i = n8 * 8; i < n; ++i) dst[i] = f2bf(src[i]);
 }
 
+// Transposed bf16 weight copies for the input-gradient GEMMs. A dgrad contracts over the OUTPUT features, the slow index of a weight stored
+// [out][in]: its weight operand would be an XC image (k-rows strided, ds_read_b64_tr_b16 fragments), which the 8-wave kernels stage 10-25 %
+// slower than the k-contiguous form (tools/probe_tiles.py: 3840 x 768 x 3072 nn 41 us, the same product as nt 31). The weights change once
+// per step, so one grouped launch re-derives [in][out] copies (linear: [N][K] -> [K][N]; conv: [K][R][S][C] -> [C][R][S][K], i.e. R*S
+// matrices [K][C] -> [C][K] with row strides R*S*C / R*S*K) and every dgrad runs as a forward-form GEMM. 64 x 64 tiles through LDS
+// (odd word pitch: conflict-free both ways), 16-byte global accesses on both sides.
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, const clite_transpose_item* __restrict__ items,
+                                                                 int n_items) {
+  __shared__ uint16_t tile[64][66];
+  int lo = 0, hi = n_items - 1;              // item whose [first_tile, first_tile + tiles) holds this workgroup (block-uniform binary search)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].first_tile <= blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const clite_transpose_item it = items[lo];
+  const uint32_t t = blockIdx.x - it.first_tile;
+  const uint32_t tiles_c = (it.cols + 63) / 64, tiles_r = (it.rows + 63) / 64;
+  const uint32_t b = t / (tiles_r * tiles_c), tr = (t / tiles_c) % tiles_r, tc = t % tiles_c;
+  const bf16* s0 = src + it.src_off + (size_t)b * it.src_bstride;
+  bf16* d0 = dst + it.dst_off + (size_t)b * it.dst_bstride;
+  const int tid = threadIdx.x, c8 = (tid & 7) * 8, r0 = tid >> 3;       // 8 chunks of 8 elements per tile row, 32 rows per sweep
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t r = tr * 64 + r0 + 32 * h, c = tc * 64 + c8;
+    Chunk16 ch;
+    ch.u = u32x4{0u, 0u, 0u, 0u};
+    if (r < it.rows && c < it.cols) ch.u = *(const u32x4*)(s0 + (size_t)r * it.src_ld + c);        // cols % 8 == 0 (checked by the launcher)
+    const uint16_t* e = (const uint16_t*)&ch;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[r0 + 32 * h][c8 + k] = e[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t c = tc * 64 + r0 + 32 * h, r = tr * 64 + c8;          // output row = input column
+    if (c < it.cols && r < it.rows) {
+      Chunk16 ch;
+      uint16_t* e = (uint16_t*)&ch;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = tile[c8 + k][r0 + 32 * h];
+      *(u32x4*)(d0 + (size_t)c * it.dst_ld + r) = ch.u;                                             // rows % 8 == 0
+    }
+  }
+}
+
 // dst[i] = src[i] + src[stride + i] + ... + src[(slices - 1) * stride + i], summed in slice order (every rank of a data-parallel job reduces
 // ITS chunk of the gradient arena this way, so the order is fixed by construction)
 __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ src, int slices, size_t stride, size_t n, float* __restrict__ dst) {
@@ -153,3 +198,10 @@ extern "C" int clite_cast_bf16(const float* src, void* dst, uint64_t n, void* st
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, (size_t)n);
   return (int)hipGetLastError();
 }
+
+extern "C" int clite_transpose_weights(const void* src, void* dst, const clite_transpose_item* items_dev, int n_items, uint32_t total_tiles, void* stream) {
+  if (!src || !dst || !items_dev || n_items <= 0 || total_tiles == 0) return -1;
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, (bf16*)dst, items_dev, n_items);
+  return (int)hipGetLastError();
+}
+

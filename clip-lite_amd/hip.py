@@ -26,7 +26,7 @@ class Epilogue(C.Structure):
         ("alpha", C.c_float), ("bias", C.c_void_p), ("act", C.c_int32), ("preact", C.c_void_p),
         ("dact_aux", C.c_void_p), ("dact", C.c_int32), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
         ("drop_site", C.c_uint32), ("residual", C.c_void_p), ("colsum", C.c_void_p),
-        ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32),
+        ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32), ("colsum_rows", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
         ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("relu_bits", C.c_void_p), ("splitk_ws", C.c_void_p),
     ]
@@ -51,6 +51,11 @@ class WgradItem(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32)]
 
 
+class TransposeItem(C.Structure):
+    _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64)] + [(n, C.c_uint32) for n in
+                ("rows", "cols", "src_ld", "dst_ld", "batch", "src_bstride", "dst_bstride", "first_tile")]
+
+
 class OptimItem(C.Structure):
     _fields_ = [("start", C.c_uint64), ("count", C.c_uint32), ("lr", C.c_float), ("wd", C.c_float), ("reserved", C.c_uint32)]
 
@@ -67,6 +72,9 @@ _SIGNATURES = {
     "clite_conv_fwd": [_V, _V, _V, _V, _V],
     "clite_conv_dgrad": [_V, _V, _V, _V, _V],
     "clite_conv_dgrad_s2class": [_V, _V, _V, _I, _I, _V, _V],
+    "clite_conv_dgrad_wt": [_V, _V, _V, _V, _V],
+    "clite_conv_dgrad_s2class_wt": [_V, _V, _V, _I, _I, _V, _V],
+    "clite_transpose_weights": [_V, _V, _V, _I, _U32, _V],
     "clite_conv_wgrad": [_V, _V, _V, _V, _V],
     "clite_wgrad_group": [_I, _V, _I, _V, _V, _U64, _V],
     "clite_fp8_quantize": [_I, _V, _U64, _V, _V, _V, _V],
@@ -204,7 +212,7 @@ class Stats:
 
 
 def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
-             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False, ws=None, relu_bits=None):
+             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False, ws=None, relu_bits=None, colsum_rows=0):
     """bn = (y, stats: Stats, rows): accumulate the BatchNorm-backward reductions (sum v, sum v*(y - mean)) into `colsum`.
     relu_bits: the relu' mask of that form as packed bits (uint8 [M][ldc / 8], written by bn_apply) instead of dact_aux."""
     ep = Epilogue()
@@ -225,6 +233,7 @@ def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, pr
         ep.colsum, ep.colsum_replicas, ep.colsum_stride = p(colsum.t), colsum.R, colsum.rstride
     else:
         ep.colsum = p(colsum)
+    ep.colsum_rows = colsum_rows      # 1: column sums only (a bias gradient accumulated by the GEMM that produces the gradient tensor)
     if bn is not None:
         y, st, rows = bn
         ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = p(y), p(st.t), st.R, st.rstride, 1.0 / rows
@@ -257,8 +266,14 @@ def conv_fwd(x, w, cv, ep):
     check(lib().clite_conv_fwd(p(x), p(w), C.byref(cv), C.byref(ep), stream_ptr(x)), "conv_fwd")
 
 
-def conv_dgrad(dy, w, cv, ep):
-    check(lib().clite_conv_dgrad(p(dy), p(w), C.byref(cv), C.byref(ep), stream_ptr(dy)), "conv_dgrad")
+def conv_dgrad(dy, w, cv, ep, wt=False):
+    """wt: `w` is the transposed copy [C][R][S][K] (Arena.wt): both GEMM operands k-contiguous (clite_conv_dgrad_wt)."""
+    fn = lib().clite_conv_dgrad_wt if wt else lib().clite_conv_dgrad
+    check(fn(p(dy), p(w), C.byref(cv), C.byref(ep), stream_ptr(dy)), "conv_dgrad")
+
+
+def transpose_weights(src, dst, items_dev, n_items, total_tiles):
+    check(lib().clite_transpose_weights(p(src), p(dst), p(items_dev), n_items, total_tiles, stream_ptr(src)), "transpose_weights")
 
 
 def s2_class_weights(w):
@@ -267,15 +282,17 @@ def s2_class_weights(w):
     return [w[:, (ph + 1) & 1::2, (pw + 1) & 1::2, :].contiguous() for ph in (0, 1) for pw in (0, 1)]
 
 
-def conv_dgrad_s2(dy, w, cv, make_ep, wsubs=None):
+def conv_dgrad_s2(dy, w, cv, make_ep, wsubs=None, wt=False):
     """dgrad of a 3x3 / stride-2 / pad-1 conv as its four input-parity classes (a quarter of the MACs of the gathered form).
-    `make_ep()` builds the epilogue (called once per class: the classes write disjoint rows of the same output)."""
+    `make_ep()` builds the epilogue (called once per class: the classes write disjoint rows of the same output). wt: `w` / `wsubs` are
+    (slices of) the transposed weight [C][R][S][K] — the same tap slicing applies to axes 1 and 2 of either layout."""
     if wsubs is None:
         wsubs = s2_class_weights(w)
+    fn = lib().clite_conv_dgrad_s2class_wt if wt else lib().clite_conv_dgrad_s2class
     for ph in (0, 1):
         for pw in (0, 1):
             ep = make_ep()
-            check(lib().clite_conv_dgrad_s2class(p(dy), p(wsubs[2 * ph + pw]), C.byref(cv), ph, pw, C.byref(ep), stream_ptr(dy)), "conv_dgrad_s2class")
+            check(fn(p(dy), p(wsubs[2 * ph + pw]), C.byref(cv), ph, pw, C.byref(ep), stream_ptr(dy)), "conv_dgrad_s2class")
 
 
 def s2_classes_ok(cv):

@@ -147,6 +147,7 @@ class FusedSGD(torch.optim.Optimizer):
         self.zero_frozen()
         hip.sgd_step(self.arena.flat_p, self.arena.flat_g, self.flat_v, self.flat_slow, self.arena.flat_lp,
                      C.c_void_p(self._items.data_ptr()), self._n_items, self.hp, self.sumsq)
+        self.arena._tr_stale = True          # the bf16 weights changed: the transposed copies of the dgrad GEMMs are out of date
         self._dirty = False
 
     # -- torch.optim.SGD-compatible checkpoint layout -----------------------------------------------------------------

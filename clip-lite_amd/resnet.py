@@ -148,6 +148,15 @@ def _conv(rt, x, N, H, W, conv, training):
     return u
 
 
+def _wd(rt, conv):
+    """(weight operand of the conv's dgrad, is it the transposed copy): bf16 mode reads [C][R][S][K] (Arena.wt) so the dgrad GEMM has both operands
+    k-contiguous like the forward; the exact-f32 mode reads the weight as stored."""
+    A = rt.arena
+    if rt.transposed_dgrad and A.has_wt(conv.weight):
+        return A.wt(conv.weight), True
+    return A.w(conv.weight), False
+
+
 def s2_class_weights(rt, net):
     """{id(conv): the four tap-subset weights} of every conv whose dgrad runs as parity classes (hip.conv_dgrad_s2); put into the forward
     context as ctx["s2w"] by a caller that wants them made ahead of backward (train_loop.TrainStep: on the side stream, at the start of the step)."""
@@ -157,7 +166,7 @@ def s2_class_weights(rt, net):
     for blk in net.blocks():
         for conv, _ in blk.units()[1:]:           # (a block's first conv takes the block-input path of resnet_backward, not the parity classes)
             if conv.k == 3 and conv.stride == 2 and conv.pad == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0:
-                out[id(conv)] = hip.s2_class_weights(rt.arena.w(conv.weight))
+                out[id(conv)] = hip.s2_class_weights(_wd(rt, conv)[0])
     return out
 
 
@@ -296,6 +305,7 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         else:
             defer.conv(dy_, u_.x, u_.cv, dw)          # hip.WgradGroup: keeps dy / x referenced until it has been launched
 
+    rt.arena.ensure_transposed(capturing=rt._capturing)
     if resume:
         dout, pre, first = ctx.pop("bwd_state")
     else:
@@ -325,8 +335,9 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 wgrad(dy, u)
             Cin = u.conv.in_channels
             dx = _alloc(rt, u.x.shape[0], Cin)
+            wd, wt = _wd(rt, u.conv)
             if i > 0 and not rt.fuse_bn_backward:
-                hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin))
+                hip.conv_dgrad(dy, wd, u.cv, hip.epilogue(dx, Cin), wt=wt)
                 prev = units[i - 1]
                 dy, _ = _bn_backward(rt, prev, dx, prev.bits, N)
             elif i > 0:
@@ -334,26 +345,27 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 dstats = rt.new_stats(Cin)
                 mk = lambda: hip.epilogue(dx, Cin, relu_bits=prev.bits, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0]))
                 if rt.s2_classes and hip.s2_classes_ok(u.cv):
-                    hip.conv_dgrad_s2(dy, rt.arena.w(u.conv.weight), u.cv, mk,       # 3x3 / stride 2: four parity classes, no zero taps
-                                      wsubs=(ctx.get("s2w") or {}).get(id(u.conv)))
+                    hip.conv_dgrad_s2(dy, wd, u.cv, mk,       # 3x3 / stride 2: four parity classes, no zero taps
+                                      wsubs=(ctx.get("s2w") or {}).get(id(u.conv)), wt=wt)
                 else:
-                    hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, mk())
+                    hip.conv_dgrad(dy, wd, u.cv, mk(), wt=wt)
                 dy = _bn_backward_apply(rt, prev, dx, dstats)
             else:
                 # gradient w.r.t. the block input: main path + shortcut
                 if identity and bi > 0 and rt.fuse_bn_backward:
                     pl = recs[bi - 1][0][-1]          # the previous block's last unit consumes this gradient
                     pre = rt.new_stats(Cin)
-                    hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv,
+                    hip.conv_dgrad(dy, wd, u.cv,
                                    hip.epilogue(dx, Cin, residual=dz, relu_bits=pl.bits, mask_after_residual=True, colsum=pre,
-                                                bn=(pl.y, pl.stats, pl.y.shape[0])))
+                                                bn=(pl.y, pl.stats, pl.y.shape[0])), wt=wt)
                 else:
-                    hip.conv_dgrad(dy, rt.arena.w(u.conv.weight), u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None))
+                    hip.conv_dgrad(dy, wd, u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None), wt=wt)
                     if ud is not None:
                         if ud.conv.weight.requires_grad:
                             wgrad(dyd, ud)
                         # shortcut branch accumulated in place (dx += dgrad); a strided 1x1 shortcut takes the scatter-add path of clite_conv_dgrad
-                        hip.conv_dgrad(dyd, rt.arena.w(ud.conv.weight), ud.cv, hip.epilogue(dx, Cin, residual=dx))
+                        wdd, wtd = _wd(rt, ud.conv)
+                        hip.conv_dgrad(dyd, wdd, ud.cv, hip.epilogue(dx, Cin, residual=dx), wt=wtd)
                 dout = dx
         if defer is None:
             rt.grads_ready(blocks[bi])

@@ -51,6 +51,7 @@ class Arena:
         self.flat_p = torch.zeros(off, device=device, dtype=torch.float32)
         self.flat_g = torch.zeros(off, device=device, dtype=torch.float32)
         self.flat_lp = torch.zeros(off, device=device, dtype=torch.bfloat16) if lowp else None
+        self.flat_lpT, self._tr, self._tr_stale, self._tr_event, self._tr_shape = None, None, True, None, {}
         self.params = {}
         self.names = order
         for n in order:
@@ -137,6 +138,83 @@ class Arena:
         """Re-derive the bf16 copy from the f32 masters (after load_state_dict or any out-of-band weight edit)."""
         if self.lowp:
             hip.cast_bf16(self.flat_p, self.flat_lp, self.total)
+        self._tr_stale = True
+
+    # transposed bf16 copies for the input-gradient GEMMs (include/clite.h: clite_transpose_weights) ----------------------------------
+    def register_transposed(self, weights, groups=()):
+        """weights: parameters whose dgrad reads a transposed copy — Linear [N][K] -> [K][N], conv (kernel layout [K][R][S][C]) -> [C][R][S][K].
+        groups: lists of adjacent 2-D weights with equal K that one GEMM reads as a single [sum N][K] matrix (BERT's q/k/v): transposed as one
+        matrix, so the copy is the [K][sum N] operand of the fused input gradient. Same offsets as the bf16 arena."""
+        if not self.lowp:
+            return
+        import ctypes as C
+        items, tile, done = [], 0, set()
+
+        def add(off, rows, cols, src_ld, dst_ld, batch, sb, db):
+            nonlocal tile
+            it = hip.TransposeItem(off, off, rows, cols, src_ld, dst_ld, batch, sb, db, tile)
+            items.append(it)
+            tile += batch * ((rows + 63) // 64) * ((cols + 63) // 64)
+
+        for g in groups:
+            ps = [p for p in g]
+            offs = [self.index[p._clite[1]] for p in ps]
+            if any(p.dim() != 2 or p.shape[1] != ps[0].shape[1] for p in ps) or any(o + n != o2 for (o, n), (o2, _) in zip(offs[:-1], offs[1:])):
+                continue
+            rows, cols = sum(p.shape[0] for p in ps), ps[0].shape[1]
+            if rows % 8 or cols % 8:
+                continue
+            add(offs[0][0], rows, cols, cols, rows, 1, 0, 0)
+            self._tr_shape[tuple(id(p) for p in ps)] = (offs[0][0], (cols, rows))
+            done.update(id(p) for p in ps)
+        for p in weights:
+            if id(p) in done:
+                continue
+            o, numel = self.index[p._clite[1]]
+            if p.dim() == 2 and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0:
+                N, K = p.shape
+                add(o, N, K, K, N, 1, 0, 0)
+                self._tr_shape[id(p)] = (o, (K, N))
+            elif p.dim() == 4 and p.shape[0] % 8 == 0 and p.shape[1] % 8 == 0:
+                K, Cc, R, S = p.shape
+                add(o, K, Cc, R * S * Cc, R * S * K, R * S, Cc, K)
+                self._tr_shape[id(p)] = (o, (Cc, R, S, K))
+        if not items:
+            return
+        arr = (hip.TransposeItem * len(items))(*items)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self._tr = (host.to(self.device), len(items), tile)
+        self.flat_lpT = torch.zeros(self.total, device=self.device, dtype=torch.bfloat16)
+        self._tr_stale = True
+
+    def ensure_transposed(self, force=False, capturing=False):
+        """Bring the transposed copies up to date with the bf16 arena on the current stream (one grouped launch), or — when another stream has
+        already done so since the weights last changed — order the current stream behind that launch. Inside a stream capture only `force`
+        does anything: the captured step places the launch itself (train_loop.TrainStep) and orders its phases explicitly."""
+        if self._tr is None:
+            return
+        if capturing and not force:
+            return
+        if self._tr_stale or force:
+            dev, n, tiles = self._tr
+            hip.transpose_weights(self.flat_lp, self.flat_lpT, dev, n, tiles)
+            self._tr_stale = False
+            if not capturing and self.device.type == "cuda":
+                self._tr_event = torch.cuda.Event()
+                self._tr_event.record(torch.cuda.current_stream(self.device))
+        elif self._tr_event is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._tr_event)
+
+    def has_wt(self, *ps):
+        return self._tr is not None and ((id(ps[0]) if len(ps) == 1 else tuple(id(p) for p in ps)) in self._tr_shape)
+
+    def wt(self, *ps):
+        """Transposed bf16 copy: one weight -> [K][N] / [C][R][S][K]; several adjacent ones (a registered group) -> [K][sum N]."""
+        o, shape = self._tr_shape[id(ps[0]) if len(ps) == 1 else tuple(id(p) for p in ps)]
+        n = 1
+        for d in shape:
+            n *= d
+        return self.flat_lpT[o:o + n].view(shape)
 
 
 class StepState:
@@ -188,6 +266,16 @@ class DeviceRuntime:
         # keeps the single-pass statistics that come for free out of the conv epilogue
         self.precise_bn = not lowp
         self.arena = Arena(model.named_parameters(), self.device, lowp, contiguous_groups)
+        # input gradients as forward-form GEMMs on transposed weight copies (bf16 mode; Arena.register_transposed): every conv weight with
+        # >= 8 input channels and every Linear weight; BERT's adjacent q/k/v weights as one matrix
+        self.transposed_dgrad = bool(lowp)
+        if lowp:
+            by_name = dict(model.named_parameters())
+            tw = [m.weight for m in model.modules()
+                  if isinstance(getattr(m, "weight", None), torch.nn.Parameter) and hasattr(m.weight, "_clite")
+                  and (hasattr(m, "in_features") or hasattr(m, "in_channels"))]
+            tg = [[by_name[n] for n in g] for g in contiguous_groups if all(n in by_name for n in g) and by_name[g[0]].dim() == 2]
+            self.arena.register_transposed(tw, tg)
         self.base_seed = int(seed)
         self._zpools = {}          # one pre-zeroed pool per launch stream (the two encoders run on different streams)
         self.side_stream = None    # the text encoder's stream (model.py), created on first use

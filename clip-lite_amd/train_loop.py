@@ -167,6 +167,9 @@ class TrainStep:
             # (first, on this stream: the tap-subset weights of the stride-2 dgrads — they depend on the weights only; in front of each class's
             # GEMM they were twelve small copies on the critical path of the image backward)
             from .resnet import s2_class_weights
+            # the transposed weight copies of every input-gradient GEMM (Arena.register_transposed): one grouped launch per step, here — behind
+            # the previous step's update in stream order, ahead of both backward passes (the image backward starts behind the heads' join)
+            rt.arena.ensure_transposed(force=True, capturing=True)
             keep["ctx_i"]["s2w"] = keep["s2w"] = s2_class_weights(rt, m.image_encoder.img_encoder)
             keep["step_t"] = rt.next_step(True)
             keep["txt"], keep["ctx_t"] = bert_forward(rt, m.text_encoder.strans, sb["input_ids"], sb["attention_mask"], keep["step_t"])
@@ -403,6 +406,7 @@ class TrainStep:
             if self.exchange is not None:
                 self.exchange.reduce_all()
                 self._g_update.replay()
+        rt.arena._tr_stale = True          # the replayed update changed the weights: an eager step that follows re-derives the transposed copies
         self.scaler.update()
         self.scheduler.step()
         return self._static_out

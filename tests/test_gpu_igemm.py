@@ -110,6 +110,23 @@ def test_conv_fwd_dgrad_wgrad(dt, N, H, W, Cc, K, R, S, st, pad):
     dx = torch.empty(N, H, W, Cc, device="cuda", dtype=torch.float32)
     hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc))
     assert _rel(dx, x32.grad.permute(0, 2, 3, 1)) < 2e-3
+    # the same input gradient on the transposed weight [C][R][S][K] (clite_conv_dgrad_wt: forward-form GEMM, what the bf16 step runs), with
+    # the transposed copy made by the grouped transpose kernel (clite_transpose_weights) and checked against torch's permute
+    wt = torch.zeros(Cc, R, S, K, device="cuda", dtype=w.dtype)
+    if dt == BF16:
+        it = hip.TransposeItem(0, 0, K, Cc, R * S * Cc, R * S * K, R * S, Cc, K, 0)
+        items = torch.frombuffer(bytearray(bytes(it)), dtype=torch.uint8).cuda()
+        hip.transpose_weights(w, wt, items, 1, R * S * ((K + 63) // 64) * ((Cc + 63) // 64))
+        assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
+    else:
+        wt.copy_(w.permute(3, 1, 2, 0))
+    dx2 = torch.full((N, H, W, Cc), 3.0, device="cuda", dtype=torch.float32)
+    hip.conv_dgrad(dy, wt, cv, hip.epilogue(dx2, Cc), wt=True)
+    assert _rel(dx2, x32.grad.permute(0, 2, 3, 1)) < 2e-3
+    if hip.s2_classes_ok(cv):
+        dx3 = torch.full((N * H * W, Cc), 5.0, device="cuda", dtype=torch.float32)
+        hip.conv_dgrad_s2(dy, wt, cv, lambda: hip.epilogue(dx3, Cc), wt=True)
+        assert _rel(dx3.view(N, H, W, Cc), x32.grad.permute(0, 2, 3, 1)) < 2e-3
     dw = torch.zeros(K, R, S, Cc, device="cuda", dtype=torch.float32)
     hip.conv_wgrad(dy, x, cv, dw)
     assert _rel(dw, w32.grad.permute(0, 2, 3, 1)) < 2e-3

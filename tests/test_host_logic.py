@@ -59,7 +59,8 @@ def test_ctypes_structs_match_header_layout(tmp_path):
     """sizeof / offsetof of every struct in include/clite.h as gcc lays them out == the ctypes mirrors in clip_lite_amd/hip.py."""
     import subprocess
     from clip_lite_amd import hip
-    structs = {"clite_epilogue": hip.Epilogue, "clite_conv": hip.Conv, "clite_bn": hip.Bn, "clite_optim_item": hip.OptimItem}
+    structs = {"clite_epilogue": hip.Epilogue, "clite_conv": hip.Conv, "clite_bn": hip.Bn, "clite_optim_item": hip.OptimItem,
+               "clite_transpose_item": hip.TransposeItem}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "clite.h"', "int main(void) {"]
     for cname, ct in structs.items():
         lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -329,3 +329,105 @@ def test_grouped_weight_gradients():
     for got, ref in zip(outs, refs):
         _close(got, ref)
     assert L.clite_wgrad_group(BF16, arr, len(items), ptr(ws_dev), ptr(ws_host), 64, None) == -2          # workspace too small: refused, nothing launched
+
+
+class TransposeItem(C.Structure):
+    _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64)] + [(n, C.c_uint32) for n in
+                ("rows", "cols", "src_ld", "dst_ld", "batch", "src_bstride", "dst_bstride", "first_tile")]
+
+
+def test_transpose_weights_grouped_launch():
+    """clite_transpose_weights: three items in one launch inside one flat buffer — a Linear [N][K] -> [K][N] with ragged 64-tiles, a conv
+    [K][R][S][C] -> [C][R][S][K] (R*S batched [K][C] -> [C][K] with the two row strides), and three adjacent q/k/v-style weights as one
+    [3N][K] matrix — against numpy transposes; untouched gaps of the destination stay as they were."""
+    rng = np.random.default_rng(4)
+    N1, K1 = 72, 136
+    Kc, R, S, Cc = 40, 3, 3, 24
+    N3, K3 = 24, 64
+    o1, o2, o3 = 0, 10240, 20480
+    total = 30720
+    src = rng.integers(0, 65535, total, dtype=np.uint16)
+    dst = np.full(total, 0x1234, np.uint16)
+    items, tile = [], 0
+    for (o, rows, cols, sld, dld, batch, sb, db) in [(o1, N1, K1, K1, N1, 1, 0, 0), (o2, Kc, Cc, R * S * Cc, R * S * Kc, R * S, Cc, Kc), (o3, 3 * N3, K3, K3, 3 * N3, 1, 0, 0)]:
+        items.append(TransposeItem(o, o, rows, cols, sld, dld, batch, sb, db, tile))
+        tile += batch * ((rows + 63) // 64) * ((cols + 63) // 64)
+    arr = (TransposeItem * 3)(*items)
+    assert lib().clite_transpose_weights(ptr(src), ptr(dst), C.byref(arr), 3, C.c_uint32(tile), None) == 0
+    assert np.array_equal(dst[o1:o1 + N1 * K1].reshape(K1, N1), src[o1:o1 + N1 * K1].reshape(N1, K1).T)
+    assert np.array_equal(dst[o2:o2 + Kc * R * S * Cc].reshape(Cc, R, S, Kc), src[o2:o2 + Kc * R * S * Cc].reshape(Kc, R, S, Cc).transpose(3, 1, 2, 0))
+    assert np.array_equal(dst[o3:o3 + 3 * N3 * K3].reshape(K3, 3 * N3), src[o3:o3 + 3 * N3 * K3].reshape(3 * N3, K3).T)
+    assert (dst[o1 + N1 * K1:o2] == 0x1234).all() and (dst[o3 + 3 * N3 * K3:] == 0x1234).all()
+
+
+@pytest.mark.parametrize("dtype,N,H,W,Cc,K,R,S,st,pad", [(BF16, 2, 8, 8, 32, 64, 3, 3, 1, 1), (F32, 2, 9, 7, 64, 32, 3, 3, 2, 1), (BF16, 3, 6, 6, 136, 64, 1, 1, 1, 0),
+                                                         (BF16, 2, 8, 8, 32, 64, 1, 1, 2, 0), (BF16, 1, 8, 8, 64, 64, 3, 3, 2, 1)])
+def test_conv_dgrad_on_transposed_weights(dtype, N, H, W, Cc, K, R, S, st, pad):
+    """clite_conv_dgrad_wt / clite_conv_dgrad_s2class_wt (weight given as [C][R][S][K]: a k-contiguous operand like the forward's) against
+    the reference dgrad; with the BatchNorm-backward epilogue too (the form the ResNet backward launches)."""
+    rng = np.random.default_rng(H + K)
+    Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - S) // st + 1
+    cv = Conv(dtype, N, H, W, Cc, K, R, S, st, pad, Ho, Wo)
+    M = N * H * W
+    w, _ = _prep(rng.standard_normal((K, R, S, Cc), dtype=np.float32) * 0.2, dtype)
+    wt, wtb = _prep(np.ascontiguousarray(w.transpose(3, 1, 2, 0)), dtype)
+    dy, dyb = _prep(rng.standard_normal((N, Ho, Wo, K), dtype=np.float32), dtype)
+    g = conv_dgrad_ref(dy, w, (N, H, W, Cc), st, pad).reshape(M, Cc)
+    out = np.zeros((M, Cc), np.float32)
+    ep = make_ep(out, Cc, out_f32=True)
+    assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == 0
+    _close(out, g)
+    if R == 1 and st == 2:       # the strided 1x1 shortcut accumulated in place: dense GEMM over the output pixels, rows scattered
+        _, acc = _prep(np.ones((M, Cc), np.float32), dtype)          # in the compute dtype: the residual operand is read as such
+        acc = acc.copy()
+        ep = make_ep(acc, Cc, out_f32=False, residual=acc)
+        assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == 0
+        _close(from_bf16(acc) if dtype == BF16 else acc, 1 + g, 8e-3)
+    if R == 3 and st == 2 and H % 2 == 0 and Cc % 64 == 0 and K % 64 == 0:
+        out2 = np.full((M, Cc), 7.0, np.float32)
+        for ph in (0, 1):
+            for pw in (0, 1):
+                sub, subb = _prep(np.ascontiguousarray(wt[:, (ph + 1) & 1::2, (pw + 1) & 1::2, :]), dtype)
+                ep = make_ep(out2, Cc, out_f32=True)
+                assert lib().clite_conv_dgrad_s2class_wt(ptr(dyb), ptr(subb), C.byref(cv), ph, pw, C.byref(ep), None) == 0
+        _close(out2, g)
+    if st == 1:
+        aux = rng.standard_normal((M, Cc)).astype(np.float32)
+        res, resb = _prep(rng.standard_normal((M, Cc), dtype=np.float32), dtype)
+        y, yb = _prep(rng.standard_normal((M, Cc), dtype=np.float32) + 3.0, dtype)
+        fstats = np.zeros((4, 3, Cc), np.float32)
+        fstats[:, 0] = y.sum(0) / 4
+        out3 = np.zeros((M, Cc), np.float32)
+        dst = np.zeros((4, 3, Cc), np.float32)
+        bits = pack_relu_bits(aux)          # (kept in a variable: the epilogue holds a raw pointer into it)
+        ep = make_ep(out3, Cc, out_f32=True, residual=resb, colsum=dst, relu_bits=bits)
+        ep.colsum_replicas, ep.colsum_stride = 4, 3 * Cc
+        ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count, ep.mask_after_residual = ptr(yb), ptr(fstats), 4, 3 * Cc, 1.0 / M, 1
+        assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == 0
+        v = (g + res) * (aux > 0)
+        _close(out3, v)
+        _close(dst.sum(0)[1], (v * (y - fstats[:, 0].sum(0) / M)).sum(0), 5e-3)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_colsum_rows_1_accumulates_the_column_sums_only(dtype):
+    """clite_epilogue.colsum_rows = 1: only row 0 (the column sums of the stored values) is accumulated — straight into a bias gradient whose
+    neighbour in memory is another tensor (BERT FFN: the gelu' input-gradient GEMM also produces intermediate.dense.bias.grad). The floats behind
+    the N sums must stay untouched, and the sums ADD to what is there."""
+    rng = np.random.default_rng(11)
+    M, N, K = 200, 136, 104
+    A, Ab = _prep(rng.standard_normal((M, K), dtype=np.float32), dtype)
+    B, Bb = _prep(rng.standard_normal((K, N), dtype=np.float32) * 0.2, dtype)
+    pre, preb = _prep(rng.standard_normal((M, N), dtype=np.float32), dtype)
+    out = np.zeros((M, N), np.uint16 if dtype == BF16 else np.float32)
+    sums = np.full(2 * N, 5.0, np.float32)
+    ep = make_ep(out, N, dact_aux=preb, dact=2, colsum=sums)
+    ep.colsum_rows = 1
+    assert lib().clite_gemm_nn(ptr(Ab), K, ptr(Bb), N, M, N, K, dtype, C.byref(ep), None) == 0
+    got = from_bf16(out) if dtype == BF16 else out
+    from math import erf, exp, pi, sqrt
+    gp = np.vectorize(lambda x: 0.5 * (1 + erf(x / sqrt(2))) + x * exp(-0.5 * x * x) / sqrt(2 * pi))(pre).astype(np.float32)
+    _close(got, (A @ B) * gp, 8e-3 if dtype == BF16 else 2e-3)
+    _close(sums[:N], 5.0 + got.sum(0), 1e-4)
+    assert (sums[N:] == 5.0).all()
+
