@@ -230,6 +230,8 @@ def main():
                     "v_mfma_f32_32x32x16_fp8_fp8, f32 accumulate); backward stays bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
+    ap.add_argument("--defer-update", action="store_true", help="run the text encoder's and heads' share of the update at the start of the NEXT step, beside "
+                    "the image forward (TrainStep defer_update; measured neutral: DESIGN.md §5.1)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL over xGMI); gloo is for single-GPU logic tests")
     ap.add_argument("--single-device", action="store_true", help="logic test only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--host-input", action="store_true", help="batches start in pinned host memory and cross PCIe every step through the train loop's "
@@ -271,7 +273,10 @@ def main():
     if dist_on:
         exchange = cdist.GradientExchange(model.runtime.arena, algorithm=args.exchange)
         model.runtime.exchange = exchange
-    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange, graph=not args.no_graph)
+    # --defer-update: the step's last kernel (the update of the text encoder and the heads) runs at the start of the next step, beside the image
+    # forward; step.finish() below then completes the last timed step's update INSIDE the timed region. Measured: 17.32 vs 17.35 ms — both are
+    # HBM-bound at that point of the step, the overlap is zero-sum — so it is off by default
+    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange, graph=not args.no_graph, defer_update=args.defer_update)
     eager_step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange)      # per-launch timing needs eager launches
     batches = synthetic_batches(args, device, rank)
     if args.host_input:
@@ -297,6 +302,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(next_batch(i))
+    step.finish()
     torch.cuda.synchronize()
     if dist_on:
         tdist.barrier()

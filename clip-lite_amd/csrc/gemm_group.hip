@@ -12,7 +12,7 @@
 // Layout of the workspace the caller hands over (device copy + pinned host staging of the same size): [items][wg map]; the library fills the
 // host side, copies it with one hipMemcpyAsync on the launch stream (a memcpy node when the stream is being captured) and launches. bf16 only;
 // the exact-f32 mode and the deterministic-reduction mode run the members one by one through clite_conv_wgrad / clite_gemm_tn.
-#include "igemm_dma.h"
+#include "igemm_wide.h"
 #include "det.h"
 #include <string.h>
 #include <algorithm>
@@ -133,12 +133,114 @@ __global__ __launch_bounds__(256) void igemm_group_kernel(const GroupItem<LA, LB
     }
 }
 
+// The same grouped launch on the 8-wave wide tiles of igemm_wide.h (K tile 64, one workgroup per CU): a 256 x 256 tile stages 256 B of
+// operands per MFMA, 256 x 128 / 128 x 256 384 B, the 4-wave 128 x 128 x 32 tile 512 B — and the weight-gradient GEMMs (K = 3840 ... 25088
+// pixels or tokens) are bound by exactly that L2 -> LDS traffic (500-620 TF/s on the narrow tiles). Members whose output
+// has >= 256 rows and columns (every BERT matrix, the layer3 / layer4 convs) take the 256 x 256 tile; narrower outputs (layer1, layer2) stay on
+// the 4-wave kernels above. Both operands are XC images (contraction index slow).
+template <class CFG, class LA, class LB, int NSTAGE>
+__global__ __launch_bounds__(512) void igemm_group_wide_kernel(const GroupItem<LA, LB>* __restrict__ items, const WgEntry* __restrict__ map) {
+  constexpr int BM = CFG::BM, BN = CFG::BN;
+  constexpr int RM = CFG::RM, RN = CFG::RN, KS = CFG::KS;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int LOADS_PER_TILE = LA::NI + LB::NI;
+  static_assert(CFG::KG == 1 && NSTAGE * STAGE <= 160 * 1024, "one k-group; LDS budget");
+  __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+  const WgEntry e = map[blockIdx.x];
+  if (wave_uniform((int)e.item) < 0) return;         // padding entry: the XCD lists are of unequal length
+  const GroupItem<LA, LB>& it = items[wave_uniform((int)e.item)];
+  const LA la = it.la;
+  const LB lb = it.lb;
+  const int M = it.M, N = it.N;
+  const int m0 = wave_uniform((int)e.tile_m) * BM, n0 = wave_uniform((int)e.tile_n) * BN;
+  const int t_begin = wave_uniform((int)e.kchunk) * it.chunk;
+  int t_end = t_begin + it.chunk;
+  if (t_end > it.ktiles) t_end = it.ktiles;
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, wave, lane, t_begin);
+  lb.init(sb, n0, wave, lane, t_begin);
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int aoff[RM][KS], boff[RN][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i) aoff[i][ks] = LA::frag_off(wm0 + i * 32, ks, lane);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) boff[j][ks] = LB::frag_off(wn0 + j * 32, ks, lane);
+  }
+#pragma unroll
+  for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+    if (t_begin + pz < t_end) {
+      WideIssue<LA>::go(la, sa, smem + pz * STAGE, wave, lane, m0);
+      WideIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
+    }
+  }
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    const int after = t_end - 1 - t;
+    if (NSTAGE >= 3 && after >= 1) wait_vmcnt<LOADS_PER_TILE>();
+    else wait_vmcnt<0>();
+    barrier_raw();
+    const char* abuf = smem + buf * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+    bf16x8 af0[RM], bf0[RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
+#pragma unroll
+    for (int j = 0; j < RN; ++j) bf0[j] = LB::frag_at(bbuf + boff[j][0]);
+    if (t + NSTAGE - 1 < t_end) {
+      int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+      WideIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+      WideIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 af[RM], bfr[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_bf16(af[i], bfr[j], acc[i][j]);
+    }
+    if (++buf == NSTAGE) buf = 0;
+  }
+  float* out = it.out;
+  const int ldc = it.ldc;
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const int col = n0 + wn0 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) atomic_add_f32(out + (size_t)row * ldc + col, acc[i][j][r]);
+      }
+    }
+}
+
 struct Plan { int M, N, Ktot, ktiles, chunk, nchunks, tm, tn; };
-Plan plan(int M, int N, int Ktot, int BM, int BN) {
+Plan plan(int M, int N, int Ktot, int BM, int BN, int bk = GBK, int kchunk = KCHUNK) {
   Plan p;
   p.M = M; p.N = N; p.Ktot = Ktot;
-  p.ktiles = (Ktot + GBK - 1) / GBK;
-  p.nchunks = (p.ktiles + KCHUNK - 1) / KCHUNK;
+  p.ktiles = (Ktot + bk - 1) / bk;
+  p.nchunks = (p.ktiles + kchunk - 1) / kchunk;
   p.chunk = (p.ktiles + p.nchunks - 1) / p.nchunks;
   p.nchunks = (p.ktiles + p.chunk - 1) / p.chunk;
   p.tm = (M + BM - 1) / BM; p.tn = (N + BN - 1) / BN;
@@ -173,9 +275,17 @@ typedef DmaXCStrided<bf16, 128, GBK> XS128;
 typedef DmaXCStrided<bf16, 64, GBK> XS64;
 typedef DmaXCGather<bf16, 128, GBK> XG128;
 typedef DmaXCGather<bf16, 64, GBK> XG64;
+// 8-wave wide tile (K tile 64): 256 x 256 on a 2-stage ring (128 KB). The rectangular 256 x 128 / 128 x 256 tiles for layer2's 128-wide outputs
+// were measured and dropped: that segment's group took 1.45 ms instead of 0.86 on the 4-wave tiles
+typedef WideCfg<256, 256, 128, 64, 1> W256;
+typedef DmaXCStrided<bf16, 256, WIDE_BK, WIDE_NW> WS256;
+typedef DmaXCGather<bf16, 256, WIDE_BK, WIDE_NW> WG256;
+constexpr int WKCHUNK = 128;            // K tiles of 64 per workgroup at most (8192 pixels / tokens, as KCHUNK)
+template <class CFG> struct GroupStages { static constexpr int n = 3; };
+template <> struct GroupStages<W256> { static constexpr int n = 2; };
 
 // one bucket = one kernel instantiation; items and map entries are appended to the host staging image
-template <class CFG, class LA, class LB>
+template <class CFG, class LA, class LB, bool WIDE = false>
 struct Bucket {
   std::vector<GroupItem<LA, LB>> items;
   std::vector<Plan> plans;
@@ -194,7 +304,7 @@ struct Bucket {
   // eight L2s) the grouped launches of a ResNet-50 + BERT step fetched 17.9 GB for 5.5 GB of operands.
   // Lists of unequal length are padded with NO_ITEM entries (the workgroup exits at once).
   static constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
-  static constexpr int XCDS = 8, BUNDLE = 64;
+  static constexpr int XCDS = 8, BUNDLE = WIDE ? 32 : 64;
   void build_map() {
     std::vector<uint32_t> order(items.size());
     for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
@@ -233,8 +343,12 @@ struct Bucket {
   }
   int launch(char* dev, size_t off, hipStream_t st) const {
     if (items.empty()) return 0;
-    hipLaunchKernelGGL((igemm_group_kernel<CFG, LA, LB, 3>), dim3((unsigned)map.size()), dim3(256), 0, st,
-                       (const GroupItem<LA, LB>*)(dev + off), (const WgEntry*)(dev + off + item_bytes()));
+    if constexpr (WIDE)
+      hipLaunchKernelGGL((igemm_group_wide_kernel<CFG, LA, LB, GroupStages<CFG>::n>), dim3((unsigned)map.size()), dim3(512), 0, st,
+                         (const GroupItem<LA, LB>*)(dev + off), (const WgEntry*)(dev + off + item_bytes()));
+    else
+      hipLaunchKernelGGL((igemm_group_kernel<CFG, LA, LB, 3>), dim3((unsigned)map.size()), dim3(256), 0, st,
+                         (const GroupItem<LA, LB>*)(dev + off), (const WgEntry*)(dev + off + item_bytes()));
     return (int)hipGetLastError();
   }
 };
@@ -242,6 +356,8 @@ struct Bucket {
 bool fits32(size_t elems, size_t esize) { return elems * esize < 0xF0000000ull; }
 
 }  // namespace
+
+bool clite_group_wide_enabled();      // gemm_wide.hip: false under tile policy 4 (every launch on the 4-wave kernels)
 
 extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n, void* ws_dev, void* ws_host, uint64_t ws_bytes, void* stream) {
   if (!items || n <= 0) return n == 0 ? 0 : -1;
@@ -252,7 +368,7 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
     for (int i = 0; i < n; ++i) {
       const clite_wgrad_item& w = items[i];
       int rc;
-      if (w.kind == 0) {
+      if ((w.kind & ~CLITE_WGRAD_NARROW) == 0) {
         rc = clite_conv_wgrad(w.a, w.b, &w.cv, w.out, stream);
       } else {
         clite_epilogue ep = {};
@@ -267,36 +383,49 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
   Bucket<C64x128, XS64, XG128> conv_fewk;     // <= 64 output channels
   Bucket<C128x64, XS128, XG64> conv_fewc;     // <= 64 (r, s, ci) columns
   Bucket<C128, XS128, XS128> linear;
+  Bucket<W256, WS256, WG256, true> conv_w256;             // >= 256 output channels and >= 256 columns
+  Bucket<W256, WS256, WS256, true> linear_w256;
+  const bool wide_all = clite_group_wide_enabled();
   for (int i = 0; i < n; ++i) {
     const clite_wgrad_item& w = items[i];
     if (!w.a || !w.b || !w.out) return -1;
-    if (w.kind == 0) {
+    const bool wide = wide_all && !(w.kind & CLITE_WGRAD_NARROW);
+    const int kind = w.kind & ~CLITE_WGRAD_NARROW;
+    if (kind == 0) {
       const clite_conv& c = w.cv;
       if (c.dtype != CLITE_BF16 || c.C % 8 || c.K % 8 || (c.R * c.S > 1 && (c.C % 32 || c.K % 32))) return -1;
       if (!fits32((size_t)c.N * c.H * c.W * c.C, 4) || !fits32((size_t)c.N * c.Ho * c.Wo * c.K, 4)) return -1;
       const int P = c.N * c.Ho * c.Wo, Ncols = c.R * c.S * c.C;
       const uint32_t yb = (uint32_t)((size_t)P * c.K * 2), xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * 2);
-      if (c.K <= 64) conv_fewk.add(XS64{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 64, 128));
+      if (wide && c.K >= 256 && Ncols >= 256) conv_w256.add(WS256{w.a, yb, c.K, c.K, P, 1}, WG256{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 256, 256, WIDE_BK, WKCHUNK));
+      else if (c.K <= 64) conv_fewk.add(XS64{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 64, 128));
       else if (Ncols <= 64) conv_fewc.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG64{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 64));
       else conv_full.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 128));
-    } else if (w.kind == 1) {
+    } else if (kind == 1) {
       if (w.M <= 0 || w.N <= 0 || w.K <= 0 || w.M % 8 || w.N % 8 || w.lda % 8 || w.ldb % 8 || w.lda < w.M || w.ldb < w.N) return -1;
       if (!fits32((size_t)w.K * w.lda, 4) || !fits32((size_t)w.K * w.ldb, 4)) return -1;
       const uint32_t ab = (uint32_t)((((size_t)w.K - 1) * w.lda + w.M) * 2), bb = (uint32_t)((((size_t)w.K - 1) * w.ldb + w.N) * 2);
-      linear.add(XS128{w.a, ab, w.lda, w.M, w.K, 1}, XS128{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 128, 128));
+      if (wide && w.M >= 256 && w.N >= 256) linear_w256.add(WS256{w.a, ab, w.lda, w.M, w.K, 1}, WS256{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 256, 256, WIDE_BK, WKCHUNK));
+      else linear.add(XS128{w.a, ab, w.lda, w.M, w.K, 1}, XS128{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 128, 128));
     } else {
       return -1;
     }
   }
   conv_full.build_map(); conv_fewk.build_map(); conv_fewc.build_map(); linear.build_map();
-  const size_t o0 = 0, o1 = o0 + conv_full.bytes(), o2 = o1 + conv_fewk.bytes(), o3 = o2 + conv_fewc.bytes(), need = o3 + linear.bytes();
+  conv_w256.build_map(); linear_w256.build_map();
+  const size_t o0 = 0, o1 = o0 + conv_full.bytes(), o2 = o1 + conv_fewk.bytes(), o3 = o2 + conv_fewc.bytes(), o4 = o3 + linear.bytes(),
+               o7 = o4 + conv_w256.bytes(), need = o7 + linear_w256.bytes();
   if (need > ws_bytes) return -2;
   char* host = (char*)ws_host;
   char* dev = (char*)ws_dev;
-  // fill the host image, copy it once, then enqueue the (up to four) launches: they read `dev` after the copy, in stream order
+  // fill the host image, copy it once, then enqueue the (up to six) launches: they read `dev` after the copy, in stream order. The long
+  // one-per-CU workgroups of the wide buckets go first; the 4-wave buckets fill in behind them
   conv_full.stage(host, o0); conv_fewk.stage(host, o1); conv_fewc.stage(host, o2); linear.stage(host, o3);
+  conv_w256.stage(host, o4); linear_w256.stage(host, o7);
   int rc = (int)hipMemcpyAsync(dev, host, need, hipMemcpyHostToDevice, st);
   if (rc) return rc;
+  if ((rc = conv_w256.launch(dev, o4, st))) return rc;
+  if ((rc = linear_w256.launch(dev, o7, st))) return rc;
   if ((rc = conv_full.launch(dev, o0, st))) return rc;
   if ((rc = conv_fewk.launch(dev, o1, st))) return rc;
   if ((rc = conv_fewc.launch(dev, o2, st))) return rc;

@@ -318,6 +318,8 @@ class WgradGroup:
     every operand referenced and owns the descriptor workspace (device + pinned host), so it must outlive a captured graph that contains
     its launch."""
 
+    wide = True          # class-wide switch (tools/ab_runtime.py hip.WgradGroup.wide=0): False keeps every member on the 4-wave tiles (CLITE_WGRAD_NARROW)
+
     def __init__(self, dt, workspace=None):
         """workspace: optional pre-allocated (device uint8 tensor, pinned host uint8 tensor) of equal size — required when launch() runs
         inside a stream capture, where pinned memory cannot be allocated (alloc_workspace())."""
@@ -337,7 +339,7 @@ class WgradGroup:
 
     def conv(self, dy, x, cv, dw):
         it = WgradItem()
-        it.kind, it.a, it.b, it.out, it.cv = 0, p(dy), p(x), p(dw), cv
+        it.kind, it.a, it.b, it.out, it.cv = (0 if self.wide else 0x100), p(dy), p(x), p(dw), cv
         self.items.append(it)
         self.keep += [dy, x, dw]
         ncols = cv.R * cv.S * cv.C
@@ -346,7 +348,7 @@ class WgradGroup:
     def linear(self, A, B, M, N, K, out, lda=None, ldb=None, ldc=None):
         """out[M][N] += A[K][M]^T B[K][N] (f32 accumulate)."""
         it = WgradItem()
-        it.kind, it.a, it.b, it.out = 1, p(A), p(B), p(out)
+        it.kind, it.a, it.b, it.out = (1 if self.wide else 0x101), p(A), p(B), p(out)
         it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, K, lda or M, ldb or N, ldc or N
         self.items.append(it)
         self.keep += [A, B, out]

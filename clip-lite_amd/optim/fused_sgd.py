@@ -68,12 +68,14 @@ class FusedSGD(torch.optim.Optimizer):
                 else:
                     spans.append([o, o + n])
         self._frozen_spans = [tuple(x) for x in spans]
+        rows.sort()                      # by arena offset: a [lo, hi) element range of the arena is then a contiguous run of items (launch(span=...))
         arr = (hip.OptimItem * len(rows))()
         for i, (s, c, lr, wd) in enumerate(rows):
             arr[i].start, arr[i].count, arr[i].lr, arr[i].wd = s, c, lr, wd
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self._items = host.to(self.arena.device)
         self._n_items = len(rows)
+        self._item_starts = [r[0] for r in rows]
         self._items_key = key
 
     def _lr_mult(self):
@@ -141,12 +143,20 @@ class FusedSGD(torch.optim.Optimizer):
             self.arena.flat_g[lo:hi].zero_()
 
     @torch.no_grad()
-    def launch(self):
+    def launch(self, span=None):
+        """span = (lo, hi): update only the tensors whose arena offset lies in [lo, hi) — the captured step updates the image encoder at the end
+        of a step and the rest at the start of the next one (train_loop.TrainStep, defer_update); every tensor exactly once per step."""
         self.arena.join()
         self._build_items()
         self.zero_frozen()
-        hip.sgd_step(self.arena.flat_p, self.arena.flat_g, self.flat_v, self.flat_slow, self.arena.flat_lp,
-                     C.c_void_p(self._items.data_ptr()), self._n_items, self.hp, self.sumsq)
+        first, n = 0, self._n_items
+        if span is not None:
+            import bisect
+            first = bisect.bisect_left(self._item_starts, span[0])
+            n = bisect.bisect_left(self._item_starts, span[1]) - first
+        if n > 0:
+            hip.sgd_step(self.arena.flat_p, self.arena.flat_g, self.flat_v, self.flat_slow, self.arena.flat_lp,
+                         C.c_void_p(self._items.data_ptr() + first * C.sizeof(hip.OptimItem)), n, self.hp, self.sumsq)
         self.arena._tr_stale = True          # the bf16 weights changed: the transposed copies of the dgrad GEMMs are out of date
         self._dirty = False
 

@@ -65,7 +65,7 @@ class TrainStep:
     with the RCCL all-reduce of the flat gradient arena issued eagerly between them (collectives stay outside the captures)."""
 
     def __init__(self, model, optimizer, scheduler, scaler, clip_grad_norm, exchange=None, graph=False, graph_warmup=2, pad_to=None,
-                 allow_eager_fallback=False):
+                 allow_eager_fallback=False, defer_update=False):
         """pad_to: caption length the step is captured at (DATA.MAX_CAPTION_LENGTH). The reference's collate pads each batch to ITS longest
         caption (data/dataloader.py:218-236), so L changes from batch to batch; shorter batches are right-padded (id 0 = [PAD], mask 0) into
         the captured buffers. Masked positions receive exactly zero attention weight and feed nothing downstream of the [CLS] pooler, so
@@ -76,13 +76,37 @@ class TrainStep:
         self.clip, self.exchange = clip_grad_norm, exchange
         self.inner = optimizer.optimizer if hasattr(optimizer, "optimizer") else optimizer
         self.graph = bool(graph)
+        # defer_update (captured per-phase steps only): the update needs the global gradient norm, i.e. the LAST weight gradient of the image
+        # backward, so it cannot start earlier — but only the image encoder's parameters are needed right away (the next image forward). With
+        # defer_update the step ends after [norm + update of the image encoder]; the text encoder's and the heads' share (85 % of the parameters,
+        # 0.7 of the 0.87 ms) runs as the FIRST thing of the next step on the text encoder's stream, which idles ~1 ms there while the image
+        # forward is still going. Same kernels, same arguments, every tensor updated exactly once per step: parameters are bit-identical to the
+        # undeferred step once finish() has run. Anything that reads parameters between steps (checkpoint, evaluation, state_dict) must call
+        # finish() first; train_loop.main and bench.py do. MEASURED NEUTRAL on MI355X (17.32 vs 17.35 ms: the update and the first stages of the
+        # image forward are both HBM-bound, so the overlap is zero-sum) and therefore OFF by default; kept as an option with its exactness test.
+        self.defer_update = bool(defer_update)
+        self._pending_rest = False
         self.graph_warmup = graph_warmup
         self._eager_steps = 0
         self._g = self._g_update = self._graphs = None
         self._static_batch = self._static_out = None
         self.replays = self.eager_steps = 0        # how many steps took the captured / the eager launch path
 
+    def finish(self):
+        """Run what a deferred step left undone (the update of everything but the image encoder); no-op otherwise. Leaves the current stream
+        ordered behind it."""
+        if not self._pending_rest:
+            return
+        rt = self.model.runtime
+        main, side = torch.cuda.current_stream(rt.device), rt.side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._graphs["update_rest"].replay()
+        main.wait_stream(side)
+        self._pending_rest = False
+
     def _eager(self, batch):
+        self.finish()
         self.eager_steps += 1
         self.optimizer.zero_grad()
         output_dict = self.model(batch)
@@ -230,9 +254,24 @@ class TrainStep:
             bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous(), defer=keep["wg_t"])
             keep["wg_t"].launch()
 
-        def update():
-            self._capture_update()
+        A0 = rt.arena
+        img_span = A0.region("image_encoder.")
+
+        def norm():
+            self.inner.arena.join()
+            if self.clip and self.clip > 0:
+                self.inner._build_items()
+                self.inner.zero_frozen()          # frozen tensors' unconditional gradients must not enter the norm
+                self.inner.sumsq.zero_()
+                hip_sumsq(self.inner)
+
+        def update_img():                 # what the next image forward needs ...
+            self.inner.launch(span=img_span)
             rt.end_capture()
+
+        def update_rest():                # ... and the rest (text encoder, heads): arena order is text_encoder | image_encoder | loss
+            self.inner.launch(span=(0, img_span[0]))
+            self.inner.launch(span=(img_span[1], A0.total))
 
         rt.begin_capture()
         try:
@@ -247,7 +286,9 @@ class TrainStep:
                 for i, sg in enumerate(segs):       # every segment's weight gradients but the last one's replay on the side stream
                     capture("image_bwd_" + sg, pool_main, image_bwd(i))
                     capture("wgrad_" + sg, pool_side if i < len(segs) - 1 else pool_main, wgrad(i))
-                capture("update", pool_main, update)
+                capture("norm", pool_main, norm)
+                capture("update_rest", pool_side, update_rest)
+                capture("update_img", pool_main, update_img)
         except BaseException:
             rt.abort_capture()
             raise
@@ -261,7 +302,7 @@ class TrainStep:
         l2, l3, l4, img = A.region(pre + "layer2."), A.region(pre + "layer3."), A.region(pre + "layer4."), self._regions["image_encoder"]
         assert img[0] <= l2[0] <= l2[1] <= l3[0] <= l3[1] <= l4[0] <= l4[1] <= img[1]
         self._seg_spans = [(l3[0], img[1]), (l2[0], l3[0]), (img[0], l2[0])]          # s0 = [layer4, layer3], s1 = layer2, s2 = layer1 + stem
-        self._g, self._graphs, self._keep, self._static_out = graphs["update"], graphs, keep, keep["result"]
+        self._g, self._graphs, self._keep, self._static_out = graphs["update_img"], graphs, keep, keep["result"]
         self._segs = segs
 
     def _replay_direct(self):
@@ -308,7 +349,12 @@ class TrainStep:
                 ex.reduce_span(pos, rt.arena.total, after=main)
             ex.wait()
         main.wait_stream(side)
-        G["update"].replay()
+        G["norm"].replay()
+        G["update_img"].replay()
+        if self.defer_update:
+            self._pending_rest = True          # first thing of the next step, on the side stream (_replay), or finish()
+        else:
+            G["update_rest"].replay()
 
     def _capture_single(self, batch):
         rt = self.model.runtime
@@ -380,6 +426,10 @@ class TrainStep:
         feed = rt.side_stream if self._graphs is not None else None
         if feed is not None:
             feed.wait_stream(torch.cuda.current_stream(rt.device))      # the previous step's update (main) read hp; its text graphs (side) the captions
+            if self._pending_rest:            # the deferred share of the previous step's update: ahead of this step's hyper-parameter upload
+                with torch.cuda.stream(feed):
+                    self._graphs["update_rest"].replay()
+                self._pending_rest = False
         for k, v in batch.items():
             if torch.is_tensor(v):
                 dst = self._static_batch[k]
@@ -488,6 +538,7 @@ def main(_A: argparse.Namespace):
                 logger.info("train " + " ".join(f"{k}={v:.5f}" for k, v in comps.items()))
 
         if iteration % _A.checkpoint_every == 0:
+            step.finish()          # the deferred share of the last update: before anything reads the parameters
             if dist.is_master_process():
                 checkpoint_manager.step(iteration)
             dist.synchronize()
@@ -507,9 +558,11 @@ def main(_A: argparse.Namespace):
                 logger.info("val " + " ".join(f"{k}={float(v):.5f}" for k, v in val_loss_dict.items()))
 
         if (iteration / _C.OPTIM.NUM_ITERATIONS) > 0.8 and iteration % _A.climax_freq == 0:
+            step.finish()
             if dist.is_master_process():
                 checkpoint_manager.climax_step(iteration)
             dist.synchronize()
+    step.finish()
 
 
 def cli():

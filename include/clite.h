@@ -143,6 +143,8 @@ int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float*
  * library fills ws_host, copies it with one hipMemcpyAsync on `stream` and launches — under stream capture that is a memcpy node, so ws_host
  * must stay alive and unchanged for as long as the captured graph is replayed. With dtype = CLITE_F32, in deterministic-reduction mode, or
  * with ws_dev / ws_host NULL the members are launched one by one. Returns 0, -1 (bad member), -2 (workspace too small) or a HIP status. */
+#define CLITE_WGRAD_NARROW 0x100   /* OR-ed into `kind`: keep this member on the 4-wave 128 x 128 x 32 tiles (members with >= 256 rows and columns
+                                    * otherwise take the 8-wave 256 x 256 tile); for A/B timing and parity tests */
 typedef struct clite_wgrad_item {
   int32_t kind;
   const void* a;

@@ -124,6 +124,60 @@ def test_f32_mode_matches_oracle(visual, mode, layers, B, S, Ls, idim):
             assert torch.allclose(sd[k].float().cpu(), sdo[k].float(), rtol=rt_, atol=at_), (k, (sd[k].float().cpu() - sdo[k].float()).abs().max().item())
 
 
+def _rerun_hip(M, batch):
+    """One more forward + backward of the HIP model on the same batch with a clean gradient arena (train-mode BatchNorm uses batch statistics,
+    so the running-statistic updates of the earlier runs do not change the result)."""
+    M.runtime.arena.flat_g.zero_()
+    for p in M.parameters():
+        if p.grad is not None and not hasattr(p, "_clite"):
+            p.grad = None
+    out = M({k: v.cuda() for k, v in batch.items()})
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("visual,mode,layers,B,S,Ls,idim", [
+    ("resnet18", "train_sbert", 2, 4, 64, 9, 512),
+    ("resnet50", "train_sbert", 1, 8, 128, 30, 2048),
+])
+def test_f32_fast_mode_matches_oracle_median_of_three(visual, mode, layers, B, S, Ls, idim):
+    """The FAST (float-atomic, split-K) exact-f32 path — the default reductions, not the deterministic twins — against the oracle, with a
+    metric that survives ReLU-kink events: summation-order noise (~1e-5 after a dozen train-mode BatchNorms) can put one
+    activation on the other side of its kink in one run, which switches its whole incoming gradient — a bimodal error on one tensor in about
+    one run in ten (tools/diag_ragged*.py) although every kernel is right. Three independent forward + backward passes are made; the LOSS
+    must meet the 1e-4 bar in EVERY pass (a kink moves the loss continuously), and every parameter gradient is judged by the MEDIAN over the
+    three passes of its error against the fp64 evaluation, at the same bar as the deterministic test: max(2e-3 max|truth|, 16 x the fp32
+    oracle's own error). A wrong kernel fails all three passes; a kink event would have to hit the same tensor in two of three."""
+    M, Mo, Md, out, ref = run_case(visual, mode, layers, False, B, S, Ls, idim)
+    batch = {"image": det_tensor("image", (B, 3, S, S), "normal")}
+    ids = torch.randint(1000, 30522, (B, Ls), generator=torch.Generator().manual_seed(1))
+    ids[:, 0] = 101
+    ids[:, -1] = 102
+    mask = torch.ones(B, Ls, dtype=torch.long)
+    mask[B - 1, Ls - 2:] = 0
+    ids[mask == 0] = 0
+    batch["input_ids"], batch["attention_mask"] = ids, mask
+    lr = ref["loss"].item()
+    passes = [grad_report(M, Mo, Md)]
+    assert abs(out["loss"].item() - lr) < 1e-4
+    for _ in range(2):
+        o = _rerun_hip(M, batch)
+        assert abs(o["loss"].item() - lr) < 1e-4, (o["loss"].item(), lr)
+        passes.append(grad_report(M, Mo, Md))
+    gmax = max(r[2] for r in passes[0])
+    bad, events = [], 0
+    for rows in zip(*passes):
+        errs = sorted(r[0] for r in rows)
+        _, eo, sc, k = rows[0]
+        bar = max(2e-3 * max(sc, 1e-3 * gmax), 16 * eo)
+        events += errs[2] > bar >= errs[1]
+        if errs[1] > bar:
+            bad.append((errs, eo, sc, k))
+    print(f"{events} tensors had one pass beyond the bar (ReLU-kink events); {len(bad)} beyond it in the median")
+    assert not bad, sorted(bad, key=lambda t: -t[0][1])[:5]
+
+
 @pytest.mark.usefixtures("deterministic_reductions")
 def test_f32_mode_ragged_captions_odd_batch_non_square_images():
     """Edge cases of the input contract in one f32 case against the oracle: batch 6 (not a multiple of any tile), 96 x 160 images (non-square,
@@ -266,6 +320,48 @@ def test_full_size_config2_f32_matches_oracle_fixture():
             got = grads[key[5:]].grad.detach().float().cpu().reshape(want.shape)
             tol = 4e-2 if "img_encoder.bn1" in key else 2e-3
             assert (got - want).abs().max().item() <= tol * max(want.abs().max().item(), 1e-8), key
+
+
+def test_full_size_config2_f32_fast_mode_matches_oracle_fixture_median_of_three():
+    """The fast-reduction twin of the test above (the default launchers: float-atomic statistics, split-K weight gradients, grouped launches
+    off in f32): three passes, the loss and its components within 1e-4 in EVERY pass, gradient norms and the stored head-level gradients by the
+    median of the three passes at the deterministic test's bars."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_full", os.path.join(G, "make_golden_full.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    fx = np.load(os.path.join(G, "full_c2_b128.npz"))
+    M = build("resnet50", "train_sbert", 12, False, 2048)
+    batch, noise = gen.inputs()
+    M.loss.set_prior_noise(noise[0].cuda(), noise[1].cuda())
+    norm_err, grad_err = {}, {}
+    for i in range(3):
+        if i == 0:
+            out = M({k: v.cuda() for k, v in batch.items()})
+            out["loss"].backward()
+            torch.cuda.synchronize()
+        else:
+            out = _rerun_hip(M, batch)
+        assert abs(out["loss"].item() - float(fx["loss"])) < 1e-4, (i, out["loss"].item(), float(fx["loss"]))
+        for k, v in out["loss_components"].items():
+            assert abs(float(v) - float(fx["comp_" + k])) < 1e-4, (i, k, float(v), float(fx["comp_" + k]))
+        norms = {}
+        for n, p in M.named_parameters():
+            top = n.split(".")[0]
+            norms[top] = norms.get(top, 0.0) + float((p.grad.double() ** 2).sum())
+        for k, v in norms.items():
+            want = float(fx["gradnorm_" + k])
+            norm_err.setdefault(k, []).append(abs(v ** 0.5 - want) / want)
+        grads = dict(M.named_parameters())
+        for key in fx.files:
+            if key.startswith("grad_"):
+                want = torch.from_numpy(fx[key])
+                got = grads[key[5:]].grad.detach().float().cpu().reshape(want.shape)
+                grad_err.setdefault(key, []).append((got - want).abs().max().item() / max(want.abs().max().item(), 1e-8))
+    for k, e in norm_err.items():
+        assert sorted(e)[1] <= 2e-3, (k, e)
+    for key, e in grad_err.items():
+        assert sorted(e)[1] <= (4e-2 if "img_encoder.bn1" in key else 2e-3), (key, e)
 
 
 def test_full_size_config2_bf16_tracks_oracle_fixture():

@@ -139,29 +139,31 @@ def test_checkpoint_resume_is_bit_exact_in_deterministic_mode(tmp_path, determin
 
 
 def test_checkpoint_resume_equivalence_fast_mode(tmp_path):
-    """The same problem with the float-atomic (fast) reductions. The bound is the measured spread of two UNINTERRUPTED runs of this
-    problem from identical state (tools/diag_spread.py on MI355X, 12 runs, gpurun_out/r2_spread.txt: worst per-tensor relative L2 difference
-    after the 4 steps 1.6e-4 — layer1.0.bn1.bias; median 1.3e-6; exactly 0 in deterministic mode): per tensor
-    ||got - want|| <= 2e-3 * max(||want||, 1e-3), i.e. ~12x that spread. The exact statement is the deterministic-mode test above.
-    The spread has a heavy tail: about once in 30 runs a single activation sitting on a ReLU kink (|pre-activation| < 1e-5, the size of the
-    forward's summation-order noise: tools/diag_ragged_fwd.py shows one such mask element flipping from run to run) lands on different
-    sides in the two runs, its whole incoming gradient switches on or off, and the 4-sample BatchNorms amplify that ~10x per step — observed
-    once: 2.4e-2 on the momentum arena. A restore that misses state is an O(1) difference, so the test allows ONE such event: every tensor
-    within the tight bound, or all within 25x of it."""
-    want, got = _resume_problem(tmp_path, False)
-    tight, loose = [], []
-    for k in want:
-        err = (got[k] - want[k]).norm().item()
-        # the momentum arena holds raw gradient sums (not damped by the learning rate): observed 2.8e-3 on it, bound 1e-2
+    """The same problem with the float-atomic (fast) reductions, at the TIGHT bound — the measured spread of two uninterrupted runs of this
+    problem from identical state (tools/diag_spread.py on MI355X, 12 runs, profiles/r2_resume_spread.txt: worst per-tensor relative L2 difference
+    after the 4 steps 1.6e-4, median 1.3e-6; exactly 0 in deterministic mode) x 12: per tensor ||got - want|| <= 2e-3 max(||want||, 1e-3)
+    (1e-2 on the momentum arena, which holds raw gradient sums).
+    That spread has a heavy tail: about once in 30 runs one activation sitting on a ReLU kink lands on different sides in the two runs and the
+    4-sample BatchNorms amplify the switched gradient ~10x per step (tools/diag_ragged_fwd.py; observed once: 2.4e-2 on the momentum arena).
+    Round 2 answered that with a blanket 25x looser bound, which a small real restore bug would also have passed. Instead the
+    whole save / restore / continue experiment is repeated three times and every tensor is judged by the MEDIAN of its three errors at the
+    tight bound: a kink event is one outlier in one repeat; a restore that misses state is wrong in all three."""
+    errs = {}
+    for rep in range(3):
+        d = tmp_path / f"rep{rep}"
+        d.mkdir()
+        want, got = _resume_problem(d, False)
+        for k in want:
+            errs.setdefault(k, []).append(((got[k] - want[k]).norm().item(), max(want[k].norm().item(), 1e-3)))
+    bad, events = [], 0
+    for k, es in errs.items():
         tol = 1e-2 if k == "__momentum__" else 2e-3
-        scale = max(want[k].norm().item(), 1e-3)
-        if err > tol * scale:
-            tight.append((k, err, scale))
-        if err > 25 * tol * scale:
-            loose.append((k, err, scale))
-    assert not loose, loose[:5]
-    if tight:
-        print(f"ReLU-kink event: {len(tight)} tensors beyond the tight bound, all within 25x of it; worst {max(tight, key=lambda t: t[1] / t[2])}")
+        rel = sorted(e / sc for e, sc in es)
+        events += rel[2] > tol >= rel[1]
+        if rel[1] > tol:
+            bad.append((k, rel))
+    print(f"{events} tensors had one repeat beyond the tight bound (ReLU-kink events)")
+    assert not bad, bad[:5]
 
 
 def test_deterministic_mode_repeats_bitwise_and_tracks_fast_mode():
@@ -469,6 +471,54 @@ def test_bench_two_ranks_keep_identical_parameters_through_captured_steps(exchan
     res = json.loads(lines[0])
     assert res["launch"] == "hipGraph replay" and res["n_gpus"] == 2 and res["config"]["global_batch"] == 32
     assert res["replicas_identical"] is True and np.isfinite(res["loss"])
+
+
+@pytest.mark.usefixtures("deterministic")
+def test_deferred_update_is_bit_identical_after_finish():
+    """TrainStep(defer_update=True): the update of the text encoder and the heads runs at the start of the NEXT step on the side stream (beside
+    the image forward) instead of at the end of its own. Same kernels on the same arguments, every tensor updated exactly once per step: in the
+    deterministic-reduction mode the parameters, momentum and Lookahead slow weights after finish() are bit-identical to the undeferred run
+    — across a Lookahead sync (k = 3), with dropout and prior noise on — and before finish() exactly the image encoder has moved."""
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    from clip_lite_amd.optim import FusedSGD, Lookahead
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    from clip_lite_amd.train_loop import TrainStep
+    from clip_lite_amd.utils.common import GradScaler
+    B, L = 8, 12
+    batches = []
+    for i in range(3):
+        ids = torch.randint(1000, 30522, (B, L), generator=torch.Generator().manual_seed(i))
+        batches.append({"image": det_tensor(f"gimg{i}", (B, 3, 64, 64), "normal").cuda(), "input_ids": ids.cuda(),
+                        "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()})
+    res = []
+    for defer in (False, True):
+        torch.manual_seed(7)
+        te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
+        M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=True)).to("cuda").train()
+        groups = [{"params": [p], "lr": 1e-3 if "image_encoder" in n else 1e-4, "weight_decay": 1e-4} for n, p in M.named_parameters()]
+        opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
+        sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
+        step = TrainStep(M, opt, sched, GradScaler(True), 10.0, None, graph=True, graph_warmup=2, defer_update=defer)
+        losses = [step(batches[s % 3])["loss"].item() for s in range(6)]
+        A = M.runtime.arena
+        if defer:
+            assert step._pending_rest and step.replays == 4
+            torch.cuda.synchronize()
+            lo, hi = A.region("image_encoder.")
+            before = res[0][1]
+            assert torch.equal(A.flat_p[lo:hi], before[lo:hi])                   # the image encoder is up to date ...
+            assert not torch.equal(A.flat_p[:lo], before[:lo])                  # ... the text encoder is one update behind
+            assert A.flat_g[:lo].any() and not A.flat_g[lo:hi].any()            # its gradients are still there, unconsumed
+        step.finish()
+        step.finish()                                                           # idempotent
+        torch.cuda.synchronize()
+        assert not step._pending_rest and not A.flat_g.any()
+        res.append((losses, A.flat_p.clone(), opt.optimizer.flat_v.clone(), opt.optimizer.flat_slow.clone(), A.flat_lp.clone()))
+    (l0, p0, v0, s0, lp0), (l1, p1, v1, s1, lp1) = res
+    assert l0 == l1
+    assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(s0, s1) and torch.equal(lp0, lp1)
 
 
 @pytest.mark.gpu

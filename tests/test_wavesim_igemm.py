@@ -306,7 +306,10 @@ def test_grouped_weight_gradients():
     L.clite_wgrad_group.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.clite_wgrad_group_workspace.argtypes = [C.c_int, C.c_int64, C.c_void_p]
     items, refs, outs, hold = [], [], [], []
-    for (N, H, W, Cc, K, R, st, pad) in [(2, 8, 8, 32, 64, 3, 1, 1), (3, 6, 6, 64, 136, 1, 1, 0), (2, 9, 7, 128, 160, 1, 2, 0), (9, 32, 32, 32, 64, 1, 1, 0)]:      # last: 9216 pixels = 288 K tiles -> two k-chunks
+    # 4th: 9216 pixels = 288 K tiles -> two k-chunks. Then the 8-wave wide bucket: 288 x 288 outputs (256 x 256 tiles, ragged both ways, a
+    # ragged last K tile of 64), and two 128-wide outputs that stay on the 4-wave tiles
+    for (N, H, W, Cc, K, R, st, pad) in [(2, 8, 8, 32, 64, 3, 1, 1), (3, 6, 6, 64, 136, 1, 1, 0), (2, 9, 7, 128, 160, 1, 2, 0), (9, 32, 32, 32, 64, 1, 1, 0),
+                                         (2, 7, 7, 32, 288, 3, 1, 1), (1, 10, 10, 128, 256, 1, 1, 0), (1, 9, 9, 256, 128, 1, 1, 0)]:
         Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
         cv = Conv(BF16, N, H, W, Cc, K, R, R, st, pad, Ho, Wo)
         x, xb = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), BF16)
@@ -321,6 +324,13 @@ def test_grouped_weight_gradients():
     it = Item(); it.kind, it.a, it.b, it.out = 1, ptr(Ab).value, ptr(Bb).value, ptr(out).value
     it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, Kt, M, 2 * N, N
     items.append(it); outs.append(out); refs.append(1 + A.T @ B[:, :N]); hold += [Ab, Bb]
+    Kt, M, N = 100, 256, 264                                  # linear member on the 256 x 256 wide tile
+    A2, A2b = _prep(rng.standard_normal((Kt, M), dtype=np.float32), BF16)
+    B2, B2b = _prep(rng.standard_normal((Kt, N), dtype=np.float32), BF16)
+    out2 = np.ones((M, N), np.float32)
+    it = Item(); it.kind, it.a, it.b, it.out = 1, ptr(A2b).value, ptr(B2b).value, ptr(out2).value
+    it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, Kt, M, N, N
+    items.append(it); outs.append(out2); refs.append(1 + A2.T @ B2); hold += [A2b, B2b]
     nb = C.c_uint64(0)
     assert L.clite_wgrad_group_workspace(len(items), 4096, C.byref(nb)) == 0
     ws_dev, ws_host = np.zeros(nb.value, np.uint8), np.zeros(nb.value, np.uint8)

@@ -29,7 +29,15 @@ def main():
     with contextlib.redirect_stdout(sys.stderr):
         model, opt, sched = bench.build(args, device)
     rt = model.runtime
-    for s in [x for x in args.sets if not x.startswith("step.")]:
+    for s in [x for x in args.sets if x.startswith("hip.")]:        # e.g. hip.WgradGroup.wide=0
+        from clip_lite_amd import hip
+        path, v = s[4:].split("=")
+        obj = hip
+        *parents, leaf = path.split(".")
+        for name in parents:
+            obj = getattr(obj, name)
+        setattr(obj, leaf, type(getattr(obj, leaf))(int(v)))
+    for s in [x for x in args.sets if not x.startswith("step.") and not x.startswith("hip.")]:
         k, v = s.split("=")
         old = getattr(rt, k)
         setattr(rt, k, type(old)(int(v)) if isinstance(old, (bool, int)) else type(old)(v))
