@@ -10,7 +10,7 @@ SIMOBJS    := $(patsubst $(CSRC)/%.hip,build/sim/%.o,$(SRCS)) build/sim/wavesim.
 HIPFLAGS   := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wno-unused-value
 SIMFLAGS   := -x c++ -std=c++20 -O1 -g -fPIC -pthread -Itests/wavesim -Iinclude -I$(CSRC) -include tests/wavesim/wavesim.h -Wno-unknown-attributes -Wno-unused-value -Wno-psabi -DCLITE_BN_SLOTS=4 $(SIM_EXTRA)
 
-.PHONY: hip sim diag clean
+.PHONY: hip sim diag variant clean
 hip: $(LIBDIR)/libclite_hip.so
 # diagnostic build (tools/README.md): kernel-selection knobs from the environment + the round-1 register-staged engine; never loaded by the product
 diag: build/diag/libclite_hip_diag.so
@@ -23,6 +23,15 @@ $(LIBDIR)/libclite_hip.so: $(OBJS)
 build/hip/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build/hip
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# A/B variant of the PRODUCT build (no diagnostic code): make variant VAR_EXTRA="-DCLITE_BN_PREFETCH=0"; load with CLITE_HIP_LIB=build/var/libclite_hip_var.so
+VAROBJS    := $(patsubst $(CSRC)/%.hip,build/var/%.o,$(SRCS))
+variant: build/var/libclite_hip_var.so
+build/var/libclite_hip_var.so: $(VAROBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(VAROBJS)
+build/var/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build/var
+	$(HIPCC) $(HIPFLAGS) $(VAR_EXTRA) -c $< -o $@
 
 DIAGOBJS   := $(patsubst $(CSRC)/%.hip,build/diag/%.o,$(SRCS))
 build/diag/libclite_hip_diag.so: $(DIAGOBJS)

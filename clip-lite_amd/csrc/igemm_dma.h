@@ -436,6 +436,9 @@ __global__ __launch_bounds__(256) void igemm_dma_bn_kernel(LA la, LB lb, Epilogu
   constexpr int SMEM = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
   constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
   static_assert(sizeof(T) == 2 || sizeof(T) == 4, "bf16 or f32");
+  // (Measured and rejected, round 3: touching every 128-byte line of the tile's BatchNorm-input / residual rows by LDS-DMA into a scratch at
+  // the start of the tile, so that the epilogue's loads hit L2 — same-box A/B 16.99 -> 17.20 ms: the extra requests compete with the
+  // operand ring for the same L2 -> CU path that bounds the main loop.)
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
   const int tid = threadIdx.x;
