@@ -629,7 +629,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
   //  * staging one wave row at a time (34 KB, under the operand ring) + __launch_bounds__(256, 3) for three workgroups per CU: the
   //    allocator then spills 20 registers and the launches get slower — 256 -> 64 191 -> 267 us, 64 -> 256 97 -> 116, step 18.7 -> 19.2 ms.
 #ifndef CLITE_BN_AHEAD
-#define CLITE_BN_AHEAD 2
+#define CLITE_BN_AHEAD 4
 #endif
   constexpr int AHEAD = CLITE_BN_AHEAD;
   Raw8<T> pa[ROWS_PT], py[ROWS_PT], pr[ROWS_PT];

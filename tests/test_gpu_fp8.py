@@ -2,6 +2,7 @@
 this build's and are stated here): the quantiser against torch's float8_e4m3fn cast, the fp8 GEMM / conv against fp32 torch on the
 DE-QUANTISED operands (products of two e4m3 values are exact in f32, so only the summation order differs: 2e-3 of max incl. one bf16 output
 rounding), and the whole step with fp8 forward operands against the bf16 step."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -115,3 +116,48 @@ def test_fp8_forward_step_tracks_bf16_step():
     cos_self = (g0 @ g2 / (g0.norm() * g2.norm())).item()          # two bf16 runs: the float-atomic noise floor of this problem
     print(f"loss bf16 {l0:.5f} fp8-forward {l1:.5f}; gradient cosine fp8~bf16 {cos:.4f} (bf16~bf16 {cos_self:.4f})")
     assert abs(l0 - l1) < 3e-2 and cos >= 0.90
+
+
+def test_resnet101_with_fp8_forward_tracks_its_bf16_step():
+    """BASELINE configs[4] as stated — ResNet-101 WITH fp8 on (the backbone and the fp8 path had only been tested separately):
+    ResNet-101 + 2-layer BERT + heads (2048-d image features), batch 16, 128 x 128, on the conditioned problem (the last BatchNorm gain of
+    every Bottleneck x 0.1, tests/test_gpu_ops.py). The step with e4m3 forward operands (101 convs + the BERT linears on
+    v_mfma_f32_32x32x16_fp8_fp8, per-tensor current scaling) against the bf16 step on the same weights and batch. Stated bar:
+    loss within 3e-2; gradient-arena cosine >= 0.85 (twice the depth of the ResNet-18 case: e4m3's 2^-4 per-element rounding enters 101
+    times); every loss finite; and a NaN planted in the input image must come out as a NaN loss in fp8 mode (the quantiser no longer
+    launders non-finite values: ADVICE r2)."""
+    from detfill import det_tensor
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    B, L = 16, 12
+    ids = torch.randint(1000, 30522, (B, L), generator=torch.Generator().manual_seed(9))
+    batch = {"image": det_tensor("f8img101", (B, 3, 128, 128), "normal").cuda(), "input_ids": ids.cuda(), "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()}
+    u = (det_tensor("f8u1b", (B, 2048), "uniform").cuda(), det_tensor("f8u2b", (B, 768), "uniform").cuda())
+    res = []
+    for fp8 in (False, True):
+        torch.manual_seed(4)
+        te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
+        te.strans.hidden_dropout_prob = te.strans.attention_probs_dropout_prob = 0.0
+        M = VLInfoModel(te, ImageEncoder("resnet101"), JSDInfoMaxLoss(2048, 768, "dot", 0.1, True, True), "train_sbert", is_amp=True)
+        with torch.no_grad():
+            for n, p in M.named_parameters():
+                if n.endswith("bn3.weight"):           # the last BatchNorm of a Bottleneck's residual branch
+                    p.mul_(0.1)
+        M = M.to("cuda").train()
+        M.runtime.fp8 = fp8
+        M.loss.set_prior_noise(*u)
+        out = M(batch)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res.append((out["loss"].item(), M.runtime.arena.flat_g.clone()))
+        if fp8:
+            bad = {k: v.clone() for k, v in batch.items()}
+            bad["image"][3, 1, 17, 5] = float("nan")
+            M.runtime.arena.flat_g.zero_()
+            assert not np.isfinite(M(bad)["loss"].item())
+    (l0, g0), (l1, g1) = res
+    cos = (g0 @ g1 / (g0.norm() * g1.norm())).item()
+    print(f"ResNet-101: loss bf16 {l0:.5f} fp8-forward {l1:.5f}; gradient cosine fp8~bf16 {cos:.4f}")
+    assert np.isfinite(l0) and np.isfinite(l1) and abs(l0 - l1) < 3e-2 and cos >= 0.85
+

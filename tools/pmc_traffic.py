@@ -2,7 +2,7 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline
-    python tools/pmc_traffic.py <fetch .db> <write .db> profiles/r2_hbm_traffic.json
+    python tools/pmc_traffic.py <fetch .db> <write .db> profiles/r3_hbm_traffic.json
 
 The output records the date and bench.kernel_source_hash() (sha256 over csrc/, include/clite.h and the Python executors): bench.py reports
 `roofline.traffic` only while that hash matches the tree it runs from, so a kernel change without new PMC passes yields null, not a stale number.

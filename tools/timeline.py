@@ -40,7 +40,7 @@ def main():
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     sid = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)      # (stream ids need --hip-trace; HW queues do not)
     rows = c.execute(f"select name, start, end, {sid or 0} from kernels order by start").fetchall()
-    ends = [r[2] for r in rows if "sgd_step_kernel" in r[0]]
+    ends = [r[2] for r in rows if "sumsq_partial_kernel" in r[0]]
     if len(ends) < 4:
         print("not enough steps in the trace")
         return

@@ -16,7 +16,7 @@ def main():
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     q = "queue_id" if "queue_id" in cols else "0"
     rows = c.execute(f"select name, start, end, {q} from kernels order by start").fetchall()
-    ends = [i for i, r in enumerate(rows) if "sgd_step_kernel" in r[0]]
+    ends = [i for i, r in enumerate(rows) if "sumsq_partial_kernel" in r[0]]
     k = min(range(len(ends) - 1), key=lambda i: rows[ends[i + 1]][2] - rows[ends[i]][2])       # the shortest step = a replayed one
     step = rows[ends[k] + 1:ends[k + 1] + 1]
     print(f"{len(step)} kernels in the step")
