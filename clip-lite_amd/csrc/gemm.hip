@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
       if (ep.preact) store8((T*)ep.preact + o, v);
       if (ep.act == CLITE_ACT_RELU) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
       } else if (ep.act == CLITE_ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);

@@ -272,7 +272,7 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
         if (ep.preact) store8((T*)ep.preact + gidx, v);
         if (ep.act == ACT_RELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
         } else if (ep.act == ACT_GELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);

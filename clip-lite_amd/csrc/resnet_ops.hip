@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
     }
     if (p.relu) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
       if (p.relu_bits) {
         // the ReLU mask for the backward pass: one byte per 8 channels; consecutive threads own consecutive bytes (byte index = row * C/8 + chunk
         // = a workgroup constant + tid). A 64-lane byte store costs the memory pipeline about what the 16-byte data store next to it costs
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* out, ui
         load8(x + (((size_t)n * H + hi) * W + wi) * C + cc * 8, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if (v[e] > best[e] || bi[e] < 0) { best[e] = v[e]; bi[e] = r * 3 + s; }   // first maximum in scan order wins
+          if (v[e] > best[e] || bi[e] < 0 || v[e] != v[e]) { best[e] = v[e]; bi[e] = r * 3 + s; }   // first maximum in scan order wins; a NaN wins (as torch)
       }
     store8(out + (size_t)pix * C + cc * 8, best);
     uint8_t* ip = idx + (size_t)pix * C + cc * 8;
@@ -478,11 +478,11 @@ __global__ __launch_bounds__(256) void stem_bn_pool_fwd_kernel(clite_bn p, const
     for (int t = 0; t < 9; ++t) {
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = fmaxf((tap[t][e] - mean[e]) * k.a[e] + k.b[e], 0.f);
+      for (int e = 0; e < 8; ++e) v[e] = relu_f((tap[t][e] - mean[e]) * k.a[e] + k.b[e]);
       round_store_type<T>(v);                      // a0 as bn_apply would have stored it
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        if (ok[t] && (v[e] > best[e] || bi[e] < 0)) { best[e] = v[e]; bi[e] = t; }   // first maximum in scan order wins
+        if (ok[t] && (v[e] > best[e] || bi[e] < 0 || v[e] != v[e])) { best[e] = v[e]; bi[e] = t; }   // first maximum in scan order wins; a NaN wins (torch max_pool2d propagates it)
     }
     store8(out + (size_t)pix * p.C + c0, best);
     uint32_t lo = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
@@ -534,7 +534,7 @@ DEV void stem_dz(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, c
   float yv[8], a[8];
   load8(y + (((size_t)n * H + hi) * W + wi) * C + c0, yv);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { yc[e] = yv[e] - mean[e]; a[e] = fmaxf(yc[e] * k.a[e] + k.b[e], 0.f); }
+  for (int e = 0; e < 8; ++e) { yc[e] = yv[e] - mean[e]; a[e] = relu_f(yc[e] * k.a[e] + k.b[e]); }
   round_store_type<T>(a);
 #pragma unroll
   for (int e = 0; e < 8; ++e) dz[e] = a[e] > 0.f ? acc[e] : 0.f;

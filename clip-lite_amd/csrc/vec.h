@@ -73,6 +73,10 @@ template <> struct Raw8<float> {
   }
 };
 
+// ReLU that keeps a NaN a NaN, like torch.relu (fmaxf(x, 0) returns 0 for a NaN: a diverged activation would silently become a zero and the
+// loss stay finite — found by planting a NaN in an input image, tests/test_gpu_fp8.py)
+DEV float relu_f(float x) { return x < 0.f ? 0.f : x; }
+
 DEV void zero8(float (&v)[8]) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) v[e] = 0.f;
