@@ -601,6 +601,8 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(LA la, LB lb, Epilogue 
       WideIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
     }
   }
+  // (Measured and rejected, round 3: `s_setprio 1` for waves 4-7 — the static priority for the later-dispatched half that MI355X_MICROARCH.md
+  // suggests for two same-program waves per SIMD — step 16.88 vs 16.90 ms, 3x3 128 -> 128 conv 62.3 -> 63.2 us.)
   int buf = 0;
   for (int t = t_begin; t < t_end; ++t) {
     // tile t has landed once at most min(NSTAGE-2, tiles after t) younger tiles are still outstanding
