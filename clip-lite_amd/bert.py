@@ -234,6 +234,7 @@ def bert_backward(rt, net, ctx, dpooled, defer=None):
     own_group = None
     if defer is None and rt.group_wgrad and not rt.overlap_wgrad and not rt._capturing:      # (a capture cannot allocate the pinned staging)
         defer = own_group = hip.WgradGroup(rt.dt)          # uncaptured backward: grouped launch at the end of this call
+    staged, pooler_done = own_group is not None and getattr(rt, "exchange", None) is not None, False
     A.ensure_transposed(capturing=rt._capturing)
     # pooler: dpre = dpooled * (1 - y^2); h[:, 0] rows only
     dpre = _alloc(rt, B, Hd)
@@ -286,6 +287,13 @@ def bert_backward(rt, net, ctx, dpooled, defer=None):
         dh = dhp
         if own_group is None:
             rt.grads_ready(layer)
+        elif staged:
+            own_group.launch()          # eager data parallel: per-layer groups, so the layer's region can be exchanged now
+            if not pooler_done:
+                rt.grads_ready(net.pooler)          # its weight gradient rode in the first group
+                pooler_done = True
+            rt.grads_ready(layer)
+            defer = own_group = hip.WgradGroup(rt.dt)
     emb = net.embeddings
     ds0 = _alloc(rt, M, Hd)
     hip.layernorm_bwd(dt, dh, ctx["s0"], ctx["st0"], emb.LayerNorm.weight, ds0, None, A.g(emb.LayerNorm.weight), A.g(emb.LayerNorm.bias), M, Hd,
@@ -294,7 +302,10 @@ def bert_backward(rt, net, ctx, dpooled, defer=None):
                   padding_idx=0)      # HF BertEmbeddings: nn.Embedding(vocab, hidden, padding_idx=pad_token_id = 0)
     if own_group is not None:
         own_group.launch()
-        rt.grads_ready(net)
+        if staged:
+            rt.grads_ready(emb)       # the layers and the pooler were handed over as their groups were launched
+        else:
+            rt.grads_ready(net)
     else:
         rt.join_aux()
         rt.grads_ready(emb)

@@ -297,6 +297,11 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
     if defer is None and rt.group_wgrad and not rt.overlap_wgrad and not rt._capturing:      # (a capture cannot allocate the pinned staging)
         # uncaptured (eager / autograd) backward: the same grouped launch, issued at the end of this call on the same stream
         defer = own_group = hip.WgradGroup(rt.dt)
+    staged = own_group is not None and getattr(rt, "exchange", None) is not None
+    stage_first, pos = {}, 0         # index of the first block of each stage -> the stage (its gradients are final once that block is done)
+    for layer in (net.layer1, net.layer2, net.layer3, net.layer4):
+        stage_first[pos] = layer
+        pos += len(layer)
 
     def wgrad(dy_, u_):
         dw = rt.arena.g(u_.conv.weight)
@@ -369,6 +374,12 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 dout = dx
         if defer is None:
             rt.grads_ready(blocks[bi])
+        elif staged and bi in stage_first:
+            # eager data parallel: the grouped weight gradients of a finished STAGE are launched now and its region handed to the
+            # gradient exchange, so that the all-reduce overlaps the remaining backward instead of starting after the whole encoder
+            own_group.launch()
+            rt.grads_ready(stage_first[bi])
+            defer = own_group = hip.WgradGroup(rt.dt)
     if stop_block > 0:
         assert own_group is None
         ctx["bwd_state"] = (dout, pre, stop_block - 1)
@@ -393,7 +404,11 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
             defer.call(stem_wgrad)
     if own_group is not None:
         own_group.launch()
-        rt.grads_ready(net)           # every gradient of the encoder became final with that launch
+        if staged:                    # the four stages were handed over as their groups were launched: only the stem is left
+            rt.grads_ready(net.conv1)
+            rt.grads_ready(net.bn1)
+        else:
+            rt.grads_ready(net)       # every gradient of the encoder became final with that launch
     elif defer is None:
         rt.join_aux()
         rt.grads_ready(net.conv1)

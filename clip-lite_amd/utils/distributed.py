@@ -230,6 +230,8 @@ class GradientExchange:
         self._pending = []
         pos = 0
         for lo, hi in sorted(self._covered):
+            if lo < pos:          # a region summed twice would silently double its gradients
+                raise RuntimeError(f"GradientExchange: gradient region [{lo}, {hi}) was handed over twice in one step (overlaps [.., {pos}))")
             if lo > pos:
                 self._send(pos, lo)
             pos = max(pos, hi)

@@ -1,5 +1,5 @@
 """Worker of tests/test_gpu_train_step.py::test_two_rank_gpu_steps_match_shardwise_oracle — test infrastructure, launched by
-`python -m torch.distributed.run --nproc-per-node 2 tests/dp_worker.py OUT.npz STEPS [graph]`. Every rank builds the same deterministically
+`python -m torch.distributed.run --nproc-per-node 2 tests/dp_worker.py OUT.npz STEPS [graph|eager] [bf16]`. Every rank builds the same deterministically
 filled ResNet-18 + 1-layer BERT + JSD heads in the exact-f32 deterministic-reduction mode, trains STEPS data-parallel steps on ITS OWN
 shard (images, captions and prior noise are functions of (step, rank): detfill.det_tensor) through TrainStep + GradientExchange — the
 product's data-parallel path (reference train.py:174-178) — and rank 0 writes the per-step losses of both ranks, the final parameters and its
@@ -33,6 +33,7 @@ def noise(step, rank):
 def main():
     out_path, steps = sys.argv[1], int(sys.argv[2])
     graph = len(sys.argv) > 3 and sys.argv[3] == "graph"
+    lowp = len(sys.argv) > 4 and sys.argv[4] == "bf16"          # bf16 kernels, fast reductions: the grouped weight gradients' staged hand-over
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     tdist.init_process_group(backend="gloo", init_method="env://")
@@ -45,10 +46,10 @@ def main():
     from clip_lite_amd.train_loop import TrainStep
     from clip_lite_amd.utils import distributed as cdist
     from clip_lite_amd.utils.common import GradScaler
-    hip.set_deterministic(True)
+    hip.set_deterministic(not lowp)
     te = TextEncoder(mode="train_sbert", num_hidden_layers=1)
     te.strans.hidden_dropout_prob = te.strans.attention_probs_dropout_prob = 0.0
-    M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=False)).to("cuda").train()
+    M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=lowp)).to("cuda").train()
     cdist.broadcast_parameters(M)
     groups = [{"params": [p], "lr": CNN_LR if "image_encoder" in n else 1e-3, "weight_decay": 1e-4} for n, p in M.named_parameters()]
     opt = Lookahead(FusedSGD(groups, momentum=0.9), k=5, alpha=0.5)
@@ -58,7 +59,7 @@ def main():
     step_fn = TrainStep(M, opt, sched, GradScaler(False), 10.0, ex, graph=graph, graph_warmup=1)
     losses = []
     # the pinned prior noise lives in two persistent device tensors refilled before every step: a captured step keeps the ADDRESSES it recorded
-    n1, n2 = torch.empty(B, 512, device="cuda"), torch.empty(B, 768, device="cuda")
+    n1, n2 = (torch.empty(B, d, device="cuda", dtype=torch.bfloat16 if lowp else torch.float32) for d in (512, 768))
     M.loss.set_prior_noise(n1, n2)
     for s in range(steps):
         u1, u2 = noise(s, rank)

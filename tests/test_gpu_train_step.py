@@ -563,6 +563,35 @@ def test_two_rank_gpu_steps_match_shardwise_oracle(tmp_path, launch):
 
 
 @pytest.mark.gpu
+def test_two_rank_bf16_eager_steps_hand_every_region_over_once(tmp_path):
+    """The bf16 EAGER data-parallel step: the grouped weight gradients are launched per ResNet stage / BERT layer and each region
+    is handed to the exchange as soon as it is final, so the all-reduce overlaps the rest of backward. Every element of the arena must be
+    summed exactly once per step — GradientExchange.finish() raises on an overlap and fills what was never announced — the two ranks must end
+    bit-identical, and the losses must track the shard-by-shard fp32 oracle at bf16's bar (3e-2; a region summed twice would double its
+    gradients and move the later losses)."""
+    import subprocess
+    import sys
+    import dp_worker as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "dp.npz"
+    steps = 3
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29549",
+           os.path.join(root, "tests", "dp_worker.py"), str(out), str(steps), "eager", "bf16"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    assert bool(got["__identical__"])
+    Mo = det_fill(O.build_oracle_model("resnet18", "train_sbert", 1, dropout=0.0)).train()
+    opt_o = O.build_optimizer(Mo.named_parameters(), cnn_lr=W.CNN_LR, trans_lr=1e-3, lr=1e-3, k=5, alpha=0.5)
+    for s in range(steps):
+        outs, _ = O.train_step_shardwise(Mo, opt_o, [W.shard(s, rk) for rk in range(2)], s, sched=("cosine", 40, 1, 0.0), clip=10.0,
+                                         noises=[W.noise(s, rk) for rk in range(2)])
+        for rk in range(2):
+            assert abs(got["__losses__"][s][rk] - outs[rk]["loss"].item()) < 3e-2, (s, rk, got["__losses__"][s], [o["loss"].item() for o in outs])
+
+
+@pytest.mark.gpu
 def test_prefetching_batch_iterator_hands_over_intact_batches():
     """utils/common.cycle on the GPU: batches staged on the copy stream from pinned host memory arrive bit-identical and in order on the
     compute stream, also when the consumer overwrites / frees them while later batches are still in flight."""
