@@ -196,18 +196,33 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
       // it implements exactly: out = [(alpha*acc) (* relu'(aux))] (+ residual) [(* relu'(aux))], colsum; nothing else
       if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || (ep.dact_aux && ep.relu_bits) || splits != 1) return -1;
       if constexpr (IsDgrad<LA>::value) {
-        // row-range persistent form (igemm_dma_bn_kernel) for the short-K (1 x 1) dgrads whose tile count exceeds the 512 resident slots
-        // (2 workgroups per CU); one tile per workgroup otherwise
+        // the two forms of the bf16 ResNet backward get their own instantiations (igemm_epilogue_bn's FORM); everything else the run-time form
+        constexpr bool kc_b = !LB::XC;
+        int form = 0;
+        if (sizeof(T) == 2 && kc_b && ep.relu_bits && ep.bn_y && !ep.dact_aux && !ep.out_f32 && ep.alpha == 1.f) {
+          if (!ep.residual && !ep.mask_after_residual) form = 1;
+          else if (ep.residual && ep.mask_after_residual) form = 2;
+        }
+        // row-range persistent form (igemm_dma_bn_kernel) for the short-K (1 x 1) dgrads whose tile count exceeds the resident slots — two
+        // workgroups per CU, three for the specialised forms on the 128 x 128 tile (half-tile staging: 48 KB of LDS, 168 registers); one
+        // tile per workgroup otherwise
+        const int slots = (CLITE_BN_HALF && form && CFG::BM == 128) ? CLITE_BN_SLOTS * 3 / 2 : CLITE_BN_SLOTS;
         const int tiles_n = (N + CFG::BN - 1) / CFG::BN, tiles_m = (M + CFG::BM - 1) / CFG::BM;
         int rows_per_wg = CFG::BM, slices = tiles_m;
-        if (la.g.R * la.g.S == 1 && (long)tiles_m * tiles_n > CLITE_BN_SLOTS && tiles_n <= CLITE_BN_SLOTS && !deterministic()) {
-          slices = CLITE_BN_SLOTS / tiles_n;
+        if (la.g.R * la.g.S == 1 && (long)tiles_m * tiles_n > slots && tiles_n <= slots && !deterministic()) {
+          slices = slots / tiles_n;
           rows_per_wg = ((M + slices - 1) / slices + 7) & ~7;
           if (rows_per_wg < CFG::BM) rows_per_wg = CFG::BM;
           slices = (M + rows_per_wg - 1) / rows_per_wg;
         }
-        hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB>), dim3(slices * tiles_n), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
-                           M, N, ktiles, rows_per_wg);
+        const dim3 g(slices * tiles_n);
+        if constexpr (sizeof(T) == 2 && kc_b) {
+          if (form == 1) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 1>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+          else if (form == 2) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 2>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+          else hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+        } else {
+          hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+        }
         return (int)hipGetLastError();
       } else {
         return -1;

@@ -26,6 +26,16 @@
 #ifndef EPI_STAMP
 #define EPI_STAMP(i) do {} while (0)
 #endif
+// tuning constants of the BatchNorm-backward epilogue (igemm_epilogue_bn); `make variant VAR_EXTRA=-D...` builds A/B them on one box
+#ifndef CLITE_BN_AHEAD
+#define CLITE_BN_AHEAD 4           // rows of epilogue operands in flight ahead of the row being written (run-time form)
+#endif
+#ifndef CLITE_BN_AHEAD_FORM
+#define CLITE_BN_AHEAD_FORM 4      // ... in the specialised forms (fewer registers per row: no tensor-form mask)
+#endif
+#ifndef CLITE_BN_HALF
+#define CLITE_BN_HALF 0            // 1: half-tile staging + three workgroups per CU (measured: no gain)
+#endif
 
 namespace clite {
 
@@ -594,8 +604,57 @@ DEV void igemm_epilogue_plain(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& e
 // workgroups per CU anyway (registers), so the whole BM x BN accumulator tile is staged in LDS at once (one barrier instead of two per
 // wave row) and every thread then walks its BM/RPSE rows with the three extra operands (mask source, BatchNorm input, residual) of the
 // next rows already in flight: their latency is paid once per tile, not once per row.
-template <typename T, class CFG>
-DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
+// What one workgroup of igemm_dma_bn_kernel keeps across ALL the tiles it walks (they share one column tile): the BatchNorm means of the
+// thread's 8 columns — 8 x replicas dependent L2 loads, a latency chain that used to open every tile's epilogue — and the running column
+// sums, folded through LDS and added with float atomics ONCE per workgroup instead of once per tile. (An ablation build without any global
+// memory traffic still took 42 of the 85 us of the 1024 <- 256 dgrad at 14 x 14: the per-tile fixed costs, not the bytes, were half the launch.)
+struct BnEpiState {
+  float bn_mean[8], csum[8], csq[8];
+};
+template <class CFG>
+DEV void bn_epi_begin(BnEpiState& st, const Epilogue& ep, int N, int n0, int tid) {
+  constexpr int CPRE = CFG::BN / 8;
+  const int gcol = n0 + (tid % CPRE) * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { st.bn_mean[e] = 0.f; st.csum[e] = 0.f; st.csq[e] = 0.f; }
+  if (gcol < N && ep.bn_y) {
+    for (int r = 0; r < ep.bn_replicas; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) st.bn_mean[e] += ep.bn_stats[(size_t)r * ep.bn_rstride + gcol + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st.bn_mean[e] *= ep.bn_inv_count;
+  }
+}
+// fold the workgroup's column sums through LDS (free at this point) and add them: one atomic per column and statistic
+template <class CFG>
+DEV void bn_epi_finish(const BnEpiState& st, const Epilogue& ep, char* smem, int N, int n0, int tid) {
+  constexpr int CPRE = CFG::BN / 8, RPSE = 256 / CPRE;
+  if (!ep.colsum) return;
+  const int erow0 = tid / CPRE;
+  float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
+  float* red = (float*)smem;                      // [RPSE][CPRE*16]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + e] = st.csum[e];
+    red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + 8 + e] = st.csq[e];
+  }
+  lds_barrier();
+  for (int idx = tid; idx < CPRE * 16; idx += 256) {
+    float sacc = 0.f;
+    for (int r = 0; r < RPSE; ++r) sacc += red[r * (CPRE * 16) + idx];
+    int chunk = idx / 16, e = idx % 16;
+    int col = n0 + chunk * 8 + (e & 7);
+    if (col < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
+  }
+}
+
+// FORM: what the launch needs, fixed at compile time. 0 = every combination clite_epilogue allows in this form, decided by run-time flags and
+// selects (tests, f32, the tensor form of the mask). 1 / 2 = the two forms the bf16 ResNet backward launches — packed relu' bits, BatchNorm input,
+// bf16 output, alpha = 1; 2 adds the residual with the mask applied after it (the block-input gradient). The ISA of the run-time form had ~400
+// instructions per row of 8 elements (flag selects, both store paths, 64-bit index arithmetic) and an ablation build without ANY global memory
+// traffic still took half the launch: the epilogue was instruction-bound, not byte-bound. The specialised forms issue ~1/3 of that.
+template <typename T, class CFG, int FORM = 0>
+DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
                            int tid, int lane, int wave, int wm0, int wn0) {
   constexpr int BM = CFG::BM, BN = CFG::BN;
   constexpr int RM = CFG::RM, RN = CFG::RN;
@@ -603,35 +662,60 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
   const int ecol = (tid % CPRE) * 8, erow0 = tid / CPRE;
   const int gcol = n0 + ecol;
   const bool colok = gcol < N;
+  // The accumulator tile goes through LDS in NP passes of BM / NP rows (NP = 1: the whole tile at once, 68 KB = two workgroups per CU; NP = 2 in
+  // the specialised forms: 34 KB, under the 48 KB operand ring, so THREE workgroups fit a CU). The ablations of round 3 showed the launch's
+  // parts — compute, operand DMA, epilogue loads, epilogue stores — adding up instead of overlapping: with two waves per SIMD both are
+  // usually parked on memory at the same time; a third resident workgroup is what hides that.
+  // Pass p takes the p-th 32-row MFMA block of EVERY wave (not the first half of the waves), so that each wave's accumulators die by halves
+  // and no wave carries all 64 of them through the VALU-heavy row loop of the other pass: tile row R belongs to pass (R / 32) % RM and sits at
+  // image row (R / 32 / RM) * 32 + R % 32.
+  constexpr int NP = (FORM && CLITE_BN_HALF) ? RM : 1, QPP = ROWS_PT / NP;
+  static_assert(NP == 1 || (RM == 2 && ROWS_PT % NP == 0 && 32 % RPSE == 0), "pass structure");
+  auto stage = [&](int p) {
 #pragma unroll
-  for (int i = 0; i < RM; ++i)
+    for (int i = 0; i < RM; ++i) {
+      if (NP > 1 && i != p) continue;
 #pragma unroll
-    for (int j = 0; j < RN; ++j)
+      for (int j = 0; j < RN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        int col = wn0 + j * 32 + (lane & 31);
-        *(float*)(smem + row * CFG::EPI_PITCH + col * 4) = acc[i][j][r];
-      }
-  float bn_mean[8], csum[8], csq[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { bn_mean[e] = 0.f; csum[e] = 0.f; csq[e] = 0.f; }
-  if (colok && ep.bn_y) {
-    for (int r = 0; r < ep.bn_replicas; ++r)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bn_mean[e] += ep.bn_stats[(size_t)r * ep.bn_rstride + gcol + e];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bn_mean[e] *= ep.bn_inv_count;
-  }
+        for (int r = 0; r < 16; ++r) {
+          int row = (NP > 1 ? (wm0 / CFG::WM) * 32 : wm0 + i * 32) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          int col = wn0 + j * 32 + (lane & 31);
+          *(float*)(smem + row * CFG::EPI_PITCH + col * 4) = acc[i][j][r];
+        }
+    }
+  };
+  // processing order of the thread's ROWS_PT rows: pass 0's rows first. Row index q (tile row erow0 + q * RPSE) -> pass ((q * RPSE) / 32) % NP
+  auto row_of = [](int k) {          // k-th row in processing order
+    if (NP == 1) return k;
+    int p = k / QPP, n = k % QPP, seen = 0;
+    for (int q = 0; q < ROWS_PT; ++q)
+      if (((q * RPSE) / 32) % NP == p) { if (seen == n) return q; ++seen; }
+    return 0;
+  };
+  stage(0);
+  float (&bn_mean)[8] = st.bn_mean;
+  float (&csum)[8] = st.csum;
+  float (&csq)[8] = st.csq;
   // Rows whose operands are in flight ahead of the row being written. Measured alternatives (round 2, MI355X, in-step per-launch times):
   //  * all ROWS_PT rows ahead (the registers are there: the whole-tile staging holds the kernel at two workgroups per CU anyway):
   //    no faster — 1024 -> 256 1x1 dgrad 80.7 vs 82.5 us, 256 -> 64 191 vs 217;
   //  * staging one wave row at a time (34 KB, under the operand ring) + __launch_bounds__(256, 3) for three workgroups per CU: the
   //    allocator then spills 20 registers and the launches get slower — 256 -> 64 191 -> 267 us, 64 -> 256 97 -> 116, step 18.7 -> 19.2 ms.
-#ifndef CLITE_BN_AHEAD
-#define CLITE_BN_AHEAD 4
-#endif
-  constexpr int AHEAD = CLITE_BN_AHEAD;
+
+  constexpr int AHEAD = (FORM && CLITE_BN_HALF) ? 2 : (FORM ? CLITE_BN_AHEAD_FORM : CLITE_BN_AHEAD);
+  // Every operand load of the row loop is BRANCH-FREE: a buffer load whose offset is OOB_OFF (-> zeros, no memory traffic) when the operand
+  // is absent or the row / column is out of range. With the loads inside `if (ep.bn_y) ...` / `if (okr) ...` branches the compiler's
+  // waitcnt insertion put an `s_waitcnt vmcnt(0)` behind the first load of every request (found in the ISA, round 3): the rows "in
+  // flight ahead" were in fact fetched one at a time, and the epilogue phase alone ran at 2.2 TB/s (ablation without the operand DMA:
+  // 71 of the 85 us of the 1024 <- 256 dgrad at 14 x 14).
+  const bool has_bits = FORM ? true : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? true : ep.bn_y != nullptr,
+             has_res = FORM ? FORM == 2 : ep.residual != nullptr;
+  const bool mask_after = FORM ? FORM == 2 : ep.mask_after_residual != 0;
+  const rsrc_t r_bits = make_rsrc(ep.relu_bits, RSRC_WHOLE), r_aux = make_rsrc(ep.dact_aux, RSRC_WHOLE), r_y = make_rsrc(ep.bn_y, RSRC_WHOLE),
+               r_res = make_rsrc(ep.residual, RSRC_WHOLE);
+  const bool to_f32 = FORM ? false : (ep.out_f32 || sizeof(T) == 4);
+  const rsrc_t r_out = make_rsrc(ep.out, RSRC_WHOLE);
   Raw8<T> pa[ROWS_PT], py[ROWS_PT], pr[ROWS_PT];
   uint32_t pb[ROWS_PT];          // packed relu' bits of the row's 8 columns (clite_epilogue.relu_bits): one byte instead of a 16-byte chunk of dact_aux
   uint32_t gix[ROWS_PT];
@@ -640,86 +724,75 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, 
     int grow = m0 + erow0 + q * RPSE;
     okr[q] = colok && grow < M;
     gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
-    pb[q] = 0xFFu;
-    if (okr[q]) {
-      if (ep.relu_bits) pb[q] = ep.relu_bits[gix[q] >> 3];
-      else if (ep.dact_aux) pa[q].ld((const T*)ep.dact_aux + gix[q]);
-      if (ep.bn_y) py[q].ld((const T*)ep.bn_y + gix[q]);
-      if (ep.residual) pr[q].ld((const T*)ep.residual + gix[q]);
-    }
+#ifndef CLITE_EPI_ABLATE
+#define CLITE_EPI_ABLATE 0       // diagnostic builds only: 1 = epilogue without its operand loads, 2 = without its stores
+#endif
+    const uint32_t eoff = (CLITE_EPI_ABLATE & 1) ? OOB_OFF : gix[q] * (uint32_t)sizeof(T);
+    pb[q] = buf_load1(r_bits, (okr[q] && has_bits && !(CLITE_EPI_ABLATE & 1)) ? (gix[q] >> 3) : OOB_OFF);
+    if constexpr (FORM == 0) pa[q].ldb(r_aux, (okr[q] && has_aux && !has_bits) ? eoff : OOB_OFF);
+    py[q].ldb(r_y, (okr[q] && has_y) ? eoff : OOB_OFF);
+    if constexpr (FORM != 1) pr[q].ldb(r_res, (okr[q] && has_res) ? eoff : OOB_OFF);
   };
 #pragma unroll
-  for (int q = 0; q < AHEAD && q < ROWS_PT; ++q) request(q);
+  for (int k = 0; k < AHEAD && k < ROWS_PT; ++k) request(row_of(k));
   lds_barrier();
   EPI_STAMP(6);
 #pragma unroll
-  for (int q = 0; q < ROWS_PT; ++q) {
-    if (q + AHEAD < ROWS_PT) request(q + AHEAD);
-    if (!okr[q]) continue;
-    const float* src = (const float*)(smem + (erow0 + q * RPSE) * CFG::EPI_PITCH + ecol * 4);
+  for (int k = 0; k < ROWS_PT; ++k) {
+    const int q = row_of(k);
+    if (NP > 1 && k > 0 && k % QPP == 0) {          // next pass: every thread is past its reads of the previous image, then every wave stages
+      lds_barrier();
+      stage(k / QPP);
+      lds_barrier();
+    }
+    if (k + AHEAD < ROWS_PT) request(row_of(k + AHEAD));
+    const int irow = NP == 1 ? erow0 + q * RPSE : ((erow0 + q * RPSE) / 32 / RM) * 32 + (erow0 + q * RPSE) % 32;
+    const float* src = (const float*)(smem + irow * CFG::EPI_PITCH + ecol * 4);
     f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-    float msk[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { v[e] *= ep.alpha; msk[e] = 1.f; }
-    if (ep.relu_bits) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) msk[e] = (pb[q] >> e) & 1u ? 1.f : 0.f;
-    } else if (ep.dact_aux) {
-      float av[8];
+    float msk[8], av[8], rv[8], yv[8];
+    py[q].get(yv);
+    if constexpr (FORM == 0) {
       pa[q].get(av);
+      pr[q].get(rv);          // zeros when there is no residual (or the row is out of range)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) msk[e] = av[e] > 0.f ? 1.f : 0.f;       // ReLU' only (check_ep enforces dact == 1 here)
-    }
-    if (!ep.mask_after_residual) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= msk[e];
-    }
-    if (ep.residual) {
-      float rv[8];
-      pr[q].get(rv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += rv[e];
-    }
-    if (ep.mask_after_residual) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= msk[e];
-    }
-    if (ep.out_f32 || sizeof(T) == 4) {
-      store8((float*)ep.out + gix[q], v);
+      for (int e = 0; e < 8; ++e) {
+        // relu' mask: packed bits, or the sign of the tensor operand, or none (ReLU' only here: check_ep enforces dact == 1)
+        msk[e] = has_bits ? ((pb[q] >> e) & 1u ? 1.f : 0.f) : (has_aux ? (av[e] > 0.f ? 1.f : 0.f) : 1.f);
+        const float a = v[e] * ep.alpha;
+        v[e] = mask_after ? (a + rv[e]) * msk[e] : a * msk[e] + rv[e];
+        if (!okr[q]) v[e] = 0.f;          // (out-of-range rows / columns: nothing stored, nothing added to the statistics)
+      }
     } else {
-      store8((bf16*)ep.out + gix[q], v);
+      // out-of-range rows / columns need no select: their accumulators are zero (operand rows / columns past the range gather as zeros) and
+      // every operand load returned zeros, so v = 0 and nothing is added to the statistics; the store offset is OOB_OFF
+      if constexpr (FORM == 2) {
+        pr[q].get(rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (pb[q] >> e) & 1u ? v[e] + rv[e] : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (pb[q] >> e) & 1u ? v[e] : 0.f;
+      }
+    }
+    if (to_f32) {
+      union { f32x4 f; u32x4 u; } lo, hi;
+      lo.f = f32x4{v[0], v[1], v[2], v[3]}; hi.f = f32x4{v[4], v[5], v[6], v[7]};
+      const uint32_t o = (okr[q] && !(CLITE_EPI_ABLATE & 2)) ? gix[q] * 4u : OOB_OFF;
+      buf_store16(r_out, o, lo.u);
+      buf_store16(r_out, o == OOB_OFF ? OOB_OFF : o + 16, hi.u);
+    } else {
+      Chunk16 ch;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ch.e[e] = f2bf(v[e]);
+      buf_store16(r_out, (okr[q] && !(CLITE_EPI_ABLATE & 2)) ? gix[q] * 2u : OOB_OFF, ch.u);
       round8_bf16(v);   // statistics of what was stored
     }
-    if (ep.bn_y) {
-      float yv[8];
-      py[q].get(yv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * (yv[e] - bn_mean[e]); }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
-    }
+    for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += has_y ? v[e] * (yv[e] - bn_mean[e]) : v[e] * v[e]; }
   }
   lds_barrier();
   EPI_STAMP(7);
-  if (ep.colsum) {
-    float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
-    float* red = (float*)smem;                      // [RPSE][CPRE*16]
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + e] = csum[e];
-      red[erow0 * (CPRE * 16) + (tid % CPRE) * 16 + 8 + e] = csq[e];
-    }
-    lds_barrier();
-    for (int idx = tid; idx < CPRE * 16; idx += 256) {
-      float sacc = 0.f;
-      for (int r = 0; r < RPSE; ++r) sacc += red[r * (CPRE * 16) + idx];
-      int chunk = idx / 16, e = idx % 16;
-      int col = n0 + chunk * 8 + (e & 7);
-      if (col < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, sacc);
-    }
-  }
 }
 
 #if defined(CLITE_DIAG) && CLITE_DIAG

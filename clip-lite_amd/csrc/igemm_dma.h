@@ -411,8 +411,12 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
   }
   barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
   STAMP(4);
-  if constexpr (EPI == 1) igemm_epilogue_bn<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
-  else if constexpr (EPI == 2 && sizeof(T) == 2) igemm_epilogue_plain<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  if constexpr (EPI == 1) {          // (the BatchNorm-backward form is launched as igemm_dma_bn_kernel; kept for diagnostic builds)
+    BnEpiState est;
+    bn_epi_begin<CFG>(est, ep, N, n0, tid);
+    igemm_epilogue_bn<T, CFG>(acc, est, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+    bn_epi_finish<CFG>(est, ep, smem, N, n0, tid);
+  } else if constexpr (EPI == 2 && sizeof(T) == 2) igemm_epilogue_plain<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
   else igemm_epilogue<T, CFG, false>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
   STAMP(5);
 }
@@ -426,14 +430,19 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
 // range read as zero / are not stored), which costs a short main loop and an epilogue proportional to its rows. With rows_per_wg =
 // ceil(M / (512 / column tiles)) all workgroups are resident at once and finish together. rows_per_wg = BM is the plain one-tile form
 // (windowed convs, whose main loop is long: a partial tile would cost a whole one).
-template <typename T, class CFG, class LA, class LB>
-__global__ __launch_bounds__(256) void igemm_dma_bn_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int rows_per_wg) {
+template <typename T, class CFG, class LA, class LB, int FORM = 0>
+__global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dma_bn_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int rows_per_wg) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
-  constexpr int NSTAGE = 3;
+#ifndef CLITE_BN_STAGES
+#define CLITE_BN_STAGES 3
+#endif
+  constexpr int NSTAGE = CLITE_BN_STAGES;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
-  constexpr int EPIB = CFG::BM * CFG::EPI_PITCH;             // the BatchNorm-backward epilogue stages the whole tile
-  constexpr int SMEM = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
+  constexpr int EPIB = (CFG::BM / ((FORM && CLITE_BN_HALF) ? 2 : 1)) * CFG::EPI_PITCH;      // the epilogue stages the whole tile, or half of it at a time (igemm_epilogue_bn NP)
+  constexpr int RED = (256 / (CFG::BN / 8)) * (CFG::BN / 8) * 16 * 4;      // bn_epi_finish's fold image
+  constexpr int SMEM0 = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
+  constexpr int SMEM = SMEM0 > RED ? SMEM0 : RED;
   constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
   static_assert(sizeof(T) == 2 || sizeof(T) == 4, "bf16 or f32");
   // (Measured and rejected, round 3: touching every 128-byte line of the tile's BatchNorm-input / residual rows by LDS-DMA into a scratch at
@@ -468,6 +477,8 @@ __global__ __launch_bounds__(256) void igemm_dma_bn_kernel(LA la, LB lb, Epilogu
     }
   }
 
+  BnEpiState est;
+  bn_epi_begin<CFG>(est, ep, N, n0, tid);
   for (int m0 = row_begin; m0 < row_end; m0 += BM) {
     typename LA::State sa;
     typename LB::State sb;
@@ -482,14 +493,19 @@ __global__ __launch_bounds__(256) void igemm_dma_bn_kernel(LA la, LB lb, Epilogu
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
     for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+#if CLITE_ABLATE != 2
       if (pz < ktiles) {
         DmaIssue<LA>::go(la, sa, smem + pz * STAGE, wave, lane, m0);
         DmaIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
       }
+#endif
     }
     int buf = 0;
     for (int t = 0; t < ktiles; ++t) {
-      if (ktiles - 1 - t >= 1) wait_vmcnt<LOADS_PER_TILE>();
+      const int after = ktiles - 1 - t;      // tile t has landed once at most min(NSTAGE - 2, tiles after t) younger tiles are outstanding
+      if (NSTAGE >= 5 && after >= 3) wait_vmcnt<3 * LOADS_PER_TILE>();
+      else if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LOADS_PER_TILE>();
+      else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
       else wait_vmcnt<0>();
       barrier_raw();
       const char* abuf = smem + buf * STAGE;
@@ -500,13 +516,15 @@ __global__ __launch_bounds__(256) void igemm_dma_bn_kernel(LA la, LB lb, Epilogu
         for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
 #pragma unroll
         for (int j = 0; j < RN; ++j) bf0[j] = LB::frag_at(bbuf + boff[j][0]);
+#if CLITE_ABLATE != 2
         if (t + NSTAGE - 1 < ktiles) {
           int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
           DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
           DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
         }
+#endif
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        for (int ks = 0; ks < (CLITE_ABLATE == 1 ? 0 : BK / 16); ++ks) {
           bf16x8 af[RM], bfr[RN];
 #pragma unroll
           for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
@@ -539,9 +557,10 @@ __global__ __launch_bounds__(256) void igemm_dma_bn_kernel(LA la, LB lb, Epilogu
       if (++buf == NSTAGE) buf = 0;
     }
     barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
-    igemm_epilogue_bn<T, CFG>(acc, ep, rm, smem, row_end, N, m0, n0, tid, lane, wave, wm0, wn0);
-    lds_barrier();          // ... and past its last read of the epilogue's LDS image before the next tile's operands land in it
+    igemm_epilogue_bn<T, CFG, FORM>(acc, est, ep, rm, smem, row_end, N, m0, n0, tid, lane, wave, wm0, wn0);
+    // (igemm_epilogue_bn ends with a barrier: every wave is past its last read of the epilogue's LDS image before the next tile's operands land)
   }
+  bn_epi_finish<CFG>(est, ep, smem, N, n0, tid);
 }
 
 

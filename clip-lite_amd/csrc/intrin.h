@@ -38,6 +38,7 @@ DEV rsrc_t make_rsrc(const void* ptr, uint32_t bytes) {
 DEV u32x4 buf_load16(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0); }
 DEV u32x2 buf_load8(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0); }
 DEV uint32_t buf_load4(rsrc_t r, uint32_t off) { return __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+DEV uint32_t buf_load1(rsrc_t r, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(r, off, 0, 0); }   // one byte, zero-extended
 DEV void buf_store16(rsrc_t r, uint32_t off, u32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0); }
 DEV void buf_store8(rsrc_t r, uint32_t off, u32x2 v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0); }
 DEV void buf_store4(rsrc_t r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 0); }

@@ -55,9 +55,14 @@ DEV void round8_bf16(float (&v)[8]) {
 
 // 8 consecutive elements held raw (as loaded) until they are needed: lets a kernel issue several loads before converting any
 template <typename T> struct Raw8;
+// size of a buffer resource over an operand whose extent the epilogue does not know (every tensor of the step is < 0xF0000000 bytes: gemm.hip
+// fits32); an absent operand is addressed with OOB_OFF, which reads zeros from any resource
+constexpr uint32_t RSRC_WHOLE = 0xF0000000u;
+
 template <> struct Raw8<bf16> {
   u32x4 a;
   DEV void ld(const bf16* p) { a = *(const u32x4*)p; }
+  DEV void ldb(rsrc_t r, uint32_t byte_off) { a = buf_load16(r, byte_off); }          // branch-free form: out-of-range offset -> zeros
   DEV void get(float (&v)[8]) const {
     Chunk16 c;
     c.u = a;
@@ -68,6 +73,12 @@ template <> struct Raw8<bf16> {
 template <> struct Raw8<float> {
   f32x4 a, b;
   DEV void ld(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+  DEV void ldb(rsrc_t r, uint32_t byte_off) {
+    union { u32x4 u; f32x4 f; } x, y;
+    x.u = buf_load16(r, byte_off);
+    y.u = buf_load16(r, byte_off == OOB_OFF ? OOB_OFF : byte_off + 16);
+    a = x.f; b = y.f;
+  }
   DEV void get(float (&v)[8]) const {
     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
   }

@@ -34,6 +34,10 @@ def _prep(x, dtype):
     return x, x
 
 
+def outbuf_like(dtype, shape):
+    return np.zeros(shape, np.uint16 if dtype == BF16 else np.float32)
+
+
 def _close(got, ref, rel=2e-3):
     assert np.abs(got - ref).max() <= rel * max(np.abs(ref).max(), 1e-6)
 
@@ -417,6 +421,20 @@ def test_conv_dgrad_on_transposed_weights(dtype, N, H, W, Cc, K, R, S, st, pad):
         v = (g + res) * (aux > 0)
         _close(out3, v)
         _close(dst.sum(0)[1], (v * (y - fstats[:, 0].sum(0) / M)).sum(0), 5e-3)
+        # the output in the compute dtype: in bf16 these are the two compile-time specialised forms of the epilogue that the ResNet backward
+        # launches (igemm_epilogue_bn FORM 2: residual + mask after it; FORM 1: mask only) — same values, rounded once
+        for with_res in (True, False):
+            out4 = outbuf_like(dtype, (M, Cc))
+            dst4 = np.zeros((4, 3, Cc), np.float32)
+            ep = make_ep(out4, Cc, out_f32=False, residual=resb if with_res else None, colsum=dst4, relu_bits=bits)
+            ep.colsum_replicas, ep.colsum_stride = 4, 3 * Cc
+            ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count, ep.mask_after_residual = ptr(yb), ptr(fstats), 4, 3 * Cc, 1.0 / M, int(with_res)
+            assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == 0
+            got = from_bf16(out4) if dtype == BF16 else out4
+            want = (g + res) * (aux > 0) if with_res else g * (aux > 0)
+            _close(got, want, 8e-3 if dtype == BF16 else 2e-3)
+            _close(dst4.sum(0)[0], got.sum(0), 1e-3)
+            _close(dst4.sum(0)[1], (got * (y - fstats[:, 0].sum(0) / M)).sum(0), 5e-3)
 
 
 @pytest.mark.parametrize("dtype", [BF16, F32])

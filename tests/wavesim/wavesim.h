@@ -159,6 +159,7 @@ inline void wavesim_buf_store(rsrc_t r, uint32_t off, T v) {
 inline u32x4 buf_load16(rsrc_t r, uint32_t off) { assert(off % 4 == 0); return wavesim_buf_load<u32x4>(r, off); }
 inline u32x2 buf_load8(rsrc_t r, uint32_t off) { assert(off % 4 == 0); return wavesim_buf_load<u32x2>(r, off); }
 inline uint32_t buf_load4(rsrc_t r, uint32_t off) { assert(off % 4 == 0); return wavesim_buf_load<uint32_t>(r, off); }
+inline uint32_t buf_load1(rsrc_t r, uint32_t off) { return (uint32_t)wavesim_buf_load<uint8_t>(r, off); }
 inline void buf_store16(rsrc_t r, uint32_t off, u32x4 v) { assert(off % 4 == 0); wavesim_buf_store(r, off, v); }
 inline void buf_store8(rsrc_t r, uint32_t off, u32x2 v) { assert(off % 4 == 0); wavesim_buf_store(r, off, v); }
 inline void buf_store4(rsrc_t r, uint32_t off, uint32_t v) { assert(off % 4 == 0); wavesim_buf_store(r, off, v); }

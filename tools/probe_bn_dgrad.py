@@ -1,0 +1,33 @@
+"""Time the BatchNorm-backward conv dgrad (the ResNet backward's fused form) at one shape, cold caches: python tools/probe_bn_dgrad.py N H W C K R stride pad [resid]
+Used with `make variant VAR_EXTRA=-DCLITE_ABLATE=1|2` builds to split a launch into its memory side, its compute side and its epilogue."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from clip_lite_amd import hip
+
+N, H, W, Cc, K, R, st, pad = [int(x) for x in sys.argv[1:9]]
+resid = len(sys.argv) > 9
+cv = hip.conv_desc(hip.BF16, N, H, W, Cc, K, R, R, st, pad)
+M = N * H * W
+wt = torch.randn(Cc, R, R, K, device="cuda").bfloat16()
+dy = torch.randn(N, cv.Ho, cv.Wo, K, device="cuda").bfloat16()
+y = torch.randn(M, Cc, device="cuda").bfloat16()
+res = torch.randn(M, Cc, device="cuda").bfloat16()
+bits = torch.randint(0, 255, (M, Cc // 8), device="cuda", dtype=torch.uint8)
+dz = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
+fst = hip.Stats(torch.zeros(8, 3, Cc, device="cuda"), 8, Cc)
+dst = hip.Stats(torch.zeros(8, 3, Cc, device="cuda"), 8, Cc)
+fn = lambda: hip.conv_dgrad(dy, wt, cv, hip.epilogue(dz, Cc, residual=res if resid else None, relu_bits=bits, mask_after_residual=resid, colsum=dst, bn=(y, fst, M)), wt=True)
+junk = torch.empty(300 * 1024 * 1024, device="cuda", dtype=torch.uint8)
+ts = []
+for i in range(8):
+    junk.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e3)
+ts = sorted(ts[2:])
+print(f"bn dgrad {Cc}<-{K} {R}x{R} @{H} resid={int(resid)}: median {ts[len(ts) // 2]:.1f} us (min {ts[0]:.1f})")
