@@ -26,12 +26,18 @@
 #ifndef EPI_STAMP
 #define EPI_STAMP(i) do {} while (0)
 #endif
+#ifndef BN_EPI_PHASE
+#define BN_EPI_PHASE(i) do {} while (0)
+#endif
 // tuning constants of the BatchNorm-backward epilogue (igemm_epilogue_bn); `make variant VAR_EXTRA=-D...` builds A/B them on one box
 #ifndef CLITE_BN_AHEAD
 #define CLITE_BN_AHEAD 4           // rows of epilogue operands in flight ahead of the row being written (run-time form)
 #endif
 #ifndef CLITE_BN_AHEAD_FORM
 #define CLITE_BN_AHEAD_FORM 4      // ... in the specialised forms (fewer registers per row: no tensor-form mask)
+#endif
+#ifndef CLITE_BN_EARLY
+#define CLITE_BN_EARLY 4           // rows of epilogue operands igemm_dma_bn_kernel requests BEFORE a tile's main loop (specialised forms; 0: none)
 #endif
 #ifndef CLITE_BN_HALF
 #define CLITE_BN_HALF 0            // 1: half-tile staging + three workgroups per CU (measured: no gain)
@@ -648,14 +654,51 @@ DEV void bn_epi_finish(const BnEpiState& st, const Epilogue& ep, char* smem, int
   }
 }
 
+// The epilogue operands of one thread's BM / RPSE rows (relu' bits, BatchNorm input, residual, tensor-form mask), in registers. A struct of
+// its own so that igemm_dma_bn_kernel can request the first rows of a tile BEFORE the tile's main loop: the requests need only addresses,
+// not accumulators, and `vmcnt` retires in issue order — the wait on the first operand tile covers them, so their HBM round trip runs
+// beside the ring fill instead of opening the epilogue (one of a short tile's three serial round trips: ring fill, rows 0..AHEAD-1, the rest).
+template <typename T, class CFG, int FORM>
+struct BnRows {
+  static constexpr int CPRE = CFG::BN / 8, RPSE = 256 / CPRE, ROWS_PT = CFG::BM / RPSE;
+  Raw8<T> pa[ROWS_PT], py[ROWS_PT], pr[ROWS_PT];
+  uint32_t pb[ROWS_PT];          // packed relu' bits of the row's 8 columns (clite_epilogue.relu_bits): one byte instead of a 16-byte chunk of dact_aux
+  uint32_t gix[ROWS_PT];
+  bool okr[ROWS_PT];
+  // Every operand load is BRANCH-FREE: a buffer load whose offset is OOB_OFF (-> zeros, no memory traffic) when the operand is absent or
+  // the row / column is out of range. With the loads inside `if (ep.bn_y) ...` / `if (okr) ...` branches the compiler's waitcnt insertion
+  // put an `s_waitcnt vmcnt(0)` behind the first load of every request (found in the ISA, round 3): the rows "in flight ahead" were in fact
+  // fetched one at a time, and the epilogue phase alone ran at 2.2 TB/s (ablation without the operand DMA: 71 of the 85 us of the
+  // 1024 <- 256 dgrad at 14 x 14).
+  DEV void request(int q, const Epilogue& ep, const RowMap& rm, int M, int N, int m0, int n0, int tid) {
+    const int gcol = n0 + (tid % CPRE) * 8;
+    const bool has_bits = FORM ? true : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? true : ep.bn_y != nullptr,
+               has_res = FORM ? FORM == 2 : ep.residual != nullptr;
+    const rsrc_t r_bits = make_rsrc(ep.relu_bits, RSRC_WHOLE), r_aux = make_rsrc(ep.dact_aux, RSRC_WHOLE), r_y = make_rsrc(ep.bn_y, RSRC_WHOLE),
+                 r_res = make_rsrc(ep.residual, RSRC_WHOLE);
+    const int grow = m0 + tid / CPRE + q * RPSE;
+    okr[q] = gcol < N && grow < M;
+    gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
+#ifndef CLITE_EPI_ABLATE
+#define CLITE_EPI_ABLATE 0       // diagnostic builds only: 1 = epilogue without its operand loads, 2 = without its stores
+#endif
+    const uint32_t eoff = (CLITE_EPI_ABLATE & 1) ? OOB_OFF : gix[q] * (uint32_t)sizeof(T);
+    pb[q] = buf_load1(r_bits, (okr[q] && has_bits && !(CLITE_EPI_ABLATE & 1)) ? (gix[q] >> 3) : OOB_OFF);
+    if constexpr (FORM == 0) pa[q].ldb(r_aux, (okr[q] && has_aux && !has_bits) ? eoff : OOB_OFF);
+    py[q].ldb(r_y, (okr[q] && has_y) ? eoff : OOB_OFF);
+    if constexpr (FORM != 1) pr[q].ldb(r_res, (okr[q] && has_res) ? eoff : OOB_OFF);
+  }
+};
+
 // FORM: what the launch needs, fixed at compile time. 0 = every combination clite_epilogue allows in this form, decided by run-time flags and
 // selects (tests, f32, the tensor form of the mask). 1 / 2 = the two forms the bf16 ResNet backward launches — packed relu' bits, BatchNorm input,
 // bf16 output, alpha = 1; 2 adds the residual with the mask applied after it (the block-input gradient). The ISA of the run-time form had ~400
 // instructions per row of 8 elements (flag selects, both store paths, 64-bit index arithmetic) and an ablation build without ANY global memory
 // traffic still took half the launch: the epilogue was instruction-bound, not byte-bound. The specialised forms issue ~1/3 of that.
-template <typename T, class CFG, int FORM = 0>
-DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
-                           int tid, int lane, int wave, int wm0, int wn0) {
+// NREQ: the thread's first NREQ rows (processing order) were requested by the caller (BnRows::request, before the main loop).
+template <typename T, class CFG, int FORM = 0, int NREQ = 0>
+DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, BnRows<T, CFG, FORM>& rows, const Epilogue& ep, const RowMap& rm, char* smem, int M, int N,
+                           int m0, int n0, int tid, int lane, int wave, int wm0, int wn0) {
   constexpr int BM = CFG::BM, BN = CFG::BN;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int CPRE = BN / 8, RPSE = 256 / CPRE, ROWS_PT = BM / RPSE;
@@ -704,39 +747,20 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, cons
   //    allocator then spills 20 registers and the launches get slower — 256 -> 64 191 -> 267 us, 64 -> 256 97 -> 116, step 18.7 -> 19.2 ms.
 
   constexpr int AHEAD = (FORM && CLITE_BN_HALF) ? 2 : (FORM ? CLITE_BN_AHEAD_FORM : CLITE_BN_AHEAD);
-  // Every operand load of the row loop is BRANCH-FREE: a buffer load whose offset is OOB_OFF (-> zeros, no memory traffic) when the operand
-  // is absent or the row / column is out of range. With the loads inside `if (ep.bn_y) ...` / `if (okr) ...` branches the compiler's
-  // waitcnt insertion put an `s_waitcnt vmcnt(0)` behind the first load of every request (found in the ISA, round 3): the rows "in
-  // flight ahead" were in fact fetched one at a time, and the epilogue phase alone ran at 2.2 TB/s (ablation without the operand DMA:
-  // 71 of the 85 us of the 1024 <- 256 dgrad at 14 x 14).
-  const bool has_bits = FORM ? true : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? true : ep.bn_y != nullptr,
-             has_res = FORM ? FORM == 2 : ep.residual != nullptr;
+  static_assert(NREQ == 0 || NP == 1, "early requests assume the whole-tile staging order");
+  const bool has_bits = FORM ? true : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? true : ep.bn_y != nullptr;
   const bool mask_after = FORM ? FORM == 2 : ep.mask_after_residual != 0;
-  const rsrc_t r_bits = make_rsrc(ep.relu_bits, RSRC_WHOLE), r_aux = make_rsrc(ep.dact_aux, RSRC_WHOLE), r_y = make_rsrc(ep.bn_y, RSRC_WHOLE),
-               r_res = make_rsrc(ep.residual, RSRC_WHOLE);
   const bool to_f32 = FORM ? false : (ep.out_f32 || sizeof(T) == 4);
   const rsrc_t r_out = make_rsrc(ep.out, RSRC_WHOLE);
-  Raw8<T> pa[ROWS_PT], py[ROWS_PT], pr[ROWS_PT];
-  uint32_t pb[ROWS_PT];          // packed relu' bits of the row's 8 columns (clite_epilogue.relu_bits): one byte instead of a 16-byte chunk of dact_aux
-  uint32_t gix[ROWS_PT];
-  bool okr[ROWS_PT];
-  auto request = [&](int q) {
-    int grow = m0 + erow0 + q * RPSE;
-    okr[q] = colok && grow < M;
-    gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
-#ifndef CLITE_EPI_ABLATE
-#define CLITE_EPI_ABLATE 0       // diagnostic builds only: 1 = epilogue without its operand loads, 2 = without its stores
-#endif
-    const uint32_t eoff = (CLITE_EPI_ABLATE & 1) ? OOB_OFF : gix[q] * (uint32_t)sizeof(T);
-    pb[q] = buf_load1(r_bits, (okr[q] && has_bits && !(CLITE_EPI_ABLATE & 1)) ? (gix[q] >> 3) : OOB_OFF);
-    if constexpr (FORM == 0) pa[q].ldb(r_aux, (okr[q] && has_aux && !has_bits) ? eoff : OOB_OFF);
-    py[q].ldb(r_y, (okr[q] && has_y) ? eoff : OOB_OFF);
-    if constexpr (FORM != 1) pr[q].ldb(r_res, (okr[q] && has_res) ? eoff : OOB_OFF);
-  };
+  Raw8<T> (&pa)[ROWS_PT] = rows.pa, (&py)[ROWS_PT] = rows.py, (&pr)[ROWS_PT] = rows.pr;
+  uint32_t (&pb)[ROWS_PT] = rows.pb, (&gix)[ROWS_PT] = rows.gix;
+  bool (&okr)[ROWS_PT] = rows.okr;
+  auto request = [&](int q) { rows.request(q, ep, rm, M, N, m0, n0, tid); };
 #pragma unroll
-  for (int k = 0; k < AHEAD && k < ROWS_PT; ++k) request(row_of(k));
+  for (int k = NREQ; k < AHEAD && k < ROWS_PT; ++k) request(row_of(k));
   lds_barrier();
   EPI_STAMP(6);
+  BN_EPI_PHASE(4);        // accumulators staged, first requests issued
 #pragma unroll
   for (int k = 0; k < ROWS_PT; ++k) {
     const int q = row_of(k);
@@ -745,7 +769,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, cons
       stage(k / QPP);
       lds_barrier();
     }
-    if (k + AHEAD < ROWS_PT) request(row_of(k + AHEAD));
+    if (k + AHEAD < ROWS_PT && k + AHEAD >= NREQ) request(row_of(k + AHEAD));
     const int irow = NP == 1 ? erow0 + q * RPSE : ((erow0 + q * RPSE) / 32 / RM) * 32 + (erow0 + q * RPSE) % 32;
     const float* src = (const float*)(smem + irow * CFG::EPI_PITCH + ecol * 4);
     f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
@@ -793,6 +817,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, cons
   }
   lds_barrier();
   EPI_STAMP(7);
+  BN_EPI_PHASE(5);        // row loop: operands in, results out, statistics
 }
 
 #if defined(CLITE_DIAG) && CLITE_DIAG

