@@ -119,7 +119,10 @@ int clite::launch_wide(const WideOperand& a, const WideOperand& b, const clite_e
     const bool gelu = ep.act == CLITE_ACT_GELU || (ep.dact_aux && ep.dact == 2);
     const bool bn = ep.bn_y || ep.mask_after_residual;
     if (tm128 * tn128 <= 256) pick = 1;
-    else if (gelu || (bn && Ktot < 2048)) return WIDE_NOT_TAKEN;
+    //    (round 3, against the row-range persistent 4-wave kernel with its specialised epilogue, cold caches: 1x1 256 <- 1024 @14 45.2 narrow / 41.5
+    //    wide; windowed 128 <- 128 @28, K = 1152: 75 / 83; 256 <- 256 @14, K = 2304: 58 / 60 — the windowed forms gain nothing from 128-byte K rows
+    //    below K = 2048, the 1x1 forms do from K = 1024)
+    else if (gelu || (bn && Ktot < (window ? 2048 : 1024))) return WIDE_NOT_TAKEN;
     else if (N >= 1024 && tm256 * tn256 >= 128) pick = 3;
     else if (window || Ktot >= 1024) pick = 2;
     else return WIDE_NOT_TAKEN;

@@ -332,18 +332,31 @@ def jsd_backward(rt, mod, saved, gout):
 def jsd_half_forward(rt, mod, feat, which, step, site, acc, gout):
     """which: "image" | "text". Prior discriminator forward + backward and MI-block forward of one modality. acc: the step's 8 zeroed
     accumulators (slot 2 / 3 = this prior's term). Returns the state jsd_join / jsd_half_backward need."""
+    half = jsd_half_block(rt, mod, feat, which, step)
+    half["dprior"] = jsd_half_prior(rt, mod, feat, which, step, site, acc, gout)
+    return half
+
+
+def jsd_half_prior(rt, mod, feat, which, step, site, acc, gout):
+    """The prior discriminator of one modality, forward and backward (its term goes to acc[2] / acc[3], its weight gradients to the arena);
+    returns the gradient it sends to the features, or None when that prior is off. Independent of jsd_half_block: a captured step runs the
+    two on different streams (train_loop.TrainStep)."""
     feat = feat.to(rt.tdtype).contiguous()
     img = which == "image"
+    if not (mod.image_prior if img else mod.text_prior):
+        return None
+    noise = (mod._noise or (None, None))[0 if img else 1]
     pd = mod.prior_d if img else mod.text_prior_d
-    use_prior = mod.image_prior if img else mod.text_prior
-    dprior = None
-    if use_prior:
-        noise = (mod._noise or (None, None))[0 if img else 1]
-        pctx = prior_forward(rt, pd, feat, noise, acc[2:3] if img else acc[3:4], step, site)
-        dprior = prior_backward(rt, pd, pctx, gout, mod.prior_weight, None)
-    blk = mod.global_d.img_block if img else mod.global_d.text_block
+    pctx = prior_forward(rt, pd, feat, noise, acc[2:3] if img else acc[3:4], step, site)
+    return prior_backward(rt, pd, pctx, gout, mod.prior_weight, None)
+
+
+def jsd_half_block(rt, mod, feat, which, step):
+    """MI-block forward of one modality (reference loss.py:21-45)."""
+    feat = feat.to(rt.tdtype).contiguous()
+    blk = mod.global_d.img_block if which == "image" else mod.global_d.text_block
     f, c = mi_block_forward(rt, blk, feat, step.training)
-    return {"f": f, "c": c, "dprior": dprior, "blk": blk}
+    return {"f": f, "c": c, "dprior": None, "blk": blk}
 
 
 def jsd_join(rt, mod, hi, ht, acc, gout):

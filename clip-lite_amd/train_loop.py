@@ -200,7 +200,7 @@ class TrainStep:
 
         # the heads, cut along the modality boundary (loss.jsd_half_forward): the text half on the side stream right behind BERT, the image half
         # and the critic (the only joint piece) on the main stream
-        from .loss import jsd_half_backward, jsd_half_forward, jsd_join
+        from .loss import jsd_half_backward, jsd_half_block, jsd_half_forward, jsd_half_prior, jsd_join
 
         def heads_t1():
             keep["step_h"] = st = rt.next_step(True)
@@ -211,8 +211,16 @@ class TrainStep:
             keep["gout"] = torch.ones(1, device=rt.device, dtype=torch.float32)
             keep["ht"] = jsd_half_forward(rt, m.loss, keep["txt"], "text", st, keep["sites"][1], keep["acc"], keep["gout"])
 
+        # the image half in two pieces that do not depend on each other: the prior discriminator (forward + backward, ~12 latency-bound launches)
+        # on the side stream, idle between the text heads and the text backward, beside the MI block's forward on the main stream
+        def heads_p1():
+            keep["dprior_i"] = jsd_half_prior(rt, m.loss, keep["img"], "image", keep["step_h"], keep["sites"][0], keep["acc"], keep["gout"])
+
+        def heads_b1():
+            keep["hi"] = jsd_half_block(rt, m.loss, keep["img"], "image", keep["step_h"])
+
         def heads_m1():
-            keep["hi"] = jsd_half_forward(rt, m.loss, keep["img"], "image", keep["step_h"], keep["sites"][0], keep["acc"], keep["gout"])
+            keep["hi"]["dprior"] = keep["dprior_i"]
             rt.bump_counters("loss", 2)
             out, keep["df1"], keep["df2"] = jsd_join(rt, m.loss, keep["hi"], keep["ht"], keep["acc"], keep["gout"])
             keep["out"] = out
@@ -279,6 +287,8 @@ class TrainStep:
                 capture("image_fwd", pool_main, image_fwd)
                 capture("text_fwd", pool_side, text_fwd)
                 capture("heads_t1", pool_side, heads_t1)
+                capture("heads_p1", pool_side, heads_p1)
+                capture("heads_b1", pool_main, heads_b1)
                 capture("heads_m1", pool_main, heads_m1)
                 capture("heads_t2", pool_side, heads_t2)
                 capture("heads_m2", pool_main, heads_m2)
@@ -313,8 +323,11 @@ class TrainStep:
         with torch.cuda.stream(side):
             G["text_fwd"].replay()
             G["heads_t1"].replay()                 # text half of the heads: hidden under the tail of the image forward
+            side.wait_stream(main)                 # (the image features)
+            G["heads_p1"].replay()                 # image prior discriminator, forward + backward ...
+        G["heads_b1"].replay()                     # ... beside the image MI block's forward
         main.wait_stream(side)
-        G["heads_m1"].replay()                     # image half forward, critic forward + backward
+        G["heads_m1"].replay()                     # critic forward + backward
         side.wait_stream(main)
         with torch.cuda.stream(side):
             G["heads_t2"].replay()                 # text block backward ...

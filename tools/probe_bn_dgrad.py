@@ -19,6 +19,8 @@ dz = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
 fst = hip.Stats(torch.zeros(8, 3, Cc, device="cuda"), 8, Cc)
 dst = hip.Stats(torch.zeros(8, 3, Cc, device="cuda"), 8, Cc)
 fn = lambda: hip.conv_dgrad(dy, wt, cv, hip.epilogue(dz, Cc, residual=res if resid else None, relu_bits=bits, mask_after_residual=resid, colsum=dst, bn=(y, fst, M)), wt=True)
+if os.environ.get("CLITE_TILE_POLICY"):       # 1 / 2 / 3: force the 8-wave 128 x 128 / 256 x 128 / 256 x 256 tile, 4: the 4-wave kernels
+    hip.set_tile_policy(int(os.environ["CLITE_TILE_POLICY"]))
 junk = torch.empty(300 * 1024 * 1024, device="cuda", dtype=torch.uint8)
 ts = []
 for i in range(8):
