@@ -226,8 +226,9 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--f32", action="store_true", help="exact-f32 parity kernels instead of bf16")
     ap.add_argument("--loss", default="jsd", choices=["jsd", "infonce"], help="cross-modal term: the reference's JSD estimator or the InfoNCE all-pairs variant (BASELINE config 4)")
-    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: forward convs and BERT linears on OCP e4m3 operands (per-tensor current scaling, "
-                    "v_mfma_f32_32x32x16_fp8_fp8, f32 accumulate); backward stays bf16")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: the image encoder's L2-bound forward convs (3x3, and 1x1 at <= 14 x 14) on OCP e4m3 operands "
+                    "(v_mfma_f32_32x32x16_fp8_fp8, f32 accumulate; activations quantised by the producing bn_apply with delayed scaling, weights per step with "
+                    "current scaling: clip-lite_amd/fp8.py); everything else, and every backward GEMM, stays bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
     ap.add_argument("--defer-update", action="store_true", help="run the text encoder's and heads' share of the update at the start of the NEXT step, beside "
@@ -337,7 +338,7 @@ def main():
             "metric": "image-caption pairs/sec (global batch) — ResNet-50+BERT bs1024, 1/2/4/8 MI355X",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.f32 else ("fp8 (e4m3 forward operands) + bf16" if args.fp8 else "bf16"), "data": "synthetic" + (", fed from pinned host memory every step" if args.host_input else ""),
+            "dtype": "f32" if args.f32 else ("fp8 (e4m3 operands of the image encoder's 3x3 / late 1x1 forward convs) + bf16" if args.fp8 else "bf16"), "data": "synthetic" + (", fed from pinned host memory every step" if args.host_input else ""),
             "config": {"workload": f"{args.visual} + BERT-base({args.layers}L) + JSD-MI heads/priors, per-GPU batch {args.batch}, 224x224 images, "
                                    f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)" + ("" if args.loss == "jsd" else ", InfoNCE all-pairs loss"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},

@@ -171,7 +171,7 @@ def bert_forward(rt, net, input_ids, attention_mask, step):
     d0 = drop(p_h)
     hip.layernorm_fwd(dt, s0, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, h, st0, M, Hd, d0)
     ctx = {"B": B, "L": L, "ids": ids, "mask": mask, "s0": s0, "st0": st0, "d0": d0, "layers": []}
-    fp8 = rt.fp8 and rt.lowp
+    fp8 = rt.fp8_text and rt.lowp
 
     def linear(x, w, Mr, N, K, ep):
         """x [Mr][K] @ w[N][K]^T through the fused epilogue: bf16 MFMA, or OCP e4m3 operands with per-tensor current scaling (clite_gemm_nt_fp8)."""

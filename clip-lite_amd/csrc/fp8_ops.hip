@@ -66,6 +66,87 @@ __global__ __launch_bounds__(256) void to_fp8_kernel(const T* __restrict__ x, si
   }
 }
 
+// ---- delayed scaling (the producer-fused quantiser: bn_apply writes the e4m3 copy with LAST step's scale and records THIS step's amax)
+__global__ void scale_update_kernel(float* amax, float* scales, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t* slot = (uint32_t*)amax + (size_t)i * (CLITE_FP8_AMAX_REPLICAS * CLITE_FP8_AMAX_STRIDE);
+  uint32_t ab = 0;
+  for (int r = 0; r < CLITE_FP8_AMAX_REPLICAS; ++r) { const uint32_t v = slot[r * CLITE_FP8_AMAX_STRIDE]; ab = v > ab ? v : ab; slot[r * CLITE_FP8_AMAX_STRIDE] = 0u; }
+  const float a = bits_f32(ab);
+  if (ab == 0u) return;          // nothing recorded this step: keep the scales
+  const bool finite = a == a && a < INFINITY;
+  const float nanv = bits_f32(0x7FC00000u);
+  scales[2 * i] = finite ? FP8_MAX / a : nanv;
+  scales[2 * i + 1] = finite ? a / FP8_MAX : nanv;
+}
+
+// ---- many tensors of one arena, per-tensor current scaling, two launches (the conv weights of a step)
+constexpr int GROUP_CHUNK = 8192;          // elements per workgroup: 256 threads x 8 elements x 4 sweeps
+DEV void group_span(const clite_fp8_item* items, const uint32_t* table, int& item, size_t& lo8, size_t& hi8) {
+  const uint32_t e = table[blockIdx.x];
+  item = (int)(e >> 12);
+  const size_t begin = (size_t)(e & 0xFFFu) * GROUP_CHUNK, numel = items[item].numel;
+  const size_t end = begin + GROUP_CHUNK < numel ? begin + GROUP_CHUNK : numel;
+  lo8 = (items[item].offset + begin) / 8;
+  hi8 = (items[item].offset + end) / 8;
+}
+// pass 1: every workgroup leaves the max |x| of its chunk in partial[blockIdx.x] (bit pattern; NaN -> the quiet-NaN pattern) — no atomics and
+// nothing to zero, so the two launches are a pure function of the arena (same bits every time, and no memset node inside a captured step)
+__global__ __launch_bounds__(256) void group_amax_kernel(const bf16* __restrict__ base, const clite_fp8_item* items, const uint32_t* table, uint32_t* partial) {
+  int item; size_t lo8, hi8;
+  group_span(items, table, item, lo8, hi8);
+  float m = 0.f;
+  bool nan = false;
+  for (size_t i = lo8 + threadIdx.x; i < hi8; i += 256) {
+    float v[8];
+    load8(base + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m = fmaxf(m, fabsf(v[e])); nan = nan || v[e] != v[e]; }
+  }
+  __shared__ uint32_t red[4];
+  uint32_t mb = nan ? 0x7FC00000u : f32_bits(m);          // (amax_kernel: bit patterns order like the values, the NaN pattern above all)
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)wave_shfl_xor_i((int)mb, sh); mb = o > mb ? o : mb; }
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mb;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t b = red[0];
+    for (int w = 1; w < 4; ++w) b = red[w] > b ? red[w] : b;
+    partial[blockIdx.x] = b;
+  }
+}
+// pass 2: the item's amax = max over its chunks' partials (the table lists an item's chunks consecutively: its first workgroup is
+// blockIdx.x - chunk), then the conversion; the workgroup of chunk 0 publishes amax and scales
+__global__ __launch_bounds__(256) void group_to_fp8_kernel(const bf16* __restrict__ base, const clite_fp8_item* items, const uint32_t* table, const uint32_t* __restrict__ partial,
+                                                           fp8* __restrict__ q, float* amax, float* scales) {
+  int item; size_t lo8, hi8;
+  group_span(items, table, item, lo8, hi8);
+  const int chunk = (int)(table[blockIdx.x] & 0xFFFu), nchunks = (int)((items[item].numel + GROUP_CHUNK - 1) / GROUP_CHUNK);
+  const uint32_t* mine = partial + (blockIdx.x - chunk);
+  uint32_t ab = 0;
+  for (int c = threadIdx.x & 63; c < nchunks; c += 64) ab = mine[c] > ab ? mine[c] : ab;
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)wave_shfl_xor_i((int)ab, sh); ab = o > ab ? o : ab; }
+  const float a = bits_f32(ab);
+  if (chunk == 0 && threadIdx.x == 0) amax[item] = a;
+  const bool finite = a == a && a < INFINITY;
+  const float scale = !finite ? bits_f32(0x7FC00000u) : (a > 0.f ? FP8_MAX / a : 1.f);
+  if (chunk == 0 && threadIdx.x == 0) { scales[2 * item] = scale; scales[2 * item + 1] = !finite ? scale : (a > 0.f ? a / FP8_MAX : 1.f); }
+  for (size_t i = lo8 + threadIdx.x; i < hi8; i += 256) {
+    float v[8];
+    load8(base + i * 8, v);
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p0 = v[2 * e] * scale, q0 = v[2 * e + 1] * scale;
+      const float pp = p0 != p0 ? p0 : fminf(fmaxf(p0, -FP8_MAX), FP8_MAX), qq = q0 != q0 ? q0 : fminf(fmaxf(q0, -FP8_MAX), FP8_MAX);
+      w[e] = cvt2_fp8(pp, qq);
+    }
+    *(u32x2*)(q + i * 8) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+  }
+}
+
 // ---- GEMM on fp8 operands. KC x KC only (both operands k-contiguous: activations x weights, the forward direction).
 // LDS image: igemm_dma.h's KC image [rows][64 B] with 16-byte chunk c of row r in slot c ^ ((r>>2)&3); a k-step is 16 fp8 = one chunk, and
 // lane (r, h) reads bytes 8h..8h+7 of it.
@@ -242,6 +323,21 @@ extern "C" int clite_fp8_quantize(int dtype, const void* x, uint64_t n, float* a
   } else {
     return -1;
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_fp8_scale_update(float* amax, float* scales, int n, void* stream) {
+  if (!amax || !scales || n <= 0) return -1;
+  hipLaunchKernelGGL(scale_update_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, amax, scales, n);
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_fp8_quantize_group(const void* base, const clite_fp8_item* items_dev, const uint32_t* wg_table_dev, int n_items, int n_wgs,
+                                        uint32_t* partial, float* amax, float* scales, void* q_base, void* stream) {
+  if (!base || !items_dev || !wg_table_dev || !partial || !amax || !scales || !q_base || n_items <= 0 || n_items >= (1 << 20) || n_wgs <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(group_amax_kernel, dim3(n_wgs), dim3(256), 0, st, (const bf16*)base, items_dev, wg_table_dev, partial);
+  hipLaunchKernelGGL(group_to_fp8_kernel, dim3(n_wgs), dim3(256), 0, st, (const bf16*)base, items_dev, wg_table_dev, (const uint32_t*)partial, (fp8*)q_base, amax, scales);
   return (int)hipGetLastError();
 }
 

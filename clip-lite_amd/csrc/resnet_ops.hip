@@ -90,7 +90,9 @@ template <bool NT, typename T> DEV void ld8(const T* p, float (&v)[8]) { if cons
 template <bool NT, typename T> DEV void st8(T* p, const float (&v)[8]) { if constexpr (NT) store8_nt(p, v); else store8(p, v); }
 constexpr size_t BN_NT_BYTES = (size_t)64 << 20;
 
-template <typename T, bool NT>
+// Q (bf16): the producer-fused e4m3 quantiser of the fp8 forward (clite_bn.fp8_out / fp8_scale / fp8_amax): the e4m3 copy of the stored value
+// at last step's scale goes out beside it, and this step's max |out| is folded into fp8_amax — one integer atomic max per workgroup.
+template <typename T, bool NT, bool Q = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
@@ -118,6 +120,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
   // four lanes fold their mask bytes into one dword below: that needs the four chunks of a quad in one row (CPR % 4 == 0; C = 8 or 16 keep
   // byte stores) and every lane of a wave in the loop together, hence the wave-uniform trip count with a per-lane `live` predicate
   const bool pack = (CPR & 3) == 0;
+  float qmax = 0.f;
+  bool qnan = false;
+  const float qscale = (Q && p.fp8_out) ? p.fp8_scale[0] : 1.f;
 #pragma unroll 4
   for (int rb = row_begin; rb < row_end; rb += RPS) {
     const int r = rb + r0;
@@ -160,6 +165,37 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
       }
     }
     if (live) st8<NT>(out + idx, v);
+    if constexpr (Q) {
+      round8_bf16(v);          // quantise / measure the value as stored, so that the copy equals clite_fp8_quantize of `out` at the same scale
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qmax = live ? fmaxf(qmax, fabsf(v[e])) : qmax; qnan = qnan || (live && v[e] != v[e]); }
+      if (p.fp8_out && live) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // (a NaN passes the clamp untouched and converts to e4m3's NaN, as in fp8_ops.hip)
+          const float p0 = v[2 * e] * qscale, q0 = v[2 * e + 1] * qscale;
+          const float pp = p0 != p0 ? p0 : fminf(fmaxf(p0, -448.f), 448.f), qq = q0 != q0 ? q0 : fminf(fmaxf(q0, -448.f), 448.f);
+          w[e] = cvt2_fp8(pp, qq);
+        }
+        *(u32x2*)(p.fp8_out + idx) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+      }
+    }
+  }
+  if constexpr (Q) {
+    if (p.fp8_amax) {
+      __shared__ uint32_t red[4];
+      uint32_t mb = qnan ? 0x7FC00000u : f32_bits(qmax);      // non-negative floats order like their bit patterns; the quiet-NaN pattern above all
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)wave_shfl_xor_i((int)mb, sh); mb = o > mb ? o : mb; }
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mb;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t b = red[0];
+        for (int w = 1; w < 4; ++w) b = red[w] > b ? red[w] : b;
+        atomic_max_u32((uint32_t*)p.fp8_amax + (blockIdx.x % CLITE_FP8_AMAX_REPLICAS) * CLITE_FP8_AMAX_STRIDE, b);
+      }
+    }
   }
 }
 
@@ -688,6 +724,12 @@ extern "C" int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const
   int grid = bn_grid(p->M, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
   const bool nt = (size_t)p->M * p->C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
+  if (p->fp8_out || p->fp8_amax) {          // producer-fused e4m3 copy / amax (bf16 activations only)
+    if (dtype != CLITE_BF16 || (p->fp8_out && !p->fp8_scale)) return -1;
+    if (nt) hipLaunchKernelGGL((bn_apply_kernel<bf16, true, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb);
+    else hipLaunchKernelGGL((bn_apply_kernel<bf16, false, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb);
+    return (int)hipGetLastError();
+  }
   if (nt) {
     DISPATCH(dtype,
              hipLaunchKernelGGL((bn_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb),

@@ -1,0 +1,86 @@
+"""The fp8 (OCP e4m3) forward of the image encoder — BASELINE.json configs[4]; the reference has no fp8 code (encoder.py:36-41 is the call site
+whose convolutions this replaces), so the policy is this build's:
+
+* which convolutions: the windowed (3x3) ones and the 1x1 ones at <= 14 x 14 — the launches bound by L2 -> LDS operand traffic, which e4m3 halves.
+  The 1x1 convolutions of the 56 x 56 / 28 x 28 stages are HBM-bound on tensors that are written once and read once: an e4m3 copy costs the
+  half-write it saves as a half-read, so they stay bf16. The stem, the heads and every backward GEMM stay bf16.
+* weights: per-tensor CURRENT scaling, all eligible conv weights in two launches per step (hip.Fp8WeightGroup over the bf16 arena).
+* activations: per-tensor DELAYED scaling, quantised by their producer — `bn_apply` writes the e4m3 copy beside the bf16 tensor with the scale
+  made from the previous step's amax and records this step's amax (clite_bn.fp8_*); one `clite_fp8_scale_update` per step turns the amaxes
+  into next step's scales. A tensor without a scale yet (the first step) is quantised by the stand-alone `clite_fp8_quantize` (current scaling)."""
+import torch
+
+from . import hip
+
+
+def conv_eligible(conv):
+    """Channel granularity of the e4m3 operand loaders (include/clite.h: clite_conv_fwd_fp8)."""
+    return conv.in_channels % (64 if conv.k > 1 else 16) == 0
+
+
+class Fp8Forward:
+    """Per-network state of the fp8 forward: the weight group, one (amax, scales) slot per BatchNorm whose output an fp8 convolution reads."""
+
+    def __init__(self, rt, net):
+        self.rt = rt
+        convs, bns = [], []
+        for blk in net.blocks():
+            for conv, bn in blk.units():
+                convs.append(conv)
+                bns.append(bn)
+            if blk.downsample is not None:
+                convs.append(blk.downsample[0])
+        self.windex = {}
+        spans = []
+        for conv in convs:
+            if conv_eligible(conv):
+                self.windex[id(conv)] = (len(spans), conv)
+                spans.append(rt.arena.index[conv.weight._clite[1]])
+        self.wgroup = hip.Fp8WeightGroup(rt.arena.flat_lp, spans) if spans else None
+        self.slot = {id(bn): i for i, bn in enumerate(bns)}
+        n = max(len(bns), 1)
+        self.amax = torch.zeros(n, hip.FP8_AMAX_WORDS, dtype=torch.float32, device=rt.device)          # one slot of replicated words per tensor
+        self.scales = torch.ones(n, 2, dtype=torch.float32, device=rt.device)
+        self.ready, self._seen = set(), set()
+
+    # ---- policy
+    def wants(self, conv, H):
+        """Does `conv`, reading an H x H (or smaller) input, run on e4m3 operands?"""
+        return id(conv) in self.windex and (conv.k > 1 or H <= 14)
+
+    # ---- per step
+    def begin_step(self):
+        if self.wgroup is not None:
+            self.wgroup.quantize()
+
+    def weight(self, conv):
+        i, _ = self.windex[id(conv)]
+        return self.wgroup.view(i, self.rt.arena.w(conv.weight).shape)
+
+    def producer(self, bn, M, Cc, want):
+        """(clite_bn.fp8_* triple for bn_apply, the Fp8View its consumers read) for the output of `bn`; (None, None) when no fp8 conv reads it."""
+        if not want:
+            return None, None
+        s = self.slot[id(bn)]
+        self._seen.add(s)
+        amax = self.amax[s]
+        if s not in self.ready:          # no scale yet: record the amax only; the consumer quantises the bf16 tensor itself this once
+            return (None, None, amax), None
+        q = torch.empty(M, Cc, dtype=torch.uint8, device=self.rt.device)
+        return (q, self.scales[s], amax), hip.Fp8View(q, self.scales[s])
+
+    def end_step(self):
+        if self._seen:
+            hip.fp8_scale_update(self.amax, self.scales)
+            self.ready |= self._seen
+            self._seen = set()
+
+
+def forward_state(rt, net):
+    """The network's Fp8Forward when the runtime's fp8 forward is on (bf16 mode only), else None."""
+    if not (rt.fp8 and rt.lowp):
+        return None
+    st = rt.fp8_nets.get(id(net))
+    if st is None:
+        st = rt.fp8_nets[id(net)] = Fp8Forward(rt, net)
+    return st

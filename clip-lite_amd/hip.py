@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -43,12 +43,17 @@ class Bn(C.Structure):
         ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32), ("replicas", C.c_int32), ("rstride", C.c_int32), ("centered", C.c_int32),
         ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
         ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p), ("relu_bits", C.c_void_p),
+        ("fp8_out", C.c_void_p), ("fp8_scale", C.c_void_p), ("fp8_amax", C.c_void_p),
     ]
 
 
 class WgradItem(C.Structure):
     _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32)]
+
+
+class Fp8Item(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("numel", C.c_uint64)]
 
 
 class TransposeItem(C.Structure):
@@ -80,6 +85,8 @@ _SIGNATURES = {
     "clite_fp8_quantize": [_I, _V, _U64, _V, _V, _V, _V],
     "clite_gemm_nt_fp8": [_V, _I, _V, _I, _I, _I, _I, _V, _V, _V, _V],
     "clite_conv_fwd_fp8": [_V, _V, _V, _V, _V, _V, _V],
+    "clite_fp8_scale_update": [_V, _V, _I, _V],
+    "clite_fp8_quantize_group": [_V, _V, _V, _I, _I, _V, _V, _V, _V, _V],
     "clite_wgrad_group_workspace": [_I, C.c_int64, _V],
     "clite_stem_fwd": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
     "clite_stem_wgrad": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
@@ -404,6 +411,60 @@ class Fp8Tensor:
         check(lib().clite_fp8_quantize(dt, p(x), x.numel(), p(self.amax), p(self.scales), p(self.q), stream_ptr(x)), "fp8_quantize")
 
 
+class Fp8View:
+    """An e4m3 tensor somebody else produced (bn_apply's fused copy, a slice of the grouped weight quantiser's arena): q + its scales."""
+    __slots__ = ("q", "scales")
+
+    def __init__(self, q, scales):
+        self.q, self.scales = q, scales
+
+
+FP8_GROUP_CHUNK = 8192
+
+
+class Fp8WeightGroup:
+    """Per-tensor current-scaling e4m3 copies of many tensors of ONE bf16 arena in two launches (clite_fp8_quantize_group): the conv weights
+    after every optimizer update. `spans` = [(element offset, numel)]; view(i, shape) is tensor i's Fp8View."""
+
+    def __init__(self, arena_lp, spans):
+        dev = arena_lp.device
+        self.base, self.n = arena_lp, len(spans)
+        items = (Fp8Item * self.n)()
+        table = []
+        lo, hi = min(o for o, _ in spans), max(o + n for o, n in spans)
+        self.lo = lo
+        for i, (o, n) in enumerate(spans):
+            assert o % 8 == 0 and n % 8 == 0 and n <= 4096 * FP8_GROUP_CHUNK and i < (1 << 20)
+            items[i].offset, items[i].numel = o, n
+            table += [(i << 12) | c for c in range((n + FP8_GROUP_CHUNK - 1) // FP8_GROUP_CHUNK)]
+        self.spans = list(spans)
+        self.items = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+        assert max(table) < 2 ** 31
+        self.table = torch.tensor(table, dtype=torch.int32).to(dev)
+        self.n_wgs = len(table)
+        self.q = torch.zeros(hi, dtype=torch.uint8, device=dev)          # indexed by the arena's element offsets (the part below `lo` is never touched)
+        self.amax = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.partial = torch.zeros(self.n_wgs, dtype=torch.int32, device=dev)
+        self.scales = torch.ones(self.n, 2, dtype=torch.float32, device=dev)
+
+    def quantize(self):
+        check(lib().clite_fp8_quantize_group(p(self.base), p(self.items), p(self.table), self.n, self.n_wgs, p(self.partial), p(self.amax), p(self.scales), p(self.q),
+                                             stream_ptr(self.base)), "fp8_quantize_group")
+
+    def view(self, i, shape):
+        o, n = self.spans[i]
+        return Fp8View(self.q[o:o + n].view(shape), self.scales[i])
+
+
+FP8_AMAX_WORDS = 16 * 32          # one amax slot (include/clite.h: CLITE_FP8_AMAX_REPLICAS x CLITE_FP8_AMAX_STRIDE floats)
+
+
+def fp8_scale_update(amax, scales):
+    """amax: f32 [n][FP8_AMAX_WORDS] slots, scales: f32 [n][2]."""
+    assert amax.numel() % FP8_AMAX_WORDS == 0 and scales.numel() == 2 * (amax.numel() // FP8_AMAX_WORDS)
+    check(lib().clite_fp8_scale_update(p(amax), p(scales), amax.numel() // FP8_AMAX_WORDS, stream_ptr(amax)), "fp8_scale_update")
+
+
 def gemm_nt_fp8(A8, B8, M, N, K, ep, lda=None, ldb=None):
     check(lib().clite_gemm_nt_fp8(p(A8.q), lda or K, p(B8.q), ldb or K, M, N, K, p(A8.scales), p(B8.scales), C.byref(ep), stream_ptr(A8.q)), "gemm_nt_fp8")
 
@@ -429,8 +490,9 @@ def stem_unpack_grad(dwv, dw):
 
 
 # ------------------------------------------------------------------------------------------------ BN / pools
-def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, eps, relu, res_bn=None, centered=False, relu_bits=None):
-    """stats: hip.Stats (training) or None (eval: running statistics). relu_bits: uint8 [M][C / 8] that bn_apply fills with the packed ReLU mask."""
+def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, eps, relu, res_bn=None, centered=False, relu_bits=None, fp8=None):
+    """stats: hip.Stats (training) or None (eval: running statistics). relu_bits: uint8 [M][C / 8] that bn_apply fills with the packed ReLU mask.
+    fp8: (q uint8 [M][C] or None, scales f32[2] or None, amax f32[1] or None) — bn_apply's producer-fused e4m3 copy (clite_bn.fp8_*)."""
     b = Bn()
     b.M, b.C = M, Cc
     b.centered = int(centered)
@@ -443,6 +505,8 @@ def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, 
         b.res_stats = p(rs.t) if rs is not None else None
         b.res_gamma, b.res_beta, b.res_running_mean, b.res_running_var = p(rg), p(rb), p(rrm), p(rrv)
     b.relu_bits = p(relu_bits)
+    if fp8 is not None:
+        b.fp8_out, b.fp8_scale, b.fp8_amax = p(fp8[0]), p(fp8[1]), p(fp8[2])
     return b
 
 

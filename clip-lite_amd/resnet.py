@@ -116,13 +116,13 @@ def _alloc(rt, *shape):
     return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
 
 
-def _bn_desc(rt, bn, M, stats, relu, training, res=None, bits=None):
+def _bn_desc(rt, bn, M, stats, relu, training, res=None, bits=None, fp8=None):
     res_bn = None
     if res is not None:
         rbn, rstats = res
         res_bn = (rstats, rbn.weight, rbn.bias, rbn.running_mean, rbn.running_var)
     return hip.bn_desc(M, bn.num_features, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                       training, training, bn.momentum, bn.eps, relu, res_bn, centered=rt.precise_bn, relu_bits=bits)
+                       training, training, bn.momentum, bn.eps, relu, res_bn, centered=rt.precise_bn, relu_bits=bits, fp8=fp8)
 
 
 def _relu_bits(rt, M, Cc, training):
@@ -131,14 +131,16 @@ def _relu_bits(rt, M, Cc, training):
     return torch.empty(M, Cc // 8, device=rt.device, dtype=torch.uint8) if training else None
 
 
-def _conv(rt, x, N, H, W, conv, training):
+def _conv(rt, x, N, H, W, conv, training, f8=None, x8=None):
+    """f8: the network's fp8.Fp8Forward (or None); x8: the e4m3 copy of x its producer wrote (hip.Fp8View), when it did."""
     cv = hip.conv_desc(rt.dt, N, H, W, conv.in_channels, conv.out_channels, conv.k, conv.k, conv.stride, conv.pad)
     M = N * cv.Ho * cv.Wo
     y = _alloc(rt, M, conv.out_channels)
     stats = rt.new_stats(conv.out_channels) if training else None
-    if rt.fp8 and rt.lowp and conv.in_channels % (64 if conv.k > 1 else 16) == 0:
-        # OCP e4m3 operands with per-tensor current scaling (include/clite.h: clite_conv_fwd_fp8); y, the statistics and everything backward stay as they are
-        hip.conv_fwd_fp8(hip.Fp8Tensor(x, rt.dt), hip.Fp8Tensor(rt.arena.w(conv.weight), rt.dt), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
+    if f8 is not None and f8.wants(conv, H):
+        # OCP e4m3 operands (include/clite.h: clite_conv_fwd_fp8; policy and scaling: fp8.py); y, the statistics and everything backward stay as they are.
+        # An input without a producer-written copy (no scale yet on the first step; the pooled stem output) is quantised here, current scaling
+        hip.conv_fwd_fp8(x8 if x8 is not None else hip.Fp8Tensor(x, rt.dt), f8.weight(conv), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
     else:
         hip.conv_fwd(x, rt.arena.w(conv.weight), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
     if training and rt.precise_bn:
@@ -211,15 +213,22 @@ def resnet_forward(rt, net, image, training, staged=None):
     hip.stem_bn_pool_fwd(dt, _bn_desc(rt, net.bn1, N * Ho * Wo, st0, True, training), y0, p0, idx, N, Ho, Wo)
     ctx["stem"] = (xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq)
 
+    # fp8 forward (BASELINE configs[4]; fp8.py): the eligible convs read e4m3 copies that the producing bn_apply wrote beside its bf16 output
+    from .fp8 import forward_state
+    f8 = forward_state(rt, net)
+    if f8 is not None:
+        f8.begin_step()
     x, Hc, Wc = p0, Hq, Wq
+    x8 = None                           # (the pooled stem output has no fused copy; 1x1 convs at 56 x 56 do not want one)
     recs = []
-    for blk in net.blocks():
+    blocks = list(net.blocks())
+    for bi, blk in enumerate(blocks):
         units = []
-        xin, Hin, Win = x, Hc, Wc
-        h, Hh, Wh = xin, Hin, Win
+        xin, xin8, Hin, Win = x, x8, Hc, Wc
+        h, h8, Hh, Wh = xin, xin8, Hin, Win
         specs = blk.units()
         for i, (conv, bn) in enumerate(specs):
-            u = _conv(rt, h, N, Hh, Wh, conv, training)
+            u = _conv(rt, h, N, Hh, Wh, conv, training, f8, h8)
             u.bn = bn
             Hh, Wh = u.cv.Ho, u.cv.Wo
             M = N * Hh * Wh
@@ -227,20 +236,28 @@ def resnet_forward(rt, net, image, training, staged=None):
             u.out = _alloc(rt, M, conv.out_channels)
             u.bits = _relu_bits(rt, M, conv.out_channels, training)
             if not last:
-                hip.bn_apply(dt, _bn_desc(rt, bn, M, u.stats, True, training, bits=u.bits), u.y, None, u.out)
+                q, h8 = f8.producer(bn, M, conv.out_channels, f8.wants(specs[i + 1][0], Hh)) if f8 is not None else (None, None)
+                hip.bn_apply(dt, _bn_desc(rt, bn, M, u.stats, True, training, bits=u.bits, fp8=q), u.y, None, u.out)
             units.append(u)
             h = u.out
         ud = None
         last = units[-1]
         M = N * Hh * Wh
+        q = x8 = None
+        if f8 is not None and bi + 1 < len(blocks):          # the block output's readers: the next block's first conv and its downsample conv
+            nb = blocks[bi + 1]
+            readers = [nb.units()[0][0]] + ([nb.downsample[0]] if nb.downsample is not None else [])
+            q, x8 = f8.producer(last.bn, M, last.conv.out_channels, any(f8.wants(c, Hh) for c in readers))
         if blk.downsample is not None:
-            ud = _conv(rt, xin, N, Hin, Win, blk.downsample[0], training)
+            ud = _conv(rt, xin, N, Hin, Win, blk.downsample[0], training, f8, xin8)
             ud.bn = blk.downsample[1]
-            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, res=(ud.bn, ud.stats), bits=last.bits), last.y, ud.y, last.out)
+            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, res=(ud.bn, ud.stats), bits=last.bits, fp8=q), last.y, ud.y, last.out)
         else:
-            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, bits=last.bits), last.y, xin, last.out)
+            hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, bits=last.bits, fp8=q), last.y, xin, last.out)
         recs.append((units, ud, Hin, Win))
         x, Hc, Wc = last.out, Hh, Wh
+    if f8 is not None:
+        f8.end_step()
     Cout = net.out_dim
     feat = _alloc(rt, N, Cout)
     hip.avgpool_fwd(dt, x, feat, N, Hc * Wc, Cout)

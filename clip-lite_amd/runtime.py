@@ -284,7 +284,9 @@ class DeviceRuntime:
         import os
         self.s2_classes = True             # 3x3/stride-2 dgrads as four parity-class GEMMs (attribute: tools flip it for A/B runs)
         self.fuse_bn_backward = True       # BatchNorm-backward reductions inside the dgrad epilogues (resnet.py)
-        self.fp8 = False                   # forward convs / BERT linears on OCP e4m3 operands (BASELINE configs[4]); bf16 mode only
+        self.fp8 = False                   # image-encoder forward convs on OCP e4m3 operands, quantised by their producers (BASELINE configs[4]; fp8.py); bf16 mode only
+        self.fp8_text = False              # ... and BERT's forward linears (stand-alone quantiser, current scaling: slower than bf16 — kept for the kernel's tests)
+        self.fp8_nets = {}                 # id(ResNet) -> fp8.Fp8Forward
         self.group_wgrad = bool(lowp)      # weight gradients of a backward pass as grouped launches (hip.WgradGroup / clite_wgrad_group)
         self._aux_streams, self._aux_busy, self._aux_keep, self.overlap_wgrad = {}, set(), {}, False
         self.steps = 0

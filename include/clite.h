@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 8
+#define CLITE_ABI_VERSION 9
 int clite_abi_version(void);
 
 /* Deterministic-reduction mode (process-wide, default off; the counterpart of torch.use_deterministic_algorithms for this library).
@@ -180,6 +180,22 @@ int clite_gemm_nt_fp8(const void* A8, int lda, const void* B8, int ldb, int M, i
  * C % 64 == 0 for windowed convs. */
 int clite_conv_fwd_fp8(const void* x8, const void* w8, const clite_conv* cv, const float* x_scales, const float* w_scales,
                        const clite_epilogue* ep, void* stream);
+/* Delayed scaling, once per step over all producer-fused tensors: slot i of `amax` (clite_bn.fp8_amax; a = the maximum of its words) with
+ * a != 0: scales[2i] = 448 / a, scales[2i + 1] = a / 448 (both NaN when a is not finite); the slot is zeroed. A slot that stayed 0 keeps
+ * its scales. */
+#define CLITE_FP8_AMAX_REPLICAS 16
+#define CLITE_FP8_AMAX_STRIDE 32
+int clite_fp8_scale_update(float* amax, float* scales, int n, void* stream);
+/* Per-tensor CURRENT scaling of many tensors of one arena in two launches (the conv weights after the optimizer update): item i is the
+ * `numel` (% 8 == 0) elements at element offset `offset` (% 8 == 0) of `base`; its e4m3 copy goes to q_base + offset, its scales to
+ * scales[2i..2i+1], its amax to amax[i]. wg_table_dev[w] = (item << 12 | chunk): workgroup w handles elements [chunk * 8192, (chunk + 1) * 8192)
+ * of its item (chunk < 4096, i.e. tensors up to 32 M elements; items < 2^20), an item's chunks CONSECUTIVE and ascending in the table;
+ * `partial` is n_wgs words of scratch. No atomics, nothing to zero: the result is a pure function of the arena. bf16 only. */
+typedef struct clite_fp8_item {
+  uint64_t offset, numel;
+} clite_fp8_item;
+int clite_fp8_quantize_group(const void* base, const clite_fp8_item* items_dev, const uint32_t* wg_table_dev, int n_items, int n_wgs,
+                             uint32_t* partial, float* amax, float* scales, void* q_base, void* stream);
 
 /* ResNet stem conv1 = nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False) (torchvision, reference encoder.py:36-38) on the
  * pre-padded NHWC4 image from clite_image_to_nhwc4 (Hp >= 2*(Ho-1)+7, Wp >= 2*(Wo-1)+8, Wp even). wv is the weight packed
@@ -215,6 +231,18 @@ typedef struct clite_bn {
   float* res_running_var;
   uint8_t* relu_bits;        /* clite_bn_apply with relu = 1: optional [M][C / 8] bytes, bit e of byte (m * C + c) / 8 = (out[m][c + e] > 0): the
                               * ReLU mask the backward pass needs, at 1/16 of the bytes of re-reading `out` for its sign. NULL: not written. */
+  /* clite_bn_apply, bf16, fp8 forward (the producer-fused quantiser of DESIGN.md §6.2; any of the three may be NULL):
+   *   fp8_out   [M][C] e4m3 copy of `out` for the convs that read it: q = e4m3(clamp(out * fp8_scale[0], +-448)) of the value as stored,
+   *             written by the same pass — half a write instead of clite_fp8_quantize's two reads and half a write;
+   *   fp8_scale device f32[2] = {scale, 1 / scale}: DELAYED scaling, made from an earlier step's amax (clite_fp8_scale_update);
+   *   fp8_amax  one amax SLOT = device f32[CLITE_FP8_AMAX_REPLICAS * CLITE_FP8_AMAX_STRIDE]: max |out| of THIS call folded in by integer
+   *             atomic maxima on the bit pattern, workgroup b into word (b % REPLICAS) * STRIDE — same-address atomics retire at ~90 per
+   *             microsecond chip-wide, a thousand workgroups on one word cost more than the pass over a small tensor; the slot's value is
+   *             the maximum of its words (clite_fp8_scale_update folds and zeroes them). A NaN anywhere makes it the quiet-NaN pattern,
+   *             an infinity +inf: both give NaN scales, as clite_fp8_quantize does. */
+  uint8_t* fp8_out;
+  const float* fp8_scale;
+  float* fp8_amax;
 } clite_bn;
 
 /* Second pass of a two-pass variance (used by the exact-f32 parity mode): stats[2][c] += sum_m (y[m][c] - stats[0][c]/M)^2;

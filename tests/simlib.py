@@ -87,6 +87,7 @@ class Bn(C.Structure):
         ("update_running", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("relu", C.c_int32), ("replicas", C.c_int32), ("rstride", C.c_int32), ("centered", C.c_int32),
         ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
         ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p), ("relu_bits", C.c_void_p),
+        ("fp8_out", C.c_void_p), ("fp8_scale", C.c_void_p), ("fp8_amax", C.c_void_p),
     ]
 
 

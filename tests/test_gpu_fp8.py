@@ -105,7 +105,7 @@ def test_fp8_forward_step_tracks_bf16_step():
                 if n.endswith("bn2.weight"):           # the last BatchNorm of a BasicBlock's residual branch
                     p.mul_(0.1)
         M = M.to("cuda").train()
-        M.runtime.fp8 = fp8
+        M.runtime.fp8 = M.runtime.fp8_text = fp8          # image encoder (producer-fused, fp8.py) and BERT's linears (stand-alone quantiser)
         M.loss.set_prior_noise(*u)
         out = M(batch)
         out["loss"].backward()
@@ -121,8 +121,9 @@ def test_fp8_forward_step_tracks_bf16_step():
 def test_resnet101_with_fp8_forward_tracks_its_bf16_step():
     """BASELINE configs[4] as stated — ResNet-101 WITH fp8 on (the backbone and the fp8 path had only been tested separately):
     ResNet-101 + 2-layer BERT + heads (2048-d image features), batch 16, 128 x 128, on the conditioned problem (the last BatchNorm gain of
-    every Bottleneck x 0.1, tests/test_gpu_ops.py). The step with e4m3 forward operands (101 convs + the BERT linears on
-    v_mfma_f32_32x32x16_fp8_fp8, per-tensor current scaling) against the bf16 step on the same weights and batch. Stated bar:
+    every Bottleneck x 0.1, tests/test_gpu_ops.py). The step with e4m3 forward operands (the image encoder's eligible convs — fp8.py's policy — and
+    the BERT linears on v_mfma_f32_32x32x16_fp8_fp8) against the bf16 step on the same weights and batch, then a second fp8 step that runs the
+    PRODUCER-FUSED quantiser (bn_apply writes the e4m3 copies at the delayed scale). Stated bar:
     loss within 3e-2; gradient-arena cosine >= 0.85 (twice the depth of the ResNet-18 case: e4m3's 2^-4 per-element rounding enters 101
     times); every loss finite; and a NaN planted in the input image must come out as a NaN loss in fp8 mode (the quantiser no longer
     launders non-finite values: ADVICE r2)."""
@@ -145,13 +146,27 @@ def test_resnet101_with_fp8_forward_tracks_its_bf16_step():
                 if n.endswith("bn3.weight"):           # the last BatchNorm of a Bottleneck's residual branch
                     p.mul_(0.1)
         M = M.to("cuda").train()
-        M.runtime.fp8 = fp8
+        M.runtime.fp8 = M.runtime.fp8_text = fp8
         M.loss.set_prior_noise(*u)
         out = M(batch)
         out["loss"].backward()
         torch.cuda.synchronize()
         res.append((out["loss"].item(), M.runtime.arena.flat_g.clone()))
         if fp8:
+            # The first forward had no scales yet (stand-alone quantiser, current scaling) and recorded every tensor's amax; from the second on
+            # bn_apply writes the e4m3 copies itself at the scale made from the previous forward's amax (delayed scaling, fp8.py). Same weights,
+            # same batch: the delayed scale IS the current one, so the fused step repeats the first up to what two runs of this 101-layer problem differ by
+            # anyway (float-atomic order through 101 ReLU layers: loss +- 5e-3, gradient cosine ~0.88; measured)
+            (st,) = M.runtime.fp8_nets.values()
+            assert st.ready and not st._seen
+            M.runtime.arena.flat_g.zero_()
+            out2 = M(batch)
+            out2["loss"].backward()
+            torch.cuda.synchronize()
+            g1f, g2f = res[-1][1], M.runtime.arena.flat_g
+            cos2 = (g1f @ g2f / (g1f.norm() * g2f.norm())).item()
+            print(f"fused quantiser: loss {out2['loss'].item():.5f} (first fp8 step {res[-1][0]:.5f}), gradient cosine {cos2:.4f}")
+            assert abs(out2["loss"].item() - res[-1][0]) < 1e-2 and cos2 >= 0.85          # (two runs of this 101-layer problem decorrelate to ~0.88 by float-atomic order alone; the copies themselves are checked bit for bit in test_bn_apply_fused_e4m3_copy_matches_torch_cast)
             bad = {k: v.clone() for k, v in batch.items()}
             bad["image"][3, 1, 17, 5] = float("nan")
             M.runtime.arena.flat_g.zero_()
@@ -161,3 +176,41 @@ def test_resnet101_with_fp8_forward_tracks_its_bf16_step():
     print(f"ResNet-101: loss bf16 {l0:.5f} fp8-forward {l1:.5f}; gradient cosine fp8~bf16 {cos:.4f}")
     assert np.isfinite(l0) and np.isfinite(l1) and abs(l0 - l1) < 3e-2 and cos >= 0.85
 
+
+
+@pytest.mark.parametrize("M,Cc,res", [(401408, 128, False), (25088, 256, True), (1000, 64, False)])
+def test_bn_apply_fused_e4m3_copy_matches_torch_cast(M, Cc, res):
+    """clite_bn.fp8_out / fp8_scale / fp8_amax (the producer-fused quantiser) at the streaming (>= 64 MB) and cached sizes: the
+    copy equals torch's float8_e4m3fn cast of the STORED bf16 output at the given scale (saturating), fp8_amax = max |out|, and the bf16 output
+    and ReLU bits are bit-identical to the plain call's."""
+    hip = _hip()
+    g = torch.Generator(device="cuda").manual_seed(M % 977)
+    y = (torch.randn(M, Cc, device="cuda", generator=g) * 2 + 0.5).bfloat16()
+    r = torch.randn(M, Cc, device="cuda", generator=g).bfloat16() if res else None
+    st = hip.Stats(torch.zeros(8 * 3 * Cc, device="cuda"), 8, Cc)
+    st.t.view(8, 3, Cc)[0, 0] = y.float().sum(0)
+    st.t.view(8, 3, Cc)[0, 1] = (y.float() ** 2).sum(0)
+    gamma, beta = 1 + 0.1 * torch.randn(Cc, device="cuda", generator=g), 0.1 * torch.randn(Cc, device="cuda", generator=g)
+
+    def run(fp8):
+        rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+        out = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
+        bits = torch.empty(M, Cc // 8, device="cuda", dtype=torch.uint8)
+        hip.bn_apply(BF16, hip.bn_desc(M, Cc, st, gamma, beta, rm, rv, True, True, 0.1, 1e-5, True, relu_bits=bits, fp8=fp8), y, r, out)
+        torch.cuda.synchronize()
+        return out, bits
+
+    out0, bits0 = run(None)
+    amax_true = out0.float().abs().max()
+    scales = torch.tensor([448.0 / (0.7 * amax_true.item()), 0.7 * amax_true.item() / 448.0], device="cuda")
+    q = torch.full((M, Cc), 0x55, device="cuda", dtype=torch.uint8)
+    amax = torch.zeros(hip.FP8_AMAX_WORDS, device="cuda")
+    out1, bits1 = run((q, scales, amax))
+    assert torch.equal(out0, out1) and torch.equal(bits0, bits1)
+    assert amax.max().item() == amax_true.item()
+    ref = (out0.float() * scales[0]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    same = (q == ref) | ((q & 0x7f == 0) & (ref & 0x7f == 0))
+    assert same.all(), (~same).sum().item()
+    hip.fp8_scale_update(amax, scales.view(1, 2))
+    torch.cuda.synchronize()
+    assert not amax.any() and abs(scales[0].item() * amax_true.item() / 448.0 - 1) < 1e-6

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from simlib import Conv, bf16_round, from_bf16, lib, make_ep, ptr, to_bf16
+from simlib import Bn, Conv, bf16_round, from_bf16, lib, make_ep, ptr, to_bf16
 
 BF16, F32 = 0, 1
 
@@ -133,3 +133,109 @@ def test_conv_fwd_fp8(N, H, W, Cc, K, R, st, pad):
     assert L.clite_conv_fwd_fp8(ptr(qx), ptr(qw), C.byref(cv), ptr(sx), ptr(sw), C.byref(make_ep(y, K, out_f32=True)), None) == 0
     ref = conv_ref(E4M3[qx], E4M3[qw], st, pad) * (sx[1] * sw[1])
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+SLOT = 16 * 32          # one amax slot: CLITE_FP8_AMAX_REPLICAS x CLITE_FP8_AMAX_STRIDE words (include/clite.h)
+
+
+def quantize_at(x, scale):
+    """e4m3 codes of clamp(x * scale, +-448), round to nearest even (quantize_ref with the scale given: delayed scaling)."""
+    y = np.clip(x.astype(np.float32) * np.float32(scale), -448, 448).astype(np.float32)
+    pos = E4M3[:127]
+    idx = np.searchsorted(pos, np.abs(y), side="left").clip(1, 126)
+    lo, hi = pos[idx - 1], pos[idx]
+    dl, dh = np.abs(y) - lo, hi - np.abs(y)
+    pick_hi = (dh < dl) | ((dh == dl) & (idx % 2 == 0))
+    code = np.where(pick_hi, idx, idx - 1).astype(np.uint8)
+    code = np.where(np.abs(y) == 0, 0, code).astype(np.uint8)
+    return code | np.where(np.signbit(y), 0x80, 0).astype(np.uint8)
+
+
+@pytest.mark.parametrize("M,Cc,res", [(70, 64, False), (33, 256, True), (19, 16, True)])
+def test_bn_apply_writes_the_e4m3_copy_and_the_amax(M, Cc, res):
+    """The producer-fused quantiser (clite_bn.fp8_out / fp8_scale / fp8_amax): bn_apply's e4m3 copy equals the stand-alone
+    quantiser's codes of the STORED bf16 output at the given (delayed) scale — values beyond the scale's range saturate at +-448 — and fp8_amax
+    receives max |out| of the call (folded into what was there). The bf16 output and the ReLU bits are those of the plain call, bit for bit.
+    Ragged row counts and C = 16 (byte-store form of the bits) included."""
+    L = lib()
+    rng = np.random.default_rng(M + Cc)
+    y = bf16_round(rng.standard_normal((M, Cc)).astype(np.float32) * 2 + 0.5)
+    r = bf16_round(rng.standard_normal((M, Cc)).astype(np.float32))
+    yb, rb = to_bf16(y), to_bf16(r)
+    gamma = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    stats = np.zeros((1, 3, Cc), np.float32)
+    stats[0, 0], stats[0, 1] = y.sum(0), (y * y).sum(0)
+
+    def run(fp8):
+        rm, rv = np.zeros(Cc, np.float32), np.ones(Cc, np.float32)
+        p = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 1, 0.1, 1e-5, 1, 1, 3 * Cc, 0)
+        out = np.zeros((M, Cc), np.uint16)
+        bits = np.zeros((M, Cc // 8), np.uint8)
+        p.relu_bits = ptr(bits)
+        if fp8 is not None:
+            p.fp8_out, p.fp8_scale, p.fp8_amax = ptr(fp8[0]), ptr(fp8[1]), ptr(fp8[2])
+        assert L.clite_bn_apply(C.byref(p), BF16, ptr(yb), ptr(rb) if res else None, ptr(out), None) == 0
+        return out, bits
+
+    out0, bits0 = run(None)
+    a = from_bf16(out0)
+    scale = np.float32(448.0 / (0.6 * np.abs(a).max()))          # a stale scale: the top 40 % of the range saturates
+    q = np.full((M, Cc), 0x55, np.uint8)
+    scales = np.array([scale, 1 / scale], np.float32)
+    amax = np.zeros(SLOT, np.float32)
+    amax[32] = 0.125                                             # (something smaller recorded earlier in the step, by another workgroup)
+    out1, bits1 = run((q, scales, amax))
+    assert np.array_equal(out0, out1) and np.array_equal(bits0, bits1)
+    assert amax.max() == np.abs(a).max() and not amax.reshape(16, 32)[:, 1:].any()
+    ref = quantize_at(a, scale)
+    assert np.array_equal(q & 0x7f, ref & 0x7f) and np.array_equal((q >> 7)[a != 0], (ref >> 7)[a != 0])
+    assert (np.abs(E4M3[q]) == 448.0).any()
+    # amax only (the first step: no scale yet), and a NaN in the input stays visible in the amax
+    amax2 = np.zeros(SLOT, np.float32)
+    run((None, None, amax2))
+    assert amax2.max() == np.abs(a).max()
+    yb.reshape(-1)[5] = 0x7FC0
+    amax3 = np.zeros(SLOT, np.float32)
+    run((None, None, amax3))
+    assert np.isnan(amax3).any()
+    # f32 activations have no fused copy
+    p = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(np.zeros(Cc, np.float32)), ptr(np.ones(Cc, np.float32)), 1, 0, 0.1, 1e-5, 1, 1, 3 * Cc, 0)
+    p.fp8_amax = ptr(amax3)
+    assert L.clite_bn_apply(C.byref(p), F32, ptr(y), None, ptr(np.zeros((M, Cc), np.float32)), None) != 0
+
+
+def test_grouped_weight_quantiser_and_scale_update():
+    """clite_fp8_quantize_group: three tensors of one bf16 arena (one longer than a workgroup's 8192-element chunk, one all zero) get the
+    stand-alone quantiser's codes and scales, untouched bytes between them stay untouched; clite_fp8_scale_update turns recorded amaxes into
+    {448 / amax, amax / 448}, zeroes them, keeps the scales of a slot that recorded nothing and makes a non-finite amax's scales NaN."""
+    L = lib()
+    L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.clite_fp8_quantize_group.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.clite_fp8_scale_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(11)
+    total = 64 + 20000 + 128 + 512 + 64
+    arena = bf16_round((rng.standard_normal(total) * np.exp(rng.standard_normal(total))).astype(np.float32))
+    spans = [(64, 20000), (64 + 20000 + 128, 512), (total - 64, 64)]
+    arena[spans[2][0]:] = 0.0
+    buf = to_bf16(arena)
+    items = np.array([v for o, n in spans for v in (o, n)], np.uint64)
+    table = np.array([(i << 12) | c for i, (o, n) in enumerate(spans) for c in range((n + 8191) // 8192)], np.uint32)
+    q = np.full(total, 0x55, np.uint8)
+    amax, scales = np.full(3, 7.0, np.float32), np.zeros((3, 2), np.float32)
+    partial = np.full(len(table), 0x7F7F7F7F, np.uint32)            # scratch: whatever it held before
+    assert L.clite_fp8_quantize_group(ptr(buf), ptr(items), ptr(table), 3, len(table), ptr(partial), ptr(amax), ptr(scales), ptr(q), None) == 0
+    covered = np.zeros(total, bool)
+    for i, (o, n) in enumerate(spans):
+        x = arena[o:o + n].reshape(-1, 8)
+        q1, s1, a1 = _quant(L, x, BF16)
+        assert np.array_equal(q[o:o + n], q1.reshape(-1)) and np.array_equal(scales[i], s1) and amax[i] == a1[0], i
+        covered[o:o + n] = True
+    assert (q[~covered] == 0x55).all()
+    am = np.zeros((4, SLOT), np.float32)
+    am[0, 0], am[0, 5 * 32] = 1.5, 2.0                             # a slot's value is the maximum of its words
+    am[2, 32], am[3, 15 * 32], am[3, 0] = np.inf, np.nan, 7.0
+    sc = np.tile(np.array([3.0, 5.0], np.float32), (4, 1))
+    assert L.clite_fp8_scale_update(ptr(am), ptr(sc), 4, None) == 0
+    assert np.allclose(sc[0], [224.0, 2.0 / 448.0]) and np.array_equal(sc[1], [3.0, 5.0]) and np.isnan(sc[2]).all() and np.isnan(sc[3]).all()
+    assert not am.view(np.uint32).any()

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--f32", action="store_true")
     ap.add_argument("--loss", default="jsd", choices=["jsd", "infonce"])
+    ap.add_argument("--fp8", action="store_true", help="the image encoder's fp8 forward (clip-lite_amd/fp8.py)")
     ap.add_argument("--back-to-back", action="store_true", help="issue every launch twice and time the second (profiling only: accumulating outputs double)")
     args = ap.parse_args()
     from clip_lite_amd import hip
@@ -29,6 +30,7 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
         model, opt, sched = bench.build(args, device)
+    model.runtime.fp8 = bool(args.fp8)
     model.overlap_encoders = False      # per-launch timing: nothing else may share the chip
     step = TrainStep(model, opt, sched, GradScaler(True), 10.0, None)
     batches = bench.synthetic_batches(args, device, 0)
