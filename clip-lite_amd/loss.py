@@ -144,7 +144,7 @@ def mi_block_forward(rt, blk, x, training, updates=2):
     B, Fin, U = x.shape[0], blk.feature_sz, blk.units
     l1, bn, _, l2 = blk.feature_nonlinear
     z = _alloc(rt, B, U)
-    stats = rt.new_stats(U) if training else None
+    stats = rt.new_stats(U, B) if training else None
     hip.gemm_nt(dt, x, A.w(l1.weight), B, U, Fin, hip.epilogue(z, U, colsum=stats, ws=rt.gemm_ws(B, U)))
     if training and rt.precise_bn:
         hip.bn_centered_var(dt, z, stats, B, U)
@@ -188,7 +188,7 @@ def mi_block_backward(rt, blk, ctx, dout, dx_residual=None):
     hip.colsum(dt, dtt, A.g(l2.bias), B, U)
     da = _alloc(rt, B, U)
     hip.gemm_nn(dt, dtt, A.w(l2.weight), B, U, U, hip.epilogue(da, U, ws=rt.gemm_ws(B, U)))
-    dstats = rt.new_stats(U)
+    dstats = rt.new_stats(U, B)
     hip.bn_bwd_reduce(dt, da, a, z, stats, dstats, B, U)
     dz = _alloc(rt, B, U)
     desc = hip.bn_desc(B, U, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn)

@@ -136,7 +136,7 @@ def _conv(rt, x, N, H, W, conv, training, f8=None, x8=None):
     cv = hip.conv_desc(rt.dt, N, H, W, conv.in_channels, conv.out_channels, conv.k, conv.k, conv.stride, conv.pad)
     M = N * cv.Ho * cv.Wo
     y = _alloc(rt, M, conv.out_channels)
-    stats = rt.new_stats(conv.out_channels) if training else None
+    stats = rt.new_stats(conv.out_channels, M) if training else None
     if f8 is not None and f8.wants(conv, H):
         # OCP e4m3 operands (include/clite.h: clite_conv_fwd_fp8; policy and scaling: fp8.py); y, the statistics and everything backward stay as they are.
         # An input without a producer-written copy (no scale yet on the first step; the pooled stem output) is quantised here, current scaling
@@ -202,7 +202,7 @@ def resnet_forward(rt, net, image, training, staged=None):
     wv = _alloc(rt, 64, 7, 8, 4)
     hip.stem_pack(dt, rt.arena.w32(net.conv1.weight), wv)
     y0 = _alloc(rt, N * Ho * Wo, 64)
-    st0 = rt.new_stats(64) if training else None
+    st0 = rt.new_stats(64, N * Ho * Wo) if training else None
     hip.stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, hip.epilogue(y0, 64, colsum=st0))
     if training and rt.precise_bn:
         hip.bn_centered_var(dt, y0, st0, N * Ho * Wo, 64)
@@ -268,7 +268,7 @@ def resnet_forward(rt, net, image, training, staged=None):
 def _bn_backward(rt, u, dout, mask, N, want_dz=False, train_params=True):
     """BN backward of unit u given dout (gradient w.r.t. the post-BN tensor) and the ReLU mask (packed bits, an activation tensor, or None)."""
     M, Cc = u.y.shape
-    dstats = rt.new_stats(Cc)
+    dstats = rt.new_stats(Cc, M)
     hip.bn_bwd_reduce(rt.dt, dout, mask, u.y, u.stats, dstats, M, Cc)
     dy = _alloc(rt, M, Cc)
     dz = _alloc(rt, M, Cc) if want_dz else None
@@ -364,7 +364,7 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 dy, _ = _bn_backward(rt, prev, dx, prev.bits, N)
             elif i > 0:
                 prev = units[i - 1]
-                dstats = rt.new_stats(Cin)
+                dstats = rt.new_stats(Cin, prev.y.shape[0])
                 mk = lambda: hip.epilogue(dx, Cin, relu_bits=prev.bits, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0]))
                 if rt.s2_classes and hip.s2_classes_ok(u.cv):
                     hip.conv_dgrad_s2(dy, wd, u.cv, mk,       # 3x3 / stride 2: four parity classes, no zero taps
@@ -376,7 +376,7 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 # gradient w.r.t. the block input: main path + shortcut
                 if identity and bi > 0 and rt.fuse_bn_backward:
                     pl = recs[bi - 1][0][-1]          # the previous block's last unit consumes this gradient
-                    pre = rt.new_stats(Cin)
+                    pre = rt.new_stats(Cin, pl.y.shape[0])
                     hip.conv_dgrad(dy, wd, u.cv,
                                    hip.epilogue(dx, Cin, residual=dz, relu_bits=pl.bits, mask_after_residual=True, colsum=pre,
                                                 bn=(pl.y, pl.stats, pl.y.shape[0])), wt=wt)
@@ -404,7 +404,7 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
     xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq = ctx["stem"]
     # max-pool backward + ReLU mask + BatchNorm backward straight from (dpool, idx, y0): neither the un-pooled gradient nor the mask is stored
     bn1 = net.bn1
-    dst0 = rt.new_stats(64)
+    dst0 = rt.new_stats(64, N * Ho * Wo)
     dy0 = _alloc(rt, N * Ho * Wo, 64)
     desc0 = hip.bn_desc(N * Ho * Wo, 64, st0, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, True, False, bn1.momentum, bn1.eps, False,
                         centered=rt.precise_bn)

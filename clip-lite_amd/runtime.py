@@ -321,9 +321,17 @@ class DeviceRuntime:
             return None
         return self.zpool.take(M * N)
 
-    def new_stats(self, Cc):
-        """Zeroed replicated accumulator for per-channel statistics of a [rows][Cc] tensor."""
-        return hip.Stats(self.zpool.take(STAT_REPLICAS * 3 * Cc), STAT_REPLICAS, Cc)
+    def new_stats(self, Cc, rows=None):
+        """Zeroed replicated accumulator for per-channel statistics of a [rows][Cc] tensor. The replicas exist to spread the producers' float
+        atomics (one per workgroup and column: same-address atomics retire at ~90 per microsecond), and every READER pays for them: each
+        workgroup of bn_apply / bn_bwd_apply / the BatchNorm-backward dgrad sums all replicas of its columns in its prologue — thousands of
+        workgroups reading the same few lines: 3.5 us per launch at 8 replicas (bn_apply on 25088 x 256: 10.9 us, 7.6 with one), which is most
+        of what the ~150 small BatchNorm launches of a step cost beyond their bytes. So the count follows the number of producing workgroups.
+        Same-box A/B on the captured step (8 everywhere / 1-2-4-8 by rows / this rule / 1 everywhere): 16.29 / 15.87 / 15.63 / 15.73 ms."""
+        R = STAT_REPLICAS
+        if rows is not None and not hip.is_deterministic():          # (the deterministic mode deals its reduction workgroups one per replica: det.h)
+            R = 1 if rows <= 65536 else 2 if rows <= 262144 else 4
+        return hip.Stats(self.zpool.take(R * 3 * Cc), R, Cc)
 
     # -- weight gradients off the critical path ---------------------------------------------------------------------------
     # In backward only dgrad -> BN backward -> dgrad ... is a dependency chain; every weight-gradient GEMM (conv wgrad, linear
