@@ -284,6 +284,7 @@ class DeviceRuntime:
         import os
         self.s2_classes = True             # 3x3/stride-2 dgrads as four parity-class GEMMs (attribute: tools flip it for A/B runs)
         self.fuse_bn_backward = True       # BatchNorm-backward reductions inside the dgrad epilogues (resnet.py)
+        self.stat_replicas_fixed = False   # True: 8 statistics replicas everywhere (new_stats; tools/ab_runtime.py stat_replicas_fixed=1 for the A/B)
         self.fp8 = False                   # image-encoder forward convs on OCP e4m3 operands, quantised by their producers (BASELINE configs[4]; fp8.py); bf16 mode only
         self.fp8_text = False              # ... and BERT's forward linears (stand-alone quantiser, current scaling: slower than bf16 — kept for the kernel's tests)
         self.fp8_nets = {}                 # id(ResNet) -> fp8.Fp8Forward
@@ -329,7 +330,10 @@ class DeviceRuntime:
         of what the ~150 small BatchNorm launches of a step cost beyond their bytes. So the count follows the number of producing workgroups.
         Same-box A/B on the captured step (8 everywhere / 1-2-4-8 by rows / this rule / 1 everywhere): 16.29 / 15.87 / 15.63 / 15.73 ms."""
         R = STAT_REPLICAS
-        if rows is not None and not hip.is_deterministic():          # (the deterministic mode deals its reduction workgroups one per replica: det.h)
+        # bf16 mode only: the exact-f32 mode's second (centered) variance pass adds its deviations from up to 1024 workgroups per column — there 8
+        # replicas are faster (same-box A/B, bench --f32: 67.0 ms with 8, 70.7 with this rule); the deterministic mode deals one reduction workgroup
+        # per replica (det.h)
+        if rows is not None and self.lowp and not self.stat_replicas_fixed and not hip.is_deterministic():
             R = 1 if rows <= 65536 else 2 if rows <= 262144 else 4
         return hip.Stats(self.zpool.take(R * 3 * Cc), R, Cc)
 
