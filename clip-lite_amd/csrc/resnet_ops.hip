@@ -333,10 +333,14 @@ int bn_grid(int M, int C, int* rows_per_block) {
   int sweeps = (M + RPS - 1) / RPS;
   // 16 row sweeps per workgroup amortise the per-channel coefficient prologue on large tensors; small tensors (layer3/4: a few MB)
   // are latency-bound instead and want every CU busy: down to 4 sweeps per workgroup until there are ~1024 workgroups
-  int spw = sweeps / 1024;
-  spw = spw < 4 ? 4 : (spw > 16 ? 16 : spw);
+#ifndef CLITE_BN_MAXWG
+#define CLITE_BN_MAXWG 1024
+#define CLITE_BN_MINSPW 4
+#endif
+  int spw = sweeps / CLITE_BN_MAXWG;
+  spw = spw < CLITE_BN_MINSPW ? CLITE_BN_MINSPW : (spw > 16 ? 16 : spw);
   int want = (sweeps + spw - 1) / spw;
-  int grid = want < 1 ? 1 : (want > 1024 ? 1024 : want);
+  int grid = want < 1 ? 1 : (want > CLITE_BN_MAXWG ? CLITE_BN_MAXWG : want);
   int spb = (sweeps + grid - 1) / grid;
   *rows_per_block = spb * RPS;
   return (M + *rows_per_block - 1) / *rows_per_block;
