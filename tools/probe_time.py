@@ -18,6 +18,8 @@ dx = torch.empty_like(x)
 cs = hip.Stats(torch.zeros(8 * 3 * K, device="cuda"), 8, K)
 fn = {"conv_fwd": lambda: hip.conv_fwd(x, w, cv, hip.epilogue(y, K, colsum=cs)),
       "conv_dgrad": lambda: hip.conv_dgrad(dy, w, cv, hip.epilogue(dx, Cc))}[kind]
+if os.environ.get("CLITE_TILE_POLICY"):       # 1 / 2 / 3: force the 8-wave 128 x 128 / 256 x 128 / 256 x 256 tile, 4: the 4-wave kernels
+    hip.set_tile_policy(int(os.environ["CLITE_TILE_POLICY"]))
 junk = torch.empty(300 * 1024 * 1024, device="cuda", dtype=torch.uint8)
 ts = []
 for i in range(8):
