@@ -347,7 +347,7 @@ def main():
             # mode's; bf16 storage cannot meet it (neither would the reference's fp16 AMP) and is tested at its own bars
             "precision_note": ("exact-f32 kernels: loss within 1e-4 of the fp32 oracle (tests/test_gpu_model.py, fixtures from the reference)" if args.f32 else
                                "bf16 kernels with f32 accumulation: full-size loss within 2e-2 of the fp32 oracle, conditioned-problem gradient cosine >= 0.93 "
-                               "(tests/test_gpu_model.py, tests/test_gpu_ops.py); the 1e-4 bar is met by `--f32` (profiles/r3_bench_f32.json: 67.5 ms/step)"),
+                               "(tests/test_gpu_model.py, tests/test_gpu_ops.py); the 1e-4 bar is met by `--f32` (profiles/r3_bench_f32.json: 67 ms/step)"),
             "roofline": {"bound": "mfma", "kernel": "clite::igemm_dma_kernel / igemm_wide_kernel family (all conv/linear fwd+dgrad+wgrad launches of one step)",
                          "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": (gemm_tflops / MFMA_PEAK_TFLOPS) if gemm_tflops else None, "traffic": traffic,
