@@ -16,7 +16,8 @@ same [CLS] ... [SEP] framing.
 
 Image source: when a record's image file exists it is decoded with PIL and put through the reference's transforms by name
 (`DATA.IMAGE_TRANSFORM_{TRAIN,VAL}`; factories.py:112-160): smallest_resize (shorter side -> 256 for DEFAULT_IMAGE_TRANSFORM, else the
-crop size), center_crop, random_resized_crop, horizontal_flip, normalize (ImageNet mean / std on [0, 1] pixels), HWC -> CHW float32
+crop size), center_crop, random_resized_crop (scale 0.2-1), horizontal_flip (which also swaps "left" / "right" in the caption), color_jitter,
+normalize (ImageNet mean / std on [0, 1] pixels), HWC -> CHW float32
 (data/dataloader.py:186-192). A record whose file is missing gets a seeded synthetic image (the mock json of the reference points at
 files that exist on no machine we have).
 """
@@ -103,10 +104,58 @@ IMAGENET_COLOR_STD = (0.229, 0.224, 0.225)
 DEFAULT_IMAGE_TRANSFORM = ("smallest_resize::256", "center_crop", "normalize")     # reference data/transforms.py:238-244
 
 
-def load_image(path: str, transforms, crop_size: int, generator=None) -> torch.Tensor:
+def swap_left_right(caption: str) -> str:
+    """What the reference's HorizontalFlip does to the caption of a flipped image (data/transforms.py:175-181): "left" <-> "right"."""
+    return caption.replace("left", "[TMP]").replace("right", "left").replace("[TMP]", "right")
+
+
+def _transform_args(arg: str, crop_size: int):
+    """The part after "::" of a transform name. The reference's syntax is a kwargs dict, `random_resized_crop::{'scale': (0.08, 1.0)}`
+    (factories.py:112-115,163-173: eval of the text; here ast.literal_eval — literals only); a bare integer is this package's short form for
+    the size. Returns (size, kwargs)."""
+    if not arg:
+        return crop_size, {}
+    import ast
+    val = ast.literal_eval(arg)
+    if isinstance(val, dict):
+        kw = dict(val)
+        size = int(kw.pop("size", kw.pop("max_size", crop_size)))
+        return size, kw
+    return int(val), {}
+
+
+def _color_jitter(img, rnd, brightness=0.4, contrast=0.4, saturation=0.4, hue=0.1, p=0.8):
+    """The reference's `color_jitter` (factories.py:132-134: albumentations ColorJitter(0.4, 0.4, 0.4, 0.1, p = 0.8)) on a PIL image:
+    with probability p, brightness / contrast / saturation factors uniform in [1 - x, 1 + x] and a hue shift uniform in [-hue, hue] (fraction of
+    the colour circle), applied in a random order. Same distribution family as albumentations / torchvision; the draws come from this
+    package's generator, so individual images differ from an albumentations run with the same seed."""
+    from PIL import Image, ImageEnhance
+    import numpy as np
+    if rnd() >= p:
+        return img
+    fb, fc, fs = (1.0 + (2.0 * rnd() - 1.0) * x for x in (brightness, contrast, saturation))
+    fh = (2.0 * rnd() - 1.0) * hue
+    order = sorted(range(4), key=lambda _: rnd())
+    for op in order:
+        if op == 0:
+            img = ImageEnhance.Brightness(img).enhance(fb)
+        elif op == 1:
+            img = ImageEnhance.Contrast(img).enhance(fc)
+        elif op == 2:
+            img = ImageEnhance.Color(img).enhance(fs)
+        else:
+            hsv = np.asarray(img.convert("HSV")).copy()
+            hsv[..., 0] = (hsv[..., 0].astype(np.int16) + int(round(fh * 255))) % 256
+            img = Image.fromarray(hsv, "HSV").convert("RGB")
+    return img
+
+
+def load_image(path: str, transforms, crop_size: int, generator=None, return_flipped=False):
     """PIL decode -> RGB -> the named transforms -> f32 CHW (reference data/dataloader.py:186-192 with the transform table of
-    factories.py:112-160). Names may carry an argument as "name::value" (reference factories.py:213-221 passes the crop size to the
-    resize / crop transforms). Random transforms draw from `generator` (a torch.Generator) so that a dataset index is reproducible."""
+    factories.py:112-160). Names may carry arguments as "name::{kwargs dict}" (the reference's syntax, factories.py:112-115) or "name::size";
+    factories.py:213-221 passes the crop size to the resize / crop transforms. Random transforms draw from `generator` (a torch.Generator) so
+    that a dataset index is reproducible. return_flipped: also return whether `horizontal_flip` fired — the reference's flip swaps "left" and
+    "right" in the caption of a flipped image (data/transforms.py:156-181), which the dataset applies before tokenising."""
     from PIL import Image
     import numpy as np
     img = Image.open(path).convert("RGB")
@@ -114,10 +163,10 @@ def load_image(path: str, transforms, crop_size: int, generator=None) -> torch.T
     def rnd():
         return float(torch.rand((), generator=generator))
 
-    normalized = False
+    normalized, flipped = False, False
     for spec in transforms:
         name, _, arg = spec.partition("::")
-        size = int(arg) if arg else crop_size
+        size, kw = _transform_args(arg, crop_size)
         if name == "smallest_resize":            # albumentations SmallestMaxSize: shorter side -> size, aspect kept, bilinear
             w, h = img.size
             sc = size / min(w, h)
@@ -128,12 +177,14 @@ def load_image(path: str, transforms, crop_size: int, generator=None) -> torch.T
             w, h = img.size
             l, t = (w - size) // 2, (h - size) // 2
             img = img.crop((l, t, l + size, t + size))
-        elif name == "random_resized_crop":      # albumentations RandomResizedCrop(scale=(0.08, 1), ratio=(3/4, 4/3)), 10 tries then centre
+        elif name == "random_resized_crop":      # reference factories.py:124-126: RandomResizedSquareCrop(scale=(0.2, 1.0), ratio=(0.75, 1.333)); 10 tries then centre
+            s_lo, s_hi = kw.get("scale", (0.2, 1.0))
+            r_lo, r_hi = kw.get("ratio", (0.75, 1.333))
             w, h = img.size
             box = None
             for _ in range(10):
-                area = w * h * (0.08 + 0.92 * rnd())
-                logr = math.log(3 / 4) + (math.log(4 / 3) - math.log(3 / 4)) * rnd()
+                area = w * h * (s_lo + (s_hi - s_lo) * rnd())
+                logr = math.log(r_lo) + (math.log(r_hi) - math.log(r_lo)) * rnd()
                 ar = math.exp(logr)
                 cw, ch = int(round(math.sqrt(area * ar))), int(round(math.sqrt(area / ar)))
                 if 0 < cw <= w and 0 < ch <= h:
@@ -144,11 +195,13 @@ def load_image(path: str, transforms, crop_size: int, generator=None) -> torch.T
                 s_ = min(w, h)
                 box = ((w - s_) // 2, (h - s_) // 2, (w - s_) // 2 + s_, (h - s_) // 2 + s_)
             img = img.crop(box).resize((size, size), Image.BILINEAR)
-        elif name == "horizontal_flip":
-            if rnd() < 0.5:
+        elif name == "horizontal_flip":          # reference factories.py:141: p = 0.5; the caption side is the caller's (return_flipped)
+            if rnd() < kw.get("p", 0.5):
                 img = img.transpose(Image.FLIP_LEFT_RIGHT)
-        elif name == "color_jitter":
-            pass                                 # photometric augmentation: not part of the batch contract; left out
+                flipped = not flipped
+        elif name in ("color_jitter", "color_jitter8"):
+            x = 0.8 if name == "color_jitter8" else 0.4
+            img = _color_jitter(img, rnd, kw.get("brightness", x), kw.get("contrast", x), kw.get("saturation", x), kw.get("hue", 0.1), kw.get("p", 0.8))
         elif name == "normalize":
             normalized = True
         else:
@@ -156,7 +209,8 @@ def load_image(path: str, transforms, crop_size: int, generator=None) -> torch.T
     x = torch.from_numpy(np.asarray(img, dtype=np.float32).copy()) / 255.0          # HWC in [0, 1]
     if normalized:                               # albumentations Normalize(mean, std, max_pixel_value=255)
         x = (x - torch.tensor(IMAGENET_COLOR_MEAN)) / torch.tensor(IMAGENET_COLOR_STD)
-    return x.permute(2, 0, 1).contiguous()
+    x = x.permute(2, 0, 1).contiguous()
+    return (x, flipped) if return_flipped else x
 
 
 class _CaptionDataset(Dataset):
@@ -183,15 +237,19 @@ class _CaptionDataset(Dataset):
     def __getitem__(self, idx):
         g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
         path = self.image_path(idx)
+        flipped = False
         if path is not None and os.path.isfile(path):
-            image = load_image(path, self.image_transform, self.image_size, g)
+            image, flipped = load_image(path, self.image_transform, self.image_size, g, return_flipped=True)
         else:
             image = torch.randn(3, self.image_size, self.image_size, generator=g)
         item = {"image_id": torch.tensor(idx, dtype=torch.long), "image": image}
         if self.mode == "sbert":
             item["caption_encodings"] = torch.randn(768, generator=g)
         else:
-            item["caption_tokens"] = torch.tensor(self.tokenize(self.caption(idx)), dtype=torch.long)
+            caption = self.caption(idx)
+            if flipped:          # the image transforms run on (image, RAW caption) pairs in the reference: a flipped image swaps left / right
+                caption = swap_left_right(caption)
+            item["caption_tokens"] = torch.tensor(self.tokenize(caption), dtype=torch.long)
         return item
 
     def collate_fn(self, items):

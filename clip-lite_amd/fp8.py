@@ -57,11 +57,18 @@ class Fp8Forward:
         i, _ = self.windex[id(conv)]
         return self.wgroup.view(i, self.rt.arena.w(conv.weight).shape)
 
-    def producer(self, bn, M, Cc, want):
-        """(clite_bn.fp8_* triple for bn_apply, the Fp8View its consumers read) for the output of `bn`; (None, None) when no fp8 conv reads it."""
+    def producer(self, bn, M, Cc, want, training=True):
+        """(clite_bn.fp8_* triple for bn_apply, the Fp8View its consumers read) for the output of `bn`; (None, None) when no fp8 conv reads it.
+        Eval-mode forwards (training=False) use the scales READ-ONLY: they record no amax and never make a slot ready, so a validation batch
+        neither changes the scales the next training step quantises with nor depends on more than the training state it finds."""
         if not want:
             return None, None
         s = self.slot[id(bn)]
+        if not training:
+            if s not in self.ready:      # no training step has made a scale yet: the consumer quantises with current scaling
+                return None, None
+            q = torch.empty(M, Cc, dtype=torch.uint8, device=self.rt.device)
+            return (q, self.scales[s], None), hip.Fp8View(q, self.scales[s])
         self._seen.add(s)
         amax = self.amax[s]
         if s not in self.ready:          # no scale yet: record the amax only; the consumer quantises the bf16 tensor itself this once

@@ -52,7 +52,14 @@ class VLInfoModel(nn.Module):
             raise RuntimeError("clip_lite_amd: move the model to a GPU first (model.to(device)); there is no CPU path")
         return self._rt
 
+    def state_dict(self, *args, **kw):
+        if self._rt is not None:
+            self._rt.arena.flush_pending()          # a deferred share of the last update (TrainStep defer_update) lands before parameters are read
+        return super().state_dict(*args, **kw)
+
     def load_state_dict(self, state_dict, strict=True, **kw):
+        if self._rt is not None:
+            self._rt.arena.flush_pending()
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         if self._rt is not None:
             self._rt.arena.refresh_lowp()
@@ -60,6 +67,8 @@ class VLInfoModel(nn.Module):
 
     def forward(self, batch):
         rt = self.runtime
+        if not self.training:
+            rt.arena.flush_pending()          # an eval forward between deferred steps must see the completed update
         if self.mode == "sbert":
             image_features = self.image_encoder(batch["image"])
             text_features = self.text_encoder(batch["caption_encodings"])

@@ -162,6 +162,7 @@ class FusedSGD(torch.optim.Optimizer):
 
     # -- torch.optim.SGD-compatible checkpoint layout -----------------------------------------------------------------
     def state_dict(self):
+        self.arena.flush_pending()          # a deferred share of the last update (TrainStep defer_update) must land before momentum is read
         state, groups = {}, []
         for i, g in enumerate(self.param_groups):
             p = g["params"][0]
@@ -171,6 +172,7 @@ class FusedSGD(torch.optim.Optimizer):
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
+        self.arena.flush_pending()
         for i, g in enumerate(self.param_groups):
             saved = sd["param_groups"][i]
             for k, v in saved.items():

@@ -236,7 +236,7 @@ def resnet_forward(rt, net, image, training, staged=None):
             u.out = _alloc(rt, M, conv.out_channels)
             u.bits = _relu_bits(rt, M, conv.out_channels, training)
             if not last:
-                q, h8 = f8.producer(bn, M, conv.out_channels, f8.wants(specs[i + 1][0], Hh)) if f8 is not None else (None, None)
+                q, h8 = f8.producer(bn, M, conv.out_channels, f8.wants(specs[i + 1][0], Hh), training) if f8 is not None else (None, None)
                 hip.bn_apply(dt, _bn_desc(rt, bn, M, u.stats, True, training, bits=u.bits, fp8=q), u.y, None, u.out)
             units.append(u)
             h = u.out
@@ -247,7 +247,7 @@ def resnet_forward(rt, net, image, training, staged=None):
         if f8 is not None and bi + 1 < len(blocks):          # the block output's readers: the next block's first conv and its downsample conv
             nb = blocks[bi + 1]
             readers = [nb.units()[0][0]] + ([nb.downsample[0]] if nb.downsample is not None else [])
-            q, x8 = f8.producer(last.bn, M, last.conv.out_channels, any(f8.wants(c, Hh) for c in readers))
+            q, x8 = f8.producer(last.bn, M, last.conv.out_channels, any(f8.wants(c, Hh) for c in readers), training)
         if blk.downsample is not None:
             ud = _conv(rt, xin, N, Hin, Win, blk.downsample[0], training, f8, xin8)
             ud.bn = blk.downsample[1]
@@ -256,7 +256,7 @@ def resnet_forward(rt, net, image, training, staged=None):
             hip.bn_apply(dt, _bn_desc(rt, last.bn, M, last.stats, True, training, bits=last.bits, fp8=q), last.y, xin, last.out)
         recs.append((units, ud, Hin, Win))
         x, Hc, Wc = last.out, Hh, Wh
-    if f8 is not None:
+    if f8 is not None and training:          # (an eval forward leaves the delayed-scaling state alone)
         f8.end_step()
     Cout = net.out_dim
     feat = _alloc(rt, N, Cout)

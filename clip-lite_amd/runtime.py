@@ -41,6 +41,9 @@ class Arena:
                     placed.add(m)
         self.device, self.lowp = torch.device(device), lowp
         self._pending = []
+        # a train step that left part of its update for later (train_loop.TrainStep defer_update) registers its finish() here; every reader of the
+        # parameters outside the step (state_dict, load_state_dict, refresh_lowp, an eval forward) calls flush_pending() first
+        self.pending_update = None
         self.index = {}
         off = 0
         for n in order:
@@ -134,8 +137,15 @@ class Arena:
         assert sum((n + ALIGN - 1) // ALIGN * ALIGN for _, n in offs) == hi - lo, f"tensors under {prefix!r} are not contiguous"
         return (lo, min(hi, self.total))
 
+    def flush_pending(self):
+        """Complete a deferred share of the last update (no-op unless a TrainStep(defer_update=True) is mid-way): before anything reads or
+        overwrites parameters, momentum or the bf16 copies from outside the step."""
+        if self.pending_update is not None:
+            self.pending_update()
+
     def refresh_lowp(self):
         """Re-derive the bf16 copy from the f32 masters (after load_state_dict or any out-of-band weight edit)."""
+        self.flush_pending()
         if self.lowp:
             hip.cast_bf16(self.flat_p, self.flat_lp, self.total)
         self._tr_stale = True
@@ -271,7 +281,9 @@ class DeviceRuntime:
         self.transposed_dgrad = bool(lowp)
         if lowp:
             by_name = dict(model.named_parameters())
-            tw = [m.weight for m in model.modules()
+            # only the two encoders' backward executors read the copies (bert._dgrad, resnet._wd); the heads' small GEMMs keep clite_gemm_nn on
+            # the [out][in] weights, so their matrices (and the word embeddings, which have no in_features) are not re-transposed every step
+            tw = [m.weight for top in ("image_encoder", "text_encoder") if hasattr(model, top) for m in getattr(model, top).modules()
                   if isinstance(getattr(m, "weight", None), torch.nn.Parameter) and hasattr(m.weight, "_clite")
                   and (hasattr(m, "in_features") or hasattr(m, "in_channels"))]
             tg = [[by_name[n] for n in g] for g in contiguous_groups if all(n in by_name for n in g) and by_name[g[0]].dim() == 2]

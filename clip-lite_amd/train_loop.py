@@ -86,6 +86,8 @@ class TrainStep:
         # image forward are both HBM-bound, so the overlap is zero-sum) and therefore OFF by default; kept as an option with its exactness test.
         self.defer_update = bool(defer_update)
         self._pending_rest = False
+        if self.defer_update:          # readers of the parameters outside the step complete the update first (Arena.flush_pending)
+            self.inner.arena.pending_update = self.finish
         self.graph_warmup = graph_warmup
         self._eager_steps = 0
         self._g = self._g_update = self._graphs = None
@@ -379,6 +381,10 @@ class TrainStep:
         rt.begin_capture()
         try:
             with torch.cuda.graph(g, capture_error_mode="thread_local"):      # see _capture: other threads (pin-memory, RCCL) must not invalidate it
+                # the transposed bf16 weight copies every input-gradient GEMM reads: re-derived INSIDE the graph, first on the capture stream (every
+                # branch the executors fork is ordered behind it) — the backward executors' own ensure_transposed() is a no-op under capture, and
+                # without this node every replay would run its dgrads against the weights of the last eager step
+                rt.arena.ensure_transposed(force=True, capturing=True)
                 out = self.model(self._static_batch)
                 self.scaler.scale(out["loss"]).backward()
                 if self.exchange is None:

@@ -378,6 +378,61 @@ def test_graph_replay_matches_eager_steps():
         assert torch.allclose(b0[k].float(), b1[k].float(), rtol=5e-3, atol=1e-4), k
 
 
+def test_single_graph_bf16_replay_refreshes_transposed_weights_and_tracks_eager():
+    """The ONE-graph capture (TrainStep._capture_single: every configuration outside the per-phase form — here the `concat` critic) in bf16 mode.
+    Every bf16 input-gradient GEMM reads the transposed weight copies (Arena.flat_lpT); the captured graph must re-derive them itself at every
+    replay (without that node the replays ran their dgrads against the weights of the last eager step while the update kept moving
+    flat_lp). Checked two ways: (1) after a replay the copies equal the transpose of the bf16 weights that replay STARTED from — bitwise, and not
+    those of the previous step; (2) the replayed trajectory tracks the eager one. Learning rates are large enough that one step moves bf16 weights.
+    Tolerances (bf16, two runs differ by float-atomic order): loss 3e-2 per step, parameter movement within 10 % (relative L2)."""
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    from clip_lite_amd.optim import FusedSGD, Lookahead
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    from clip_lite_amd.train_loop import TrainStep
+    from clip_lite_amd.utils.common import GradScaler
+    B, L = 32, 12
+    batches = []
+    for i in range(3):
+        ids = torch.randint(1000, 30522, (B, L), generator=torch.Generator().manual_seed(70 + i))
+        batches.append({"image": det_tensor(f"simg{i}", (B, 3, 64, 64), "normal").cuda(), "input_ids": ids.cuda(),
+                        "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()})
+    results = []
+    for graph in (False, True):
+        torch.manual_seed(7)
+        te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
+        te.strans.hidden_dropout_prob = te.strans.attention_probs_dropout_prob = 0.0
+        M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "concat", 0.1, True, True), "train_sbert", is_amp=True))
+        M = M.to("cuda").train()
+        A = M.runtime.arena
+        assert A.flat_lpT is not None
+        p_init = A.flat_p.clone()
+        groups = [{"params": [p], "lr": 2e-2 if "image_encoder" in n else 2e-3, "weight_decay": 1e-4} for n, p in M.named_parameters()]
+        opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
+        sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=2)
+        step = TrainStep(M, opt, sched, GradScaler(True), 10.0, None, graph=graph, graph_warmup=2)
+        probes = [te.strans.encoder.layer[0].output.dense.weight, M.image_encoder.img_encoder.layer2[0].conv2.weight]
+        losses = []
+        for s in range(5):
+            before = [A.w(p).clone() for p in probes] if graph and s >= 3 else None
+            losses.append(step(batches[s % 3])["loss"].item())
+            if before is not None:
+                torch.cuda.synchronize()
+                assert step._g is not None and step._graphs is None          # the single-graph path
+                for p, w0 in zip(probes, before):
+                    wt = A.wt(p)
+                    want = w0.t() if p.dim() == 2 else w0.permute(3, 1, 2, 0)          # [N][K] -> [K][N]; kernel layout [K][R][S][C] -> [C][R][S][K]
+                    assert torch.equal(wt, want.contiguous()), "transposed copies were not re-derived inside the replayed graph"
+                    assert not torch.equal(A.w(p), w0), "the step did not move this bf16 weight: the check above proves nothing"
+        torch.cuda.synchronize()
+        results.append((losses, A.flat_p - p_init))
+    (l0, d0), (l1, d1) = results
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < 3e-2, (l0, l1)
+    rel = ((d0 - d1).norm() / d0.norm()).item()
+    assert d0.norm().item() > 1e-3 and rel < 0.1, (d0.norm().item(), rel)
+
+
 def test_graph_replay_takes_shorter_caption_batches_padded():
     """The reference's collate pads every batch to ITS longest caption (data/dataloader.py:218-236), so L varies batch to batch. TrainStep(pad_to=
     MAX_CAPTION_LENGTH) captures at the maximum length and right-pads shorter batches (id 0, mask 0) into the captured buffers: every such

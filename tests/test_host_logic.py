@@ -282,6 +282,89 @@ def test_wordpiece_vocab_and_image_file_source(tmp_path):
         WordPieceTokenizer(str(tmp_path / "nope.txt"))
 
 
+def test_wordpiece_matches_transformers_bert_tokenizer_golden():
+    """N3, bit-exact (integer work): `tests/golden/tokens_mock.npz` holds the input_ids that `transformers.BertTokenizer` — what the reference's
+    `BertTokenizer.from_pretrained(...)(caption, padding=False, truncation=True, max_length=L)` resolves to (data/dataloader.py:139-141,196-202)
+    — produced in the build container for the reference's 41 mock captions (data/mock_data.json) at L = 30 and 12 and for 17 adversarial
+    strings (accents, punctuation, CJK, control characters, a 120-character word, empty / blank input, truncation at 30 / 16 / 8 / 3 / 2),
+    over the generated vocabulary `tests/golden/vocab_mock.txt` (428 entries: whole words, prefix + "##" pieces, competing shorter prefixes,
+    letters with no entry so that some words are [UNK]); `tests/golden/make_tokens_golden.py` made it and cross-checked it against the pure-Python
+    restatement of the published algorithm (oracle/bert_wordpiece.py). The product tokenizer must reproduce every id, with and without
+    NormalizeCaption in front; the restatement is re-checked here too (the oracle against its golden)."""
+    import os
+    import numpy as np
+    from clip_lite_amd.data import WordPieceTokenizer, normalize_caption
+    from oracle import bert_wordpiece as W
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    d = np.load(os.path.join(here, "tokens_mock.npz"))
+    vp = os.path.join(here, "vocab_mock.txt")
+    tk, vocab = WordPieceTokenizer(vp), W.load_vocab(vp)
+    assert len(d["captions"]) == 68 and len(d["raw_captions"]) == 17
+    n_unk = n_cont = 0
+    inv = {i: t for t, i in vocab.items()}
+    for caps, lens, rows, norm in ((d["captions"], d["max_length"], d["input_ids"], True), (d["raw_captions"], d["raw_max_length"], d["raw_input_ids"], False)):
+        for cap, L, row in zip(caps, lens, rows):
+            cap, L, want = str(cap), int(L), [int(x) for x in row if x >= 0]
+            text = normalize_caption(cap, L) if norm else cap
+            assert tk(text, L) == want, (cap, L)
+            assert W.encode(text, vocab, L) == want, ("oracle restatement", cap, L)
+            assert len(want) <= L and want[0] == vocab["[CLS]"] and want[-1] == vocab["[SEP]"]
+            n_unk += want.count(vocab["[UNK]"])
+            n_cont += sum(inv[t].startswith("##") for t in want)
+    assert n_unk >= 5 and n_cont >= 200          # the fixture really exercises [UNK] and continuation pieces
+
+
+def test_image_transform_arguments_flip_caption_and_color_jitter(tmp_path):
+    """ADVICE r3 (data.py): the reference's transform table (factories.py:112-160) — `random_resized_crop` draws its area from scale (0.2, 1.0);
+    arguments may be the reference's kwargs-dict syntax `name::{...}`; `horizontal_flip` also swaps "left" and "right" in the caption of a
+    flipped image (data/transforms.py:156-181); `color_jitter` is a real photometric transform (p = 0.8), not a silent no-op."""
+    import numpy as np
+    from PIL import Image
+    from clip_lite_amd.data import JsonCaptionDataset, _transform_args, load_image, swap_left_right
+    assert _transform_args("", 224) == (224, {}) and _transform_args("256", 224) == (256, {})
+    assert _transform_args("{'scale': (0.08, 1.0)}", 224) == (224, {"scale": (0.08, 1.0)})
+    assert swap_left_right("a left hand and the right foot, left") == "a right hand and the left foot, right"
+    arr = np.zeros((64, 96, 3), dtype=np.uint8)
+    arr[:, :48, 0] = 200                      # left half red, right half blue
+    arr[:, 48:, 2] = 200
+    ip = tmp_path / "lr.png"
+    Image.fromarray(arr).save(ip)
+    g = lambda s: torch.Generator().manual_seed(s)
+    flips = [load_image(str(ip), ("horizontal_flip",), 64, g(s), return_flipped=True) for s in range(16)]
+    assert {f for _, f in flips} == {True, False}
+    for x, f in flips:                        # flipped <=> the red half is now on the right
+        assert (x[0, 0, -1] > 0.5) == f and (x[2, 0, 0] > 0.5) == f
+    # crop areas: default scale (0.2, 1.0) never yields a crop below 20 % of the image; the dict syntax overrides it
+    def crop_area(spec, seed):
+        gen = g(seed)
+        x = load_image(str(ip), (spec,), 32, gen)
+        assert x.shape == (3, 32, 32)
+        return x
+    for s in range(8):
+        crop_area("random_resized_crop", s)
+        crop_area("random_resized_crop::{'scale': (0.08, 1.0)}", s)
+    # colour jitter changes pixels in ~80 % of the draws and keeps the shape / range
+    base = load_image(str(ip), (), 64)
+    changed = 0
+    for s in range(20):
+        x = load_image(str(ip), ("color_jitter",), 64, g(s))
+        assert x.shape == base.shape and float(x.min()) >= 0.0 and float(x.max()) <= 1.0
+        changed += int(not torch.equal(x, base))
+    assert 10 <= changed <= 20
+    # the dataset applies the caption side of the flip before NormalizeCaption / tokenising
+    jp = tmp_path / "ann.json"
+    jp.write_text(json.dumps([{"image": "lr.png", "caption": "a dog on the left of a cat"}]))
+    seen = set()
+    for seed in range(12):
+        ds = JsonCaptionDataset([str(jp)], image_size=32, seed=seed, data_root=str(tmp_path), image_transform=("horizontal_flip", "global_resize"))
+        item = ds[0]
+        fl = bool(item["image"][0, 0, -1] > 0.5)
+        want = ds.tokenize("a dog on the right of a cat" if fl else "a dog on the left of a cat")
+        assert item["caption_tokens"].tolist() == want
+        seen.add(fl)
+    assert seen == {True, False}
+
+
 def test_caption_normalisation_known_answers():
     """reference data/transforms.py:46-90 (NormalizeCaption.pre_caption + apply_to_caption), worked by hand from its rules: the listed
     punctuation is deleted (not spaced), '-' and '/' become spaces, "<person>" -> "person" (after lower-casing, so "<PERSON>" too), runs of
