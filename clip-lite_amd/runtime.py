@@ -23,7 +23,11 @@ def _kernel_shape(p):
 
 
 class Arena:
-    def __init__(self, named_params, device, lowp, contiguous_groups=()):
+    @staticmethod
+    def layout(named_params, contiguous_groups=()):
+        """(order, index, total) of the flat buffers for these (name, tensor) pairs: named_parameters() order with every contiguous group pulled
+        together at its first member, every tensor padded to ALIGN elements. Needs shapes only (meta tensors do): the data-parallel pre-flight
+        test lays out the real ResNet-50 + BERT arena this way without allocating it."""
         named = list(named_params)
         by_name = dict(named)
         order, placed = [], set()
@@ -39,17 +43,22 @@ class Arena:
                 if m not in placed:
                     order.append(m)
                     placed.add(m)
+        index, off = {}, 0
+        for n in order:
+            numel = by_name[n].numel()
+            index[n] = (off, numel)
+            off += (numel + ALIGN - 1) // ALIGN * ALIGN
+        return order, index, off
+
+    def __init__(self, named_params, device, lowp, contiguous_groups=()):
+        named = list(named_params)
+        by_name = dict(named)
+        order, self.index, off = self.layout(named, contiguous_groups)
         self.device, self.lowp = torch.device(device), lowp
         self._pending = []
         # a train step that left part of its update for later (train_loop.TrainStep defer_update) registers its finish() here; every reader of the
         # parameters outside the step (state_dict, load_state_dict, refresh_lowp, an eval forward) calls flush_pending() first
         self.pending_update = None
-        self.index = {}
-        off = 0
-        for n in order:
-            numel = by_name[n].numel()
-            self.index[n] = (off, numel)
-            off += (numel + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
         self.flat_p = torch.zeros(off, device=device, dtype=torch.float32)
         self.flat_g = torch.zeros(off, device=device, dtype=torch.float32)

@@ -220,3 +220,77 @@ def test_two_rank_train_steps_match_shardwise_oracle(tmp_path):
         opt.step()
     for n, p in net.named_parameters():
         assert torch.allclose(got[n], p.detach(), rtol=1e-5, atol=1e-6), (n, (got[n] - p).abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Pre-flight of the driver's 8-GPU run: world 8 over gloo, both exchange forms, on the REAL gradient regions of
+# ResNet-50 + BERT-base + heads — the spans train_loop.TrainStep hands to GradientExchange.reduce_span in the captured step (heads, text
+# encoder, image chain segments [layer4, layer3] / [layer2] / [layer1, stem]); the text encoder's 109.5 M elements do not divide by 8 x 64, so
+# the mesh form runs with uneven splits and a padded gather. Gradients are small multiples of 1/8, so every summation order gives
+# the same bits: the result must EQUAL the analytic sum on every rank, for both forms.
+def _real_regions():
+    sys.path.insert(0, ROOT)
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    from clip_lite_amd.runtime import Arena
+    import contextlib
+    import io
+    with torch.device("meta"), contextlib.redirect_stdout(io.StringIO()):
+        M = VLInfoModel(TextEncoder(mode="train_sbert", num_hidden_layers=12), ImageEncoder("resnet50"), JSDInfoMaxLoss(2048, 768, "dot", 0.1, True, True),
+                        "train_sbert", True)
+    order, index, total = Arena.layout(M.named_parameters(), M.text_encoder.strans.contiguous_groups("text_encoder.strans."))
+    A = Arena.__new__(Arena)
+    A.names, A.index, A.total, A._pending = order, index, total, []
+    pre = "image_encoder.img_encoder."
+    img, l2, l3 = A.region("image_encoder."), A.region(pre + "layer2."), A.region(pre + "layer3.")
+    spans = [A.region("loss."), A.region("text_encoder."), (l3[0], img[1]), (l2[0], l3[0]), (img[0], l2[0])]      # the captured step's hand-over order
+    return A, spans
+
+
+def _fill(flat, rank, world=None):
+    """flat[i] = a[i] + rank * b[i] with a = ((7 i) mod 257 - 128) / 8 and b = (i mod 5 - 2) / 4, in slabs (no 1.2 GB index tensor); with `world`
+    given, the sum over ranks instead: world * a + world (world - 1) / 2 * b. Every value is a small multiple of 1/8: sums are exact in f32."""
+    step = 1 << 24
+    ca, cb = (1.0, float(rank)) if world is None else (float(world), world * (world - 1) / 2.0)
+    for s in range(0, flat.numel(), step):
+        e = min(flat.numel(), s + step)
+        idx = torch.arange(s, e, dtype=torch.int64)
+        a = (((idx * 7) % 257) - 128).to(torch.float32) / 8
+        b = ((idx % 5) - 2).to(torch.float32) / 4
+        flat[s:e] = ca * a + cb * b
+
+
+def _world8_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    from clip_lite_amd.utils import distributed as D
+    A, spans = _real_regions()
+    assert A.total == 156157056 and sum(hi - lo for lo, hi in spans) == A.total          # the five spans tile the whole arena
+    assert any((hi - lo) % (world * 64) for lo, hi in spans), "no uneven mesh split in this layout: the test would not cover the padded gather"
+    A.flat_g = torch.empty(A.total, dtype=torch.float32)
+    want = torch.empty(A.total, dtype=torch.float32)
+    _fill(want, 0, world)
+    # the mesh form — this package's own chunking, uneven splits and padded gather — on all five spans at full size; the all-reduce form (one
+    # library call per span, nothing of ours to size) on the two image segments that are cheap over gloo's loopback TCP (the CPU suite's time
+    # budget: the full-size all-reduce of 625 MB across 8 gloo processes alone takes ~90 s here)
+    for algorithm, which in (("mesh", spans), ("allreduce", spans[3:])):
+        ex = D.GradientExchange(A, algorithm=algorithm)
+        assert ex.world == world and ex.rank == rank
+        _fill(A.flat_g, rank)
+        for lo, hi in which:
+            ex.reduce_span(lo, hi)
+        ex.wait()
+        for lo, hi in which:
+            assert torch.equal(A.flat_g[lo:hi], want[lo:hi]), (algorithm, lo, hi, (A.flat_g[lo:hi] - want[lo:hi]).abs().max().item())
+    tdist.barrier()
+    tdist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_world8_both_exchange_forms_on_the_real_resnet50_bert_regions_gloo(tmp_path):
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_world8_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(8))
