@@ -49,11 +49,40 @@ bool is_plain(const clite_epilogue& ep) {
   return !ep.atomic && !ep.out_f32 && !ep.preact && ep.act == CLITE_ACT_NONE && !ep.dact_aux && ep.drop_p <= 0.f && !ep.residual && !ep.bn_y && !ep.mask_after_residual;
 }
 
+// The compile-time epilogue forms of BERT's linears (igemm_wide.h: WideEpiForm 3 - 6), recognised from the run-time description; 0 = none of them.
+int bert_form(const clite_epilogue& ep) {
+#ifdef CLITE_NO_BERT_FORMS          // A/B builds only (make variant VAR_EXTRA=-DCLITE_NO_BERT_FORMS): everything through the run-time-flag form
+  return 0;
+#endif
+  if (ep.atomic || ep.out_f32 || ep.bn_y || ep.mask_after_residual || ep.relu_bits || ep.splitk_ws) return 0;
+  const bool drop = ep.drop_p > 0.f, aux = ep.dact_aux != nullptr;
+  if (ep.bias && ep.preact && ep.act == CLITE_ACT_GELU && !aux && !drop && !ep.residual && !ep.colsum) return 3;
+  if (!ep.bias && !ep.preact && ep.act == CLITE_ACT_NONE && aux && ep.dact == 2 && !drop && !ep.residual && (!ep.colsum || ep.colsum_rows == 1)) return 4;
+  if (ep.bias && !ep.preact && ep.act == CLITE_ACT_NONE && !aux && drop && ep.residual && !ep.colsum) return 5;
+  if (!ep.bias && !ep.preact && ep.act == CLITE_ACT_NONE && !aux && !drop && ep.residual && !ep.colsum) return 6;
+  return 0;
+}
+
 // forward-type operand pairs (generic / plain epilogues)
 template <class CFG, class LA, class LB>
 int go_fwd(const LA& la, const LB& lb, const clite_epilogue& ep, const RowMap& rm, int M, int N, int Ktot, int splits, hipStream_t st) {
   if (is_plain(ep)) return go<CFG, 2>(la, lb, ep, rm, M, N, Ktot, splits, st);
   return go<CFG, 0>(la, lb, ep, rm, M, N, Ktot, splits, st);
+}
+// k-contiguous x k-contiguous operands (every BERT linear, forward and — on the transposed weight copies — input gradient): + the four
+// specialised forms
+template <class CFG, class LA, class LB>
+int go_linear(const LA& la, const LB& lb, const clite_epilogue& ep, const RowMap& rm, int M, int N, int Ktot, int splits, hipStream_t st) {
+  if (splits == 1 && !rm.on) {
+    switch (bert_form(ep)) {
+      case 3: return go<CFG, 3>(la, lb, ep, rm, M, N, Ktot, 1, st);
+      case 4: return go<CFG, 4>(la, lb, ep, rm, M, N, Ktot, 1, st);
+      case 5: return go<CFG, 5>(la, lb, ep, rm, M, N, Ktot, 1, st);
+      case 6: return go<CFG, 6>(la, lb, ep, rm, M, N, Ktot, 1, st);
+      default: break;
+    }
+  }
+  return go_fwd<CFG>(la, lb, ep, rm, M, N, Ktot, splits, st);
 }
 
 template <class CFG>
@@ -67,7 +96,7 @@ int dispatch(const WideOperand& a, const WideOperand& b, const clite_epilogue& e
     if (a.kind == WOP_KC_DGRAD && b.kind == WOP_KC) return go<CFG, 1>(mk_kcd<BM>(a), mk_kc<BN>(b), ep, rm, M, N, Ktot, 1, st);      // transposed weights
     return -1;
   }
-  if (a.kind == WOP_KC && b.kind == WOP_KC) return go_fwd<CFG>(mk_kc<BM>(a), mk_kc<BN>(b), ep, rm, M, N, Ktot, splits, st);
+  if (a.kind == WOP_KC && b.kind == WOP_KC) return go_linear<CFG>(mk_kc<BM>(a), mk_kc<BN>(b), ep, rm, M, N, Ktot, splits, st);
   if (a.kind == WOP_KC && b.kind == WOP_XC_STRIDED) return go_fwd<CFG>(mk_kc<BM>(a), mk_xs<BN>(b), ep, rm, M, N, Ktot, splits, st);
   if (a.kind == WOP_KC_DGRAD && b.kind == WOP_XC_STRIDED) return go_fwd<CFG>(mk_kcd<BM>(a), mk_xs<BN>(b), ep, rm, M, N, Ktot, splits, st);
   if (a.kind == WOP_KC_DGRAD && b.kind == WOP_KC) return go_fwd<CFG>(mk_kcd<BM>(a), mk_kc<BN>(b), ep, rm, M, N, Ktot, splits, st);
@@ -116,7 +145,9 @@ int clite::launch_wide(const WideOperand& a, const WideOperand& b, const clite_e
     //  * inside the step (tools/layer_profile.py, profiles/r2_layers_*.txt) one 8-wave workgroup per CU exposes its epilogue — nothing else
     //    on the CU computes meanwhile — so launches whose epilogue is VALU-heavy (erf-GELU forward / derivative over a 3840 x 3072 tile set:
     //    ~14 us of VALU) or reads three extra tensors (the BatchNorm-backward form) go wide only when the K loop is long enough to pay for it
-    const bool gelu = ep.act == CLITE_ACT_GELU || (ep.dact_aux && ep.dact == 2);
+    //    (round 4: the two GELU launches of BERT's FFN have compile-time epilogue forms now — WideEpiForm 3 / 4 — and run the 256 x 256 tile faster
+    //    than the 4-wave kernel: forward 41.1 vs 49.0 us, input gradient with the bias sums 44.2 vs 59.4; other GELU combinations keep the rule)
+    const bool gelu = (ep.act == CLITE_ACT_GELU || (ep.dact_aux && ep.dact == 2)) && !(a.kind == WOP_KC && b.kind == WOP_KC && splits == 1 && bert_form(ep) != 0);
     const bool bn = ep.bn_y || ep.mask_after_residual;
     if (tm128 * tn128 <= 256) pick = 1;
     //    (round 3, against the row-range persistent 4-wave kernel with its specialised epilogue, cold caches: 1x1 256 <- 1024 @14 45.2 narrow / 41.5

@@ -289,28 +289,31 @@ DEV float gelu_grad_f(float x) {
 // a plain store). erf by Abramowitz & Stegun 7.1.26 — 1 - (a1 t + ... + a5 t^5) e^(-z^2), t = 1 / (1 + p z), |error| <= 1.5e-7, far below the
 // 2^-9 of the stored value — costs one reciprocal, one exponential and six FMAs, and the derivative reuses the exponential (e^(-z^2) with
 // z = x / sqrt 2 IS the Gaussian of the density). The f32 parity mode keeps erff.
-DEV void gelu_fast_parts(float x, float& cdf, float& gauss) {
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
-  gauss = __expf(-z * z);
-  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float half_erfc = 0.5f * poly * gauss;            // 0.5 * erfc(|z|)
-  cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+// (Round 4: constants folded — 1 / (1 + p |x| / sqrt 2), e^(-x^2 / 2) as exp2 of ONE product, the 0.5 inside the coefficients — and the sign
+// select replaced by arithmetic: with h = 0.5 erfc(|x| / sqrt 2), x Phi(x) = max(x, 0) - |x| h. 13 / 16 instructions per element instead of 18 / 21:
+// at one 8-wave workgroup per CU the GELU launches' epilogue is VALU-bound, 128 elements per thread.)
+DEV void gelu_fast_parts(float x, float& half_erfc, float& gauss) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(__fmaf_rn(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+  gauss = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.4426950408889634f));          // e^(-x^2 / 2)
+  const float poly = ((((0.5f * 1.061405429f * t - 0.5f * 1.453152027f) * t + 0.5f * 1.421413741f) * t - 0.5f * 0.284496736f) * t + 0.5f * 0.254829592f) * t;
+  half_erfc = poly * gauss;            // 0.5 * erfc(|x| / sqrt 2) = Phi(-|x|)
 }
 template <typename T> DEV float gelu_t(float x) {
   if constexpr (sizeof(T) == 2) {
-    float cdf, g;
-    gelu_fast_parts(x, cdf, g);
-    return x * cdf;
+    float h, g;
+    gelu_fast_parts(x, h, g);
+    return __fmaf_rn(-fabsf(x), h, fmaxf(x, 0.f));          // x >= 0: x (1 - h); x < 0: x h  (a NaN stays a NaN through the product)
   } else {
     return gelu_f(x);
   }
 }
 template <typename T> DEV float gelu_grad_t(float x) {
   if constexpr (sizeof(T) == 2) {
-    float cdf, g;
-    gelu_fast_parts(x, cdf, g);
-    return cdf + x * (0.39894228040143268f * g);
+    float h, g;
+    gelu_fast_parts(x, h, g);
+    const float cdf = 0.5f + copysignf(0.5f - h, x);          // Phi(x) = 1 - h for x >= 0, h for x < 0
+    return __fmaf_rn(x * 0.39894228040143268f, g, cdf);
   } else {
     return gelu_grad_f(x);
   }

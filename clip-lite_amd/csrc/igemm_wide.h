@@ -148,11 +148,24 @@ struct WideCfg {
 //   0 generic: bias, activation, pre-activation store, activation derivative, dropout, residual, f32 / bf16 store, column statistics
 //   1 BatchNorm backward (conv dgrad): relu' mask (before or after the residual), residual, bf16 / f32 store, (sum v, sum v*(bn_y - mean))
 //   2 plain: bias, bf16 store, column statistics
+// and, round 4, the four forms BERT's linears launch 84 times per step, fixed at compile time like 2 (the run-time form's ~15 wave-uniform flag
+// tests per row are scheduling barriers: one row's loads, erf arithmetic, conversions and stores issue back to back instead of interleaving
+// with the other rows' — with ONE 8-wave workgroup per CU nothing else hides that; profiles/r2_epilogue_forms.txt: + 15 us on the GELU launches):
+//   3 FFN1 forward: bias, pre-activation store, GELU, bf16 store           4 FFN2 input gradient: acc * GELU'(aux), bf16 store, column sums (bias gradient)
+//   5 output projections forward: bias, dropout, residual, bf16 store      6 input gradients into a residual stream: + residual, bf16 store
+template <int EPI> struct WideEpiForm {
+  static constexpr bool RT = EPI == 0, BN = EPI == 1;              // RT: every feature decided by run-time flags
+  static constexpr bool PREACT = EPI == 3, GELU = EPI == 3, DGELU = EPI == 4, DROP = EPI == 5, RES = EPI == 5 || EPI == 6;
+  static constexpr bool BIAS = EPI == 0 || EPI == 2 || EPI == 3 || EPI == 5;
+  static constexpr bool MAY_STATS = EPI == 0 || EPI == 1 || EPI == 2 || EPI == 4;
+};
+
 template <class CFG, int EPI>
 DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
                        int tid, int lane, int kg, int wm0, int wn0) {
   constexpr int RM = CFG::RM, RN = CFG::RN;
   typedef bf16 T;
+  typedef WideEpiForm<EPI> F;
   if constexpr (CFG::KG == 2) {
     // group 1 -> group 0: element (i, j, r) of thread t at ((i*RN + j)*16 + r)*256 + t
     float* xchg = (float*)smem;
@@ -194,6 +207,20 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
     return;
   }
 
+  // what this launch's rows do: compile-time constants in the specialised forms, wave-uniform run-time flags in forms 0 / 1
+  const bool has_preact = F::PREACT || (F::RT && ep.preact != nullptr);
+  const int act = F::GELU ? (int)ACT_GELU : (F::RT ? ep.act : (int)ACT_NONE);
+  const bool has_bits = F::BN && ep.relu_bits != nullptr;
+  const bool has_aux = F::DGELU || ((F::RT || F::BN) && !has_bits && ep.dact_aux != nullptr);
+  const int dact = F::DGELU ? 2 : (F::BN ? 1 : ep.dact);
+  const bool has_drop = F::DROP || (F::RT && ep.drop_p > 0.f);
+  const bool has_res = F::RES || ((F::RT || F::BN) && ep.residual != nullptr);
+  const bool has_y = F::BN && ep.bn_y != nullptr;
+  const bool mask_after = F::BN && ep.mask_after_residual != 0;
+  const bool to_f32 = (F::RT || F::BN) && ep.out_f32 != 0;
+  const bool stats = F::MAY_STATS && ep.colsum != nullptr;
+  const bool sums_only = F::DGELU || ep.colsum_rows == 1;          // column sums without the sums of squares (a bias gradient)
+
   constexpr int CPRE = CFG::CPRE, RPSE = CFG::RPSE, ITER = CFG::ITER, PITCH = CFG::EPI_PITCH;
   const int ecol = (tid % CPRE) * 8, erow0 = tid / CPRE;
   const int gcol = n0 + ecol;
@@ -201,11 +228,11 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
   float csum[8], csq[8], bias[8], bn_mean[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; bias[e] = 0.f; bn_mean[e] = 0.f; }
-  if (EPI != 1 && colok && ep.bias) {
+  if (F::BIAS && colok && ep.bias) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = ep.bias[gcol + e];
   }
-  if (EPI == 1 && colok && ep.bn_y) {
+  if (has_y && colok) {
     for (int r = 0; r < ep.bn_replicas; ++r)
 #pragma unroll
       for (int e = 0; e < 8; ++e) bn_mean[e] += ep.bn_stats[(size_t)r * ep.bn_rstride + gcol + e];
@@ -215,12 +242,11 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
   float keep_scale = 1.f;
   uint64_t drop_seed = 0;
   uint32_t drop_site = 0;
-  if (EPI == 0 && ep.drop_p > 0.f) {
+  if (has_drop) {
     keep_scale = 1.0f / (1.0f - ep.drop_p);
     drop_seed = ep.drop_seed; drop_site = ep.drop_site;
     seed_resolve(drop_seed, drop_site);
   }
-  const bool stats = ep.colsum != nullptr;
 
   for (int pass = 0; pass < CFG::BM / CFG::PR; ++pass) {
     // the operands of all rows this thread writes in this pass are requested before the accumulators go through LDS
@@ -234,11 +260,11 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
       okr[it] = colok && grow < M;
       gix[it] = okr[it] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
       pb[it] = 0xFFu;
-      if (EPI != 2 && okr[it]) {
-        if (EPI == 1 && ep.relu_bits) pb[it] = ep.relu_bits[gix[it] >> 3];
-        else if (ep.dact_aux) pa[it].ld((const T*)ep.dact_aux + gix[it]);
-        if (EPI == 1 && ep.bn_y) py[it].ld((const T*)ep.bn_y + gix[it]);
-        if (ep.residual) pr[it].ld((const T*)ep.residual + gix[it]);
+      if (EPI != 2 && EPI != 3 && okr[it]) {
+        if (has_bits) pb[it] = ep.relu_bits[gix[it] >> 3];
+        if (has_aux) pa[it].ld((const T*)ep.dact_aux + gix[it]);
+        if (has_y) py[it].ld((const T*)ep.bn_y + gix[it]);
+        if (has_res) pr[it].ld((const T*)ep.residual + gix[it]);
       }
     }
     // the waves that own this pass's 64 rows stage them (static accumulator indices: half h of a wave's rows = acc[2h], acc[2h+1])
@@ -268,72 +294,70 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
       const size_t gidx = gix[it];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] * ep.alpha + bias[e];
-      if constexpr (EPI == 0) {
-        if (ep.preact) store8((T*)ep.preact + gidx, v);
-        if (ep.act == ACT_RELU) {
+      if (has_preact) store8((T*)ep.preact + gidx, v);
+      if (act == ACT_RELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
-        } else if (ep.act == ACT_GELU) {
+        for (int e = 0; e < 8; ++e) v[e] = relu_f(v[e]);
+      } else if (act == ACT_GELU) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
-        } else if (ep.act == ACT_TANH) {
+        for (int e = 0; e < 8; ++e) v[e] = gelu_t<T>(v[e]);
+      } else if (act == ACT_TANH) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
       }
       float dfac[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) dfac[e] = 1.f;
-      if (EPI == 1 && ep.relu_bits) {
+      if (has_bits) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) dfac[e] = (pb[it] >> e) & 1u ? 1.f : 0.f;
-        if (!ep.mask_after_residual) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
-        }
-      } else if (EPI != 2 && ep.dact_aux) {
+      } else if (has_aux) {
         float av[8];
         pa[it].get(av);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float a = av[e];
-          dfac[e] = (EPI == 1 || ep.dact == 1) ? (a > 0.f ? 1.f : 0.f) : ep.dact == 2 ? gelu_grad_t<T>(a) : (1.f - a * a);
-        }
-        if (EPI == 0 || !ep.mask_after_residual) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
+          dfac[e] = dact == 1 ? (a > 0.f ? 1.f : 0.f) : dact == 2 ? gelu_grad_t<T>(a) : (1.f - a * a);
         }
       }
-      if (EPI == 0 && ep.drop_p > 0.f) {
+      if ((has_bits || has_aux) && !mask_after) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
+      }
+      if (has_drop) {
         float u[8];
         dropout_uniform8(drop_seed, drop_site, gidx, u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = u[e] >= ep.drop_p ? v[e] * keep_scale : 0.f;
       }
-      if (EPI != 2 && ep.residual) {
+      if (has_res) {
         float rv[8];
         pr[it].get(rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += rv[e];
       }
-      if (EPI == 1 && (ep.dact_aux || ep.relu_bits) && ep.mask_after_residual) {
+      if ((has_bits || has_aux) && mask_after) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= dfac[e];
       }
-      if (EPI != 2 && ep.out_f32) {
+      if (to_f32) {
         store8((float*)ep.out + gidx, v);
       } else {
         store8((T*)ep.out + gidx, v);
-        round8_bf16(v);   // statistics of what was stored
+        if (F::MAY_STATS) round8_bf16(v);   // statistics of what was stored
       }
-      if (EPI == 1 && ep.bn_y) {
+      if (has_y) {
         float yv[8];
         py[it].get(yv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * (yv[e] - bn_mean[e]); }
       } else if (stats) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+        for (int e = 0; e < 8; ++e) csum[e] += v[e];
+        if (!F::DGELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csq[e] += v[e] * v[e];
+        }
       }
     }
     lds_barrier();
@@ -354,7 +378,7 @@ DEV void wide_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, cons
       for (int r = 0; r < RPSE; ++r) s += red[r * (CPRE * 16) + idx];
       const int chunk = idx / 16, e = idx % 16;
       const int col = n0 + chunk * 8 + (e & 7);
-      if (col < N && (e < 8 || ep.colsum_rows != 1)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
+      if (col < N && (e < 8 || !sums_only)) atomic_add_f32(crep + (e >= 8 ? N : 0) + col, s);
     }
   }
 }

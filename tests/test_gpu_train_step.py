@@ -383,8 +383,11 @@ def test_single_graph_bf16_replay_refreshes_transposed_weights_and_tracks_eager(
     Every bf16 input-gradient GEMM reads the transposed weight copies (Arena.flat_lpT); the captured graph must re-derive them itself at every
     replay (without that node the replays ran their dgrads against the weights of the last eager step while the update kept moving
     flat_lp). Checked two ways: (1) after a replay the copies equal the transpose of the bf16 weights that replay STARTED from — bitwise, and not
-    those of the previous step; (2) the replayed trajectory tracks the eager one. Learning rates are large enough that one step moves bf16 weights.
-    Tolerances (bf16, two runs differ by float-atomic order): loss 3e-2 per step, parameter movement within 10 % (relative L2)."""
+    those of the previous step; (2) the replayed trajectory tracks the eager one. Learning rates are large enough that one step moves bf16 weights,
+    which also makes this 32-sample bf16 problem noisy: two EAGER runs of it differ by tens of percent in their parameter movement after five steps
+    (float-atomic order flips bf16 roundings; measured 0.39 between an eager and a replayed run). So the eager run is done twice and the replayed
+    run must be as close to eager run A as eager run B is, within a factor of two (and the loss within 3e-2 per step). Frozen transposed
+    copies — the bug — put the replayed run's dgrads on weights that are two steps old: caught bitwise by (1)."""
     from clip_lite_amd.encoder import ImageEncoder, TextEncoder
     from clip_lite_amd.loss import JSDInfoMaxLoss
     from clip_lite_amd.model import VLInfoModel
@@ -399,7 +402,7 @@ def test_single_graph_bf16_replay_refreshes_transposed_weights_and_tracks_eager(
         batches.append({"image": det_tensor(f"simg{i}", (B, 3, 64, 64), "normal").cuda(), "input_ids": ids.cuda(),
                         "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()})
     results = []
-    for graph in (False, True):
+    for graph in (False, False, True):
         torch.manual_seed(7)
         te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
         te.strans.hidden_dropout_prob = te.strans.attention_probs_dropout_prob = 0.0
@@ -427,10 +430,11 @@ def test_single_graph_bf16_replay_refreshes_transposed_weights_and_tracks_eager(
                     assert not torch.equal(A.w(p), w0), "the step did not move this bf16 weight: the check above proves nothing"
         torch.cuda.synchronize()
         results.append((losses, A.flat_p - p_init))
-    (l0, d0), (l1, d1) = results
+    (l0, d0), (le, de), (l1, d1) = results
     assert max(abs(a - b) for a, b in zip(l0, l1)) < 3e-2, (l0, l1)
+    spread = ((d0 - de).norm() / d0.norm()).item()          # eager vs eager: the problem's own run-to-run noise
     rel = ((d0 - d1).norm() / d0.norm()).item()
-    assert d0.norm().item() > 1e-3 and rel < 0.1, (d0.norm().item(), rel)
+    assert d0.norm().item() > 1e-3 and rel < max(2.0 * spread, 0.05), (d0.norm().item(), rel, spread)
 
 
 def test_graph_replay_takes_shorter_caption_batches_padded():

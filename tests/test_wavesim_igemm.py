@@ -459,3 +459,60 @@ def test_colsum_rows_1_accumulates_the_column_sums_only(dtype):
     _close(sums[:N], 5.0 + got.sum(0), 1e-4)
     assert (sums[N:] == 5.0).all()
 
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 104), (300, 264, 128)])
+def test_bert_epilogue_forms_compiled_in(M, N, K, tile_policy):
+    """The four compile-time epilogue forms of BERT's linears on the 8-wave kernels (igemm_wide.h WideEpiForm 3 - 6; gemm_wide.hip bert_form
+    recognises them from the run-time description): FFN1 forward (bias + pre-activation store + GELU), FFN2's input gradient (acc x GELU'(aux)
+    with the bias gradient's column sums, colsum_rows = 1), the output projections (bias + dropout + residual) and the residual-stream input
+    gradients (+ residual). Against numpy, ragged edges included; the dropout form against the same launch on the 4-wave kernel's run-time-flag
+    epilogue (policy 4): the mask is a function of (seed, site, element index) only, so the SAME elements must be zero."""
+    from scipy.special import erf
+    rng = np.random.default_rng(M + N + K)
+    A, Ab = _prep(rng.standard_normal((M, K), dtype=np.float32) * 0.3, BF16)
+    B, Bb = _prep(rng.standard_normal((N, K), dtype=np.float32) * 0.3, BF16)
+    R, Rb = _prep(rng.standard_normal((M, N), dtype=np.float32), BF16)
+    aux, auxb = _prep(rng.standard_normal((M, N), dtype=np.float32) * 1.5, BF16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    z = A @ B.T
+    cdf = lambda x: 0.5 * (1 + erf(x / np.sqrt(2)))
+    # form 3
+    out, pre = np.zeros((M, N), np.uint16), np.zeros((M, N), np.uint16)
+    ep = make_ep(out, N, bias=bias, act=2, preact=pre)
+    assert lib().clite_gemm_nt(ptr(Ab), K, ptr(Bb), K, M, N, K, BF16, C.byref(ep), None) == 0
+    _close(from_bf16(pre), z + bias, 6e-3)
+    _close(from_bf16(out), (z + bias) * cdf(z + bias), 6e-3)
+    # form 4, with and without the column sums; the floats behind the sums (what colsum_rows = 1 must not touch) stay as they were
+    for with_sums in (True, False):
+        out = np.zeros((M, N), np.uint16)
+        colsum = np.full((2, N), 7.0, np.float32)
+        colsum[0] = 0.0
+        ep = make_ep(out, N, dact_aux=auxb, dact=2, colsum=colsum if with_sums else None)
+        ep.colsum_rows = 1
+        assert lib().clite_gemm_nt(ptr(Ab), K, ptr(Bb), K, M, N, K, BF16, C.byref(ep), None) == 0
+        gp = cdf(aux) + aux * np.exp(-0.5 * aux * aux) / np.sqrt(2 * np.pi)
+        _close(from_bf16(out), z * gp, 6e-3)
+        if with_sums:
+            _close(colsum[0], from_bf16(out).sum(0), 1e-4)
+            assert (colsum[1] == 7.0).all()
+    # form 6
+    out = np.zeros((M, N), np.uint16)
+    ep = make_ep(out, N, residual=Rb)
+    assert lib().clite_gemm_nt(ptr(Ab), K, ptr(Bb), K, M, N, K, BF16, C.byref(ep), None) == 0
+    _close(from_bf16(out), z + R, 6e-3)
+    # form 5 against the run-time-flag epilogue of the 4-wave kernel
+    res = []
+    for pol in (tile_policy, 4):
+        assert lib().clite_set_tile_policy(pol) == 0
+        out = np.zeros((M, N), np.uint16)
+        ep = make_ep(out, N, bias=bias, drop_p=0.25, drop_seed=1234, drop_site=5, residual=Rb)
+        assert lib().clite_gemm_nt(ptr(Ab), K, ptr(Bb), K, M, N, K, BF16, C.byref(ep), None) == 0
+        res.append(from_bf16(out))
+    assert lib().clite_set_tile_policy(tile_policy) == 0
+    dropped = np.isclose(res[1], R, atol=0)                # a dropped element is the bare residual
+    assert 0.15 < dropped.mean() < 0.35
+    assert (np.isclose(res[0], R, atol=0) == dropped).all()
+    _close(res[0], res[1], 6e-3)
+    keep = ~dropped
+    _close(res[0][keep], ((z + bias) / 0.75 + R)[keep], 6e-3)

@@ -373,6 +373,8 @@ inline uint32_t umulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline float __expf(float x) { return expf(x); }
 inline float __frcp_rn(float x) { return 1.0f / x; }
+inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 inline float __logf(float x) { return logf(x); }
 
 #endif  // CLITE_WAVESIM_H

@@ -7,8 +7,10 @@ import torch
 from clip_lite_amd import hip
 
 SHAPES = [("nt", 3840, 3072, 768, ("", "bias", "gelu")), ("nt", 3840, 768, 3072, ("", "bias", "bdr")), ("nt", 3840, 768, 768, ("", "bias", "bdr")),
-          ("nt", 3840, 2304, 768, ("", "bias")), ("nn", 3840, 3072, 768, ("", "dgelu")), ("nn", 3840, 768, 3072, ("", "res")),
-          ("nn", 3840, 768, 2304, ("", "res")), ("nn", 3840, 768, 768, ("", "res"))]
+          ("nt", 3840, 2304, 768, ("", "bias")),
+          # input gradients: on the transposed weight copies they are gemm_nt launches too (round 3); the nn rows = the strided-weight form
+          ("nt", 3840, 3072, 768, ("dgelu", "dgelu+b")), ("nt", 3840, 768, 3072, ("res",)), ("nt", 3840, 768, 2304, ("res",)), ("nt", 3840, 768, 768, ("res",)),
+          ("nn", 3840, 3072, 768, ("", "dgelu")), ("nn", 3840, 768, 3072, ("", "res"))]
 
 
 def timed(fn, n=20):
@@ -38,6 +40,7 @@ def main():
                   "gelu": lambda: hip.epilogue(out, N, bias=bias, act=hip.ACT_GELU, preact=pre),
                   "bdr": lambda: hip.epilogue(out, N, bias=bias, drop=(0.1, 1234, 7), residual=res),
                   "dgelu": lambda: hip.epilogue(out, N, dact_aux=pre, dact=hip.DACT_GELU),
+                  "dgelu+b": lambda: hip.epilogue(out, N, dact_aux=pre, dact=hip.DACT_GELU, colsum=torch.zeros(N, device="cuda"), colsum_rows=1),
                   "res": lambda: hip.epilogue(out, N, residual=res)}[form]()
             row = []
             for pol in range(5):
