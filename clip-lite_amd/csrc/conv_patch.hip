@@ -1,0 +1,327 @@
+// Patch-resident 3 x 3 / stride 1 / pad 1 convolution for 64 -> 64 channels (bf16): torchvision ResNet's layer1 conv2 (reference encoder.py:36-41;
+// block arithmetic as restated in model_zoo/resnet.py:60-100) — forward, and its input gradient on the transposed weight copy.
+//
+// Why its own kernel (round 4; DESIGN.md §3.1, "patch-resident"). As an implicit GEMM (M = pixels, N = 64, K = 9 x 64) the tile engine gathers
+// every input pixel NINE times out of L2 — 288 KB of gathered operand per 256-pixel tile whose input patch with halo is 44 KB — and at 56 x 56
+// that gather, not HBM and not the matrix pipe, is the launch: 70.6 us forward / 83.3 us input gradient against an HBM ideal of 19 / 29
+// (profiles/r3_layers.txt). Here a workgroup keeps in LDS
+//   * ALL nine taps of the weights, [tap][out channel][64 in channels] = 72 KB, loaded once per workgroup, and
+//   * the input PATCH of a strip of R output rows: (R + 2) x (W + 1) pixels x 128 B (R = 4 at W = 56: 43 KB), double-buffered,
+// and forms every tap's A fragment by a `ds_read_b128` at a shifted patch address: L2 -> LDS traffic per tile drops 6.5 x (patch once + nothing
+// for the weights), HBM traffic stays the algorithmic input + output. One persistent 8-wave workgroup per CU walks a contiguous range of strips
+// (1792 strips at batch 128 = 7 per CU); strip i + 1's patch lands by LDS-DMA while strip i is multiplied and written.
+//
+// Patch image. Pixel (pr, pc) of the patch — pr = 0 .. R + 1 (image row y0 - 1 + pr), pc = 0 .. W + 1 (image column pc - 1) — sits at flat index
+// pr * (W + 1) + pc: the right halo of row pr IS the left halo of row pr + 1 (both are zeros), so a row costs W + 1 pixels, not W + 2. Halo and
+// out-of-image pixels are zero-filled by out-of-range DMA sources. The 16-byte chunk c of pixel p sits in slot c ^ ((p >> 1) & 7): 16 lanes reading
+// chunk c of 16 consecutive pixels then cover all 64 banks once (pixel pitch 128 B = 32 banks; a strip-row crossing inside a lane group skips one
+// pixel and costs a 2-way conflict on one pair). The DMA destination is lane-linear, so the swizzle is applied to the SOURCE chunk (igemm_dma.h).
+//
+// Waves: 4 (M) x 2 (N), each 64 pixels x 32 output channels = 2 MFMA 32 x 32 x 16 blocks; a wave skips the blocks beyond the strip (224 pixels at
+// W = 56: 7 of 8 blocks). Per k-step a wave reads 2 A + 1 B fragments for 2 MFMAs: 192 B/clk/CU of LDS reads at full matrix rate.
+//
+// Epilogue forms: 0 = what clite_conv_fwd's launches ask for (bf16 store + per-channel sum / sum of squares of the stored values); 1 = the
+// BatchNorm-backward form of the ResNet backward's dgrads (packed relu' bits, bf16 store, sum v and sum v (bn_y - mean): igemm.h FORM 1). The
+// accumulators go through the strip's own (now free) patch buffer in two halves of 128 rows; stores are whole 128-byte pixel rows.
+#include "igemm_wide.h"
+#include "wide_api.h"
+#include <type_traits>
+
+using namespace clite;
+
+namespace {
+
+constexpr int PC = 64;                        // channels in = channels out
+constexpr int PIXB = PC * 2;                  // bytes per pixel
+constexpr int NTAP = 9;
+constexpr int WBYTES = NTAP * PC * PIXB;      // 73,728: [tap][out channel][in channel]
+constexpr int MAXPIX = 344;                   // (R + 2) (W + 1) + 1 <= 344
+constexpr int PBYTES = MAXPIX * PIXB;         // 44,032 per patch buffer
+constexpr int NPI = MAXPIX / 8;               // DMA instructions per patch (8 pixels each)
+constexpr int NPW = (NPI + 7) / 8;            // ... per wave
+constexpr int EPITCH = PC * 4 + 16;           // f32 staging row
+constexpr int HALF = 128;                     // rows staged at a time
+static_assert(HALF * EPITCH <= PBYTES, "a half of the accumulator tile fits a patch buffer");
+static_assert(WBYTES + 2 * PBYTES <= 160 * 1024, "LDS budget");
+
+struct PatchArgs {
+  const void* x;
+  uint32_t xbytes;
+  const void* w;
+  uint32_t wbytes;
+  int N, H, W, R;             // R: output rows per strip
+  int strips_per_img, nstrips;
+  int flip;                   // 1: tap t reads the weight's tap 8 - t (input gradient on [C][R][S][K] weights)
+};
+
+#ifndef CLITE_PATCH_ABLATE
+#define CLITE_PATCH_ABLATE 0          // diagnostic variant builds only (tools/probe_patch.py): 1 = no MFMA loop, 2 = no global stores, 4 = no patch DMA after the first
+#endif
+
+template <int FORM>
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(PatchArgs a, Epilogue ep, int strips_per_wg) {
+  __shared__ __attribute__((aligned(1024))) char smem[WBYTES + 2 * PBYTES];
+  char* const wbuf = smem;
+  char* const pbuf = smem + WBYTES;
+  typedef bf16 T;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int wmi = wave >> 1, wni = wave & 1;
+  const int W1 = a.W + 1;
+  const int rows_strip = a.R * a.W;                         // GEMM rows of a full strip (<= 256)
+
+  int s_begin = blockIdx.x * strips_per_wg, s_end = s_begin + strips_per_wg;
+  if (s_end > a.nstrips) s_end = a.nstrips;
+  if (s_begin >= s_end) return;
+
+  // ---- the weights, once: 72 DMA instructions of 8 rows x 128 B; row = tap * 64 + out channel
+  {
+    const rsrc_t rw = make_rsrc(a.w, a.wbytes);
+#pragma unroll
+    for (int k = 0; k < NTAP; ++k) {
+      const int i = wave + 8 * k;
+      const int row = i * 8 + (lane >> 3);
+      const int t = row >> 6, oc = row & 63;
+      const int ts = a.flip ? 8 - t : t;
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      buf_load16_lds(rw, (uint32_t)(((oc * NTAP + ts) * PC + chunk * 8) * 2), wbuf + i * 1024);
+    }
+  }
+
+  // ---- patch DMA: per-lane constants of this wave's instructions (the same for every strip)
+  const rsrc_t rx = make_rsrc(a.x, a.xbytes);
+  int p_rel[NPW], p_row[NPW];          // element offset relative to the strip's first pixel; patch row (-1: never valid)
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) {
+    const int i = wave + 8 * k;
+    const int pix = i * 8 + (lane >> 3);
+    const int pr = pix / W1, pc = pix - pr * W1;
+    const int chunk = (lane & 7) ^ ((pix >> 1) & 7);
+    const bool ok = i < NPI && pc >= 1 && pc <= a.W && pr <= a.R + 1;
+    p_row[k] = ok ? pr : -1;
+    p_rel[k] = ((pr - 1) * a.W + (pc - 1)) * PC + chunk * 8;
+  }
+  auto issue_patch = [&](int strip, char* dst) {
+    const int n = strip / a.strips_per_img;
+    const int y0 = (strip - n * a.strips_per_img) * a.R;
+    const int base = (n * a.H + y0) * a.W * PC;
+#pragma unroll
+    for (int k = 0; k < NPW; ++k) {
+      const int i = wave + 8 * k;
+      if (i < NPI) {          // wave-uniform
+        const bool v = p_row[k] >= 0 && (unsigned)(y0 + p_row[k] - 1) < (unsigned)a.H;
+        buf_load16_lds(rx, v ? (uint32_t)((base + p_rel[k]) * 2) : OOB_OFF, dst + i * 1024);
+      }
+    }
+  };
+
+  // ---- K loop constants
+  int nblk = (rows_strip - 64 * wmi + 31) / 32;
+  nblk = nblk < 0 ? 0 : (nblk > 2 ? 2 : nblk);
+  nblk = wave_uniform(nblk);
+  int bpix[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    int q = 64 * wmi + 32 * mb + (lane & 31);
+    if (q > rows_strip - 1) q = rows_strip - 1;
+    const int oy = q / a.W, ox = q - oy * a.W;
+    bpix[mb] = oy * W1 + ox;
+  }
+  const int cl = lane >> 5;
+  const int rb = 32 * wni + (lane & 31);
+  const int swb = (rb >> 1) & 7;
+  int bsw[4];
+#pragma unroll
+  for (int kc = 0; kc < 4; ++kc) bsw[kc] = rb * PIXB + (((kc * 2 + cl) ^ swb) << 4);
+
+  // ---- epilogue constants
+  const int ecol = (tid & 7) * 8, erow0 = tid >> 3;          // 64 rows per sweep of the 512 threads
+  float csum[8], csq[8], bn_mean[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; bn_mean[e] = 0.f; }
+  if (FORM == 1) {
+    for (int r = 0; r < ep.bn_replicas; ++r)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bn_mean[e] += ep.bn_stats[(size_t)r * ep.bn_rstride + ecol + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bn_mean[e] *= ep.bn_inv_count;
+  }
+  const bool stats = ep.colsum != nullptr;
+  const rsrc_t r_out = make_rsrc(ep.out, RSRC_WHOLE), r_y = make_rsrc(ep.bn_y, RSRC_WHOLE), r_bits = make_rsrc(ep.relu_bits, RSRC_WHOLE);
+
+  issue_patch(s_begin, pbuf);
+  wait_vmcnt<0>();
+  lds_barrier();
+
+  for (int strip = s_begin; strip < s_end; ++strip) {
+    const int cur = (strip - s_begin) & 1;
+    char* const pcur = pbuf + cur * PBYTES;
+    if (strip + 1 < s_end && !(CLITE_PATCH_ABLATE & 4)) issue_patch(strip + 1, pbuf + (cur ^ 1) * PBYTES);
+    const int n = strip / a.strips_per_img;
+    const int y0 = (strip - n * a.strips_per_img) * a.R;
+    int rows_valid = (a.H - y0 < a.R ? a.H - y0 : a.R) * a.W;
+    const uint32_t row0 = (uint32_t)((n * a.H + y0) * a.W);
+    // FORM 1: this strip's epilogue operands (relu' bits, BatchNorm input) are requested now and land during the K loop
+    uint32_t pb[4];
+    Raw8<T> py[4];
+    if (FORM == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int trow = (j >> 1) * HALF + erow0 + 64 * (j & 1);
+        const uint32_t gix = (row0 + trow) * PC + ecol;
+        const bool v = trow < rows_valid;
+        pb[j] = buf_load1(r_bits, v ? (gix >> 3) : OOB_OFF);
+        py[j].ldb(r_y, v ? gix * 2u : OOB_OFF);
+      }
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+    // 36 k-steps (9 taps x 4 chunks of 16 channels) of straight-line code per block count, the next k-step's three fragment reads issued ahead of
+    // this k-step's MFMAs. (A block-count test INSIDE the loop made the compiler emit read -> s_waitcnt lgkmcnt(0) -> MFMA per fragment, every
+    // MFMA behind a full LDS round trip: 46 us per launch instead of ~30.)
+    // (the 72 fragment addresses are functions of per-lane constants: left alone, the compiler hoists them all out of the strip loop — 232 live
+    // registers, spills in the BatchNorm-backward form; made opaque here they are three VALU operations next to each read, in the MFMAs' shadow)
+    int bp[2] = {bpix[0], bpix[1]};
+    opaque_i(bp[0]);
+    opaque_i(bp[1]);
+    auto kloop = [&](auto nb_tag) {
+      constexpr int NB = decltype(nb_tag)::value;
+      auto a_addr = [&](int ks, int mb) -> const char* {
+        const int t = ks >> 2, kc = ks & 3;
+        const int pix = bp[mb] + (t / 3) * W1 + (t % 3);
+        return pcur + pix * PIXB + ((((kc * 2 + cl) ^ (pix >> 1)) & 7) << 4);
+      };
+      auto b_addr = [&](int ks) -> const char* { return wbuf + (ks >> 2) * (PC * PIXB) + bsw[ks & 3]; };
+      Chunk16 fa[2][2], fb[2];
+      fb[0].u = *(const u32x4*)b_addr(0);
+#pragma unroll
+      for (int mb = 0; mb < NB; ++mb) fa[0][mb].u = *(const u32x4*)a_addr(0, mb);
+#pragma unroll
+      for (int ks = 0; ks < NTAP * 4; ++ks) {
+        const int c = ks & 1, nx = c ^ 1;
+        if (ks + 1 < NTAP * 4) {
+          fb[nx].u = *(const u32x4*)b_addr(ks + 1);
+#pragma unroll
+          for (int mb = 0; mb < NB; ++mb) fa[nx][mb].u = *(const u32x4*)a_addr(ks + 1, mb);
+        }
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb) acc[mb] = mfma32_bf16(fa[c][mb].h, fb[c].h, acc[mb]);
+      }
+    };
+    if (!(CLITE_PATCH_ABLATE & 1)) {
+      if (nblk > 1) kloop(std::integral_constant<int, 2>{});
+      else if (nblk == 1) kloop(std::integral_constant<int, 1>{});
+    }
+    wait_vmcnt<0>();          // the next strip's patch and this strip's epilogue operands have landed (they had the K loop to do so)
+    lds_barrier();            // every wave is past its last read of this patch: the buffer becomes the accumulator staging
+
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if ((wmi >> 1) == h) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = 64 * (wmi & 1) + 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = 32 * wni + (lane & 31);
+            *(float*)(pcur + row * EPITCH + col * 4) = acc[mb][r];
+          }
+      }
+      lds_barrier();
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int rr = erow0 + 64 * k;
+        const int trow = h * HALF + rr;
+        const bool valid = trow < rows_valid;
+        const float* src = (const float*)(pcur + rr * EPITCH + ecol * 4);
+        const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const uint32_t gix = (row0 + trow) * PC + ecol;
+        if (FORM == 1) {
+          const uint32_t bits = pb[h * 2 + k];          // zeros for a row past the strip
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bits >> e) & 1u ? v[e] : 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = valid ? v[e] : 0.f;
+        }
+        Chunk16 ch;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ch.e[e] = f2bf(v[e]);
+        buf_store16(r_out, (valid && !(CLITE_PATCH_ABLATE & 2)) ? gix * 2u : OOB_OFF, ch.u);
+        if (FORM == 1) {
+          float yv[8];
+          py[h * 2 + k].get(yv);
+          round8_bf16(v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * (yv[e] - bn_mean[e]); }
+        } else if (stats) {
+          round8_bf16(v);   // statistics of what was stored
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * v[e]; }
+        }
+      }
+      lds_barrier();
+    }
+  }
+
+  if (stats) {
+    // one flush per workgroup: the 64 threads that share a column chunk fold through LDS (any patch buffer is free now)
+    float* red = (float*)pbuf;                      // [64 rows][8 chunks x 16]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[erow0 * 128 + (tid & 7) * 16 + e] = csum[e];
+      red[erow0 * 128 + (tid & 7) * 16 + 8 + e] = csq[e];
+    }
+    lds_barrier();
+    if (tid < 128) {
+      float s = 0.f;
+      for (int r = 0; r < 64; ++r) s += red[r * 128 + tid];
+      const int chunk = tid >> 4, e = tid & 15;
+      const int col = chunk * 8 + (e & 7);
+      float* crep = ep.colsum + (ep.colsum_replicas > 1 ? (size_t)(blockIdx.x % ep.colsum_replicas) * ep.colsum_stride : 0);
+      if (e < 8 || ep.colsum_rows != 1) atomic_add_f32(crep + (e >= 8 ? PC : 0) + col, s);
+    }
+  }
+}
+
+}  // namespace
+
+// Returns WIDE_NOT_TAKEN when the launch is not one this kernel covers (the caller then takes the implicit-GEMM path).
+int clite::launch_conv3x3_patch(const void* x, const void* w, const clite_conv& c, const clite_epilogue& ep, bool dgrad, hipStream_t st) {
+  if (c.dtype != CLITE_BF16 || c.C != PC || c.K != PC || c.R != 3 || c.S != 3 || c.stride != 1 || c.pad != 1 || c.Ho != c.H || c.Wo != c.W) return WIDE_NOT_TAKEN;
+  if (ep.ldc != PC || ep.atomic || ep.out_f32 || ep.alpha != 1.f || ep.bias || ep.act != CLITE_ACT_NONE || ep.preact || ep.dact_aux || ep.drop_p > 0.f ||
+      ep.residual || ep.mask_after_residual || ep.splitk_ws)
+    return WIDE_NOT_TAKEN;
+  int form;
+  if (!ep.bn_y && !ep.relu_bits) form = 0;
+  else if (ep.bn_y && ep.relu_bits && ep.colsum) form = 1;
+  else return WIDE_NOT_TAKEN;
+  if (!dgrad && form != 0) return WIDE_NOT_TAKEN;
+  int R = 256 / c.W;
+  if (R > c.H) R = c.H;
+  while (R >= 1 && (R + 2) * (c.W + 1) + 1 > MAXPIX) --R;
+  if (R < 1) return WIDE_NOT_TAKEN;
+  PatchArgs a;
+  a.x = x; a.xbytes = (uint32_t)((size_t)c.N * c.H * c.W * PC * 2);
+  a.w = w; a.wbytes = (uint32_t)(NTAP * PC * PC * 2);
+  a.N = c.N; a.H = c.H; a.W = c.W; a.R = R;
+  a.strips_per_img = (c.H + R - 1) / R;
+  a.nstrips = c.N * a.strips_per_img;
+  a.flip = dgrad ? 1 : 0;
+#ifndef CLITE_PATCH_WGS
+#define CLITE_PATCH_WGS 256          // one persistent workgroup per CU (the simulator build uses 2, so that its small cases walk several strips)
+#endif
+  const int grid = a.nstrips < CLITE_PATCH_WGS ? a.nstrips : CLITE_PATCH_WGS;
+  const int per = (a.nstrips + grid - 1) / grid;
+  const int g2 = (a.nstrips + per - 1) / per;
+  if (form == 0) hipLaunchKernelGGL(conv3x3_patch_kernel<0>, dim3(g2), dim3(512), 0, st, a, ep, per);
+  else hipLaunchKernelGGL(conv3x3_patch_kernel<1>, dim3(g2), dim3(512), 0, st, a, ep, per);
+  return (int)hipGetLastError();
+}

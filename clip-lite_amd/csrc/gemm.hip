@@ -470,6 +470,14 @@ int conv_fwd(const void* x, const void* w, const clite_conv& c, const clite_epil
   constexpr int BK = Cfg<T>::BK;
   int M = c.N * c.Ho * c.Wo, Ktot = c.R * c.S * c.C;
   uint32_t xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * sizeof(T)), wb = (uint32_t)((size_t)c.K * Ktot * sizeof(T));
+  if constexpr (sizeof(T) == 2) {
+    // 3 x 3 / stride 1, 64 -> 64: the patch-resident kernel (conv_patch.hip) — automatic policy only; the deterministic mode keeps the path whose
+    // statistics come from colstats_det
+    if (use_dma() && !deterministic() && tile_policy_value() == 0) {
+      const int rc = launch_conv3x3_patch(x, w, c, *ep, false, st);
+      if (rc != WIDE_NOT_TAKEN) return rc;
+    }
+  }
   if (c.K <= 64) {
     GatherKC<T, 256, BK, false> la{x, xb, geom_fwd(c)};
     GatherKC<T, 64, BK, false> lb{w, wb, geom_dense(c.K, Ktot)};
@@ -487,6 +495,12 @@ int conv_dgrad(const void* dy, const void* w, const clite_conv& c, const clite_e
   int M = c.N * c.H * c.W, Ktot = c.R * c.S * c.K;
   uint32_t yb = (uint32_t)((size_t)c.N * c.Ho * c.Wo * c.K * sizeof(T)), wb = (uint32_t)((size_t)c.K * c.R * c.S * c.C * sizeof(T));
   if constexpr (WT) {
+    if constexpr (sizeof(T) == 2) {
+      if (use_dma() && !deterministic() && tile_policy_value() == 0) {          // 3 x 3 / stride 1, 64 <- 64: conv_patch.hip
+        const int rc = launch_conv3x3_patch(dy, w, c, *ep, true, st);
+        if (rc != WIDE_NOT_TAKEN) return rc;
+      }
+    }
     if (c.R == 1 && c.S == 1 && c.pad == 0 && c.stride > 1 && ep->residual == ep->out && !ep->colsum && !ep->preact && !ep->dact_aux) {
       int P = c.N * c.Ho * c.Wo;      // strided 1x1 shortcut: dense GEMM over the output pixels, rows scattered (see below)
       RowMap rm;

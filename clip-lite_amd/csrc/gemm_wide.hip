@@ -122,6 +122,8 @@ extern "C" int clite_set_tile_policy(int policy) {
   return 0;
 }
 
+int clite::tile_policy_value() { return g_tile_policy.load(std::memory_order_relaxed); }
+
 bool clite_group_wide_enabled() { return g_tile_policy.load(std::memory_order_relaxed) != 4; }
 
 int clite::launch_wide(const WideOperand& a, const WideOperand& b, const clite_epilogue& ep, const RowMap& rm, int M, int N, int Ktot, int splits, hipStream_t st) {

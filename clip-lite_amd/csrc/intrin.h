@@ -50,6 +50,9 @@ DEV void buf_load16_lds(rsrc_t r, uint32_t off, void* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, off, 0, 0, 0);
 }
 template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Makes a value opaque to the optimiser at this point (no instruction): everything derived from it afterwards is computed where it is used
+// instead of being hoisted out of an enclosing loop into dozens of live registers.
+DEV void opaque_i(int& v) { asm volatile("" : "+v"(v)); }
 DEV void barrier_raw() { __builtin_amdgcn_s_barrier(); }   // no implied vmcnt(0): LDS-DMA may stay in flight across it
 // Workgroup barrier that orders LDS traffic only: waits for this wave's LDS operations (lgkmcnt), NOT for its global loads / stores.
 // __syncthreads() also drains vmcnt, i.e. every epilogue barrier would wait for the stores just issued to reach L2 (~1.5 us each).

@@ -17,6 +17,11 @@ struct WideOperand {      // one GEMM operand as the loaders of igemm_wide.h / i
 constexpr int WIDE_NOT_TAKEN = -1000;
 // bf16 only. Returns WIDE_NOT_TAKEN when the launch stays on the 4-wave kernels (shape, policy), else the HIP status of the launch.
 int launch_wide(const WideOperand& a, const WideOperand& b, const clite_epilogue& ep, const RowMap& rm, int M, int N, int Ktot, int splits, hipStream_t st);
+// conv_patch.hip: the patch-resident 3 x 3 / stride 1 kernel for 64 -> 64 channels (bf16), forward (w = [K][3][3][C]) or input gradient on the
+// transposed weights (dgrad: x = dy, w = [C][3][3][K]). Returns WIDE_NOT_TAKEN for every launch it does not cover.
+int launch_conv3x3_patch(const void* x, const void* w, const clite_conv& c, const clite_epilogue& ep, bool dgrad, hipStream_t st);
+// the tile policy set by clite_set_tile_policy (gemm_wide.hip): 0 = automatic; the forced forms keep every launch on the kernel family they name
+int tile_policy_value();
 
 }  // namespace clite
 #endif

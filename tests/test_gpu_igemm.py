@@ -288,3 +288,49 @@ def test_grouped_weight_gradients_match_members(tile_policy):
                 assert _rel(got, ref) < 2e-3
         finally:
             hip.set_deterministic(False)
+
+
+@pytest.mark.parametrize("N,H,W", [(8, 56, 56), (5, 28, 28), (3, 30, 44), (300, 14, 14)])
+def test_patch_resident_conv3x3_64ch(N, H, W, tile_policy):
+    """conv_patch.hip (taken under the automatic policy; every forced policy runs the implicit-GEMM kernels on the same launch, so this case also
+    checks those against the same references): 3 x 3 / stride 1 / pad 1, 64 -> 64 channels, bf16 — forward with the per-channel statistics of the
+    stored values, the input gradient on the transposed weights with a plain store and in the BatchNorm-backward form (packed relu' bits, sum v,
+    sum v (bn_y - mean)). Against torch fp32 convolutions of the same bf16 inputs: 6e-3 of max|ref| (one bf16 rounding of the output), statistics
+    1e-3 of their own magnitude. Shapes: the step's 56 x 56 (7 strips per workgroup would need 1792 strips: N = 8 gives 112 strips on 112
+    workgroups; N = 300 at 14 x 14 gives 300 whole-image strips on 256 workgroups, i.e. two strips for some), 28 x 28 (9-row strips, ragged last
+    strip), 30 x 44 (5-row strips)."""
+    hip = _hip()
+    g = torch.Generator(device="cuda").manual_seed(N + H + W)
+    C = 64
+    x, dy = _t((N, H, W, C), g, BF16), _t((N, H, W, C), g, BF16)
+    w = _t((C, 3, 3, C), g, BF16, 0.1)
+    cv = hip.conv_desc(BF16, N, H, W, C, C, 3, 3, 1, 1)
+    M = N * H * W
+    y = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+    st = hip.Stats(torch.zeros(4 * 3 * C, device="cuda"), 4, C)
+    hip.conv_fwd(x, w, cv, hip.epilogue(y, C, colsum=st))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).reshape(M, C)
+    assert _rel(y, ref) < 6e-3
+    s = st.t.view(4, 3, C).sum(0)
+    yf = y.float()
+    assert _rel(s[0], yf.sum(0)) < 1e-3 and _rel(s[1], (yf * yf).sum(0)) < 1e-3 and not s[2].any()
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    xin = torch.zeros(N, C, H, W, device="cuda", requires_grad=True)
+    gref = torch.autograd.grad(F.conv2d(xin, w.float().permute(0, 3, 1, 2), padding=1), xin, dy.float().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1).reshape(M, C)
+    dx = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+    hip.conv_dgrad(dy, wt, cv, hip.epilogue(dx, C), wt=True)
+    assert _rel(dx, gref) < 6e-3
+    aux = torch.randn(M, C, device="cuda", generator=g)
+    bits = torch.from_numpy(__import__("numpy").packbits((aux > 0).cpu().numpy(), axis=-1, bitorder="little")).cuda()
+    by = _t((M, C), g, BF16) + 3
+    fst = hip.Stats(torch.zeros(2 * 3 * C, device="cuda"), 2, C)
+    fst.t.view(2, 3, C)[:, 0] = by.float().sum(0) / 2
+    dst = hip.Stats(torch.zeros(2 * 3 * C, device="cuda"), 2, C)
+    out = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
+    hip.conv_dgrad(dy, wt, cv, hip.epilogue(out, C, relu_bits=bits, colsum=dst, bn=(by, fst, M)), wt=True)
+    want = gref * (aux > 0)
+    assert _rel(out, want) < 6e-3
+    of = out.float()
+    d = dst.t.view(2, 3, C).sum(0)
+    mean = by.float().sum(0) / M
+    assert _rel(d[0], of.sum(0)) < 1e-3 and _rel(d[1], (of * (by.float() - mean)).sum(0)) < 2e-3

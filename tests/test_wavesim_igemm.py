@@ -516,3 +516,66 @@ def test_bert_epilogue_forms_compiled_in(M, N, K, tile_policy):
     _close(res[0], res[1], 6e-3)
     keep = ~dropped
     _close(res[0][keep], ((z + bias) / 0.75 + R)[keep], 6e-3)
+
+
+@pytest.mark.policy_independent
+@pytest.mark.parametrize("N,H,W", [(3, 10, 12), (2, 9, 40), (1, 8, 56)])
+def test_patch_resident_conv3x3_64ch(N, H, W):
+    """conv_patch.hip: the patch-resident 3 x 3 / stride 1 kernel for 64 -> 64 channels (taken under the automatic tile policy only) — forward with
+    the per-channel statistics, the plain input gradient on transposed weights, and the BatchNorm-backward form (packed relu' bits + the two
+    reductions) — against the numpy references, and bit-for-bit in its stored values' statistics. The simulator build runs 2 persistent
+    workgroups, so these cases walk several strips per workgroup (double-buffered patches), ragged last strips (H = 9 with 6-row strips) and
+    MFMA row blocks that cross strip rows (W = 12, 40, 56)."""
+    assert lib().clite_set_tile_policy(0) == 0
+    rng = np.random.default_rng(H * W)
+    Cc = K = 64
+    cv = Conv(BF16, N, H, W, Cc, K, 3, 3, 1, 1, H, W)
+    M = N * H * W
+    x, xb = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), BF16)
+    w, wb = _prep(rng.standard_normal((K, 3, 3, Cc), dtype=np.float32) * 0.1, BF16)
+    dy, dyb = _prep(rng.standard_normal((N, H, W, K), dtype=np.float32), BF16)
+    # forward
+    y = np.zeros((M, K), np.uint16)
+    csr = np.zeros((4, 3, K), np.float32)
+    ep = make_ep(y, K, colsum=csr)
+    ep.colsum_replicas, ep.colsum_stride = 4, 3 * K
+    assert lib().clite_conv_fwd(ptr(xb), ptr(wb), C.byref(cv), C.byref(ep), None) == 0
+    ref = conv_ref(x, w, 1, 1).reshape(M, K)
+    got = from_bf16(y)
+    _close(got, ref, 6e-3)
+    cs = csr.sum(0)
+    _close(cs[0], got.sum(0), 1e-4)               # statistics of the STORED (bf16-rounded) values
+    _close(cs[1], (got ** 2).sum(0), 1e-4)
+    assert not csr[:, 2].any()
+    # the 4-wave implicit-GEMM path on the same launch (policy 4) agrees
+    assert lib().clite_set_tile_policy(4) == 0
+    y4 = np.zeros((M, K), np.uint16)
+    ep4 = make_ep(y4, K)
+    assert lib().clite_conv_fwd(ptr(xb), ptr(wb), C.byref(cv), C.byref(ep4), None) == 0
+    assert lib().clite_set_tile_policy(0) == 0
+    _close(got, from_bf16(y4), 8e-3)
+    # input gradient on the transposed weights, plain store
+    wt, wtb = _prep(np.ascontiguousarray(w.transpose(3, 1, 2, 0)), BF16)
+    g = conv_dgrad_ref(dy, w, (N, H, W, Cc), 1, 1).reshape(M, Cc)
+    dx = np.zeros((M, Cc), np.uint16)
+    assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(make_ep(dx, Cc)), None) == 0
+    _close(from_bf16(dx), g, 6e-3)
+    # BatchNorm-backward form (igemm.h FORM 1): v = acc where the bit is set, sum v and sum v (bn_y - mean)
+    aux = rng.standard_normal((M, Cc)).astype(np.float32)
+    yb_v, ybb = _prep(rng.standard_normal((M, Cc), dtype=np.float32) + 3.0, BF16)
+    fstats = np.zeros((2, 3, Cc), np.float32)
+    fstats[:, 0] = yb_v.sum(0) / 2
+    bits = pack_relu_bits(aux)
+    out = np.zeros((M, Cc), np.uint16)
+    dst = np.zeros((2, 3, Cc), np.float32)
+    ep = make_ep(out, Cc, colsum=dst, relu_bits=bits)
+    ep.colsum_replicas, ep.colsum_stride = 2, 3 * Cc
+    ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = ptr(ybb), ptr(fstats), 2, 3 * Cc, 1.0 / M
+    assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == 0
+    gv = from_bf16(out)
+    _close(gv, g * (aux > 0), 6e-3)
+    assert ((gv == 0) | (aux > 0)).all()
+    d = dst.sum(0)
+    _close(d[0], gv.sum(0), 1e-4)
+    _close(d[1], (gv * (yb_v - fstats[:, 0].sum(0) / M)).sum(0), 2e-3)
+    assert not d[2].any()

@@ -171,6 +171,7 @@ inline void buf_load16_lds(rsrc_t r, uint32_t off, void* lds_wave_base) {
   memcpy((char*)lds_wave_base + wavesim::g_lane * 16, &v, 16);
 }
 template <int N> inline void wait_vmcnt() {}
+inline void opaque_i(int&) {}
 inline void barrier_raw() { __syncthreads(); }
 inline void lds_barrier() { __syncthreads(); }
 
