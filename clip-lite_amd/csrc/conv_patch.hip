@@ -29,6 +29,10 @@
 
 using namespace clite;
 
+#ifndef CLITE_PATCH_WGS
+#define CLITE_PATCH_WGS 256          // one persistent workgroup per CU (the simulator build uses 2, so that its small cases walk several strips)
+#endif
+
 namespace {
 
 constexpr int PC = 64;                        // channels in = channels out
@@ -54,6 +58,14 @@ struct PatchArgs {
   int flip;                   // 1: tap t reads the weight's tap 8 - t (input gradient on [C][R][S][K] weights)
 };
 
+#ifndef CLITE_PATCH_NT
+#define CLITE_PATCH_NT 1              // 1: the strips' input patches / dy rows are loaded with the non-temporal policy (each byte is read by one CU, once or twice)
+#endif
+#if CLITE_PATCH_NT
+#define PATCH_LOAD buf_load16_lds_nt
+#else
+#define PATCH_LOAD buf_load16_lds
+#endif
 #ifndef CLITE_PATCH_ABLATE
 #define CLITE_PATCH_ABLATE 0          // diagnostic variant builds only (tools/probe_patch.py): 1 = no MFMA loop, 2 = no global stores, 4 = no patch DMA after the first
 #endif
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(PatchArgs a, Epilogu
       const int i = wave + 8 * k;
       if (i < NPI) {          // wave-uniform
         const bool v = p_row[k] >= 0 && (unsigned)(y0 + p_row[k] - 1) < (unsigned)a.H;
-        buf_load16_lds(rx, v ? (uint32_t)((base + p_rel[k]) * 2) : OOB_OFF, dst + i * 1024);
+        PATCH_LOAD(rx, v ? (uint32_t)((base + p_rel[k]) * 2) : OOB_OFF, dst + i * 1024);
       }
     }
   };
@@ -295,6 +307,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(PatchArgs a, Epilogu
 
 // Returns WIDE_NOT_TAKEN when the launch is not one this kernel covers (the caller then takes the implicit-GEMM path).
 int clite::launch_conv3x3_patch(const void* x, const void* w, const clite_conv& c, const clite_epilogue& ep, bool dgrad, hipStream_t st) {
+#ifdef CLITE_NO_PATCH          // A/B builds only (tools/build_patch_variants.sh): every launch on the implicit-GEMM path
+  return WIDE_NOT_TAKEN;
+#endif
   if (c.dtype != CLITE_BF16 || c.C != PC || c.K != PC || c.R != 3 || c.S != 3 || c.stride != 1 || c.pad != 1 || c.Ho != c.H || c.Wo != c.W) return WIDE_NOT_TAKEN;
   if (ep.ldc != PC || ep.atomic || ep.out_f32 || ep.alpha != 1.f || ep.bias || ep.act != CLITE_ACT_NONE || ep.preact || ep.dact_aux || ep.drop_p > 0.f ||
       ep.residual || ep.mask_after_residual || ep.splitk_ws)
@@ -315,13 +330,228 @@ int clite::launch_conv3x3_patch(const void* x, const void* w, const clite_conv& 
   a.strips_per_img = (c.H + R - 1) / R;
   a.nstrips = c.N * a.strips_per_img;
   a.flip = dgrad ? 1 : 0;
-#ifndef CLITE_PATCH_WGS
-#define CLITE_PATCH_WGS 256          // one persistent workgroup per CU (the simulator build uses 2, so that its small cases walk several strips)
-#endif
   const int grid = a.nstrips < CLITE_PATCH_WGS ? a.nstrips : CLITE_PATCH_WGS;
   const int per = (a.nstrips + grid - 1) / grid;
   const int g2 = (a.nstrips + per - 1) / per;
   if (form == 0) hipLaunchKernelGGL(conv3x3_patch_kernel<0>, dim3(g2), dim3(512), 0, st, a, ep, per);
   else hipLaunchKernelGGL(conv3x3_patch_kernel<1>, dim3(g2), dim3(512), 0, st, a, ep, per);
+  return (int)hipGetLastError();
+}
+
+// =====================================================================================================================================
+// Patch-resident WEIGHT GRADIENT of the same convolution: dW[co][r][s][ci] (f32) += sum over pixels of dy[p][co] * x[p + (r - 1, s - 1)][ci].
+//
+// In the grouped implicit-GEMM form a 64 -> 64 3 x 3 member at 56 x 56 takes 97 us for an HBM ideal of 19: its output is tiny (64 x 576) and its
+// contraction enormous (401 408 pixels), every workgroup owns a [64][128-column] output tile, so dy is streamed once per column tile (5 x) and
+// every input pixel is gathered nine times (tools/probe_wgrad_s2.py). Here ONE workgroup owns the WHOLE 64 x 9 x 64 output
+// in registers (36 MFMA blocks over 8 waves: waves 0-3 a tap each plus a quarter of tap 8, waves 4-7 a tap each) and walks a contiguous range
+// of strips; per strip the dy rows and the input patch land ONCE in LDS (double-buffered LDS-DMA) and all nine taps read the patch at shifted
+// addresses. Both operands are contracted over the PIXEL index, so both LDS images are [pixel][64 channels] and every fragment is a pair of
+// `ds_read_b64_tr_b16` transposed reads (igemm_dma.h's XC image).
+//
+// Flat pixel index. dy pixel (oy, ox) of the strip sits at g = oy (W + 1) + ox; the entries with ox = W, and everything past the strip, are ZERO
+// (out-of-range DMA sources), so the contraction simply runs over all flat indices 0 .. 16 ceil(R (W + 1) / 16) - 1: a zero dy contributes
+// nothing. The input patch uses conv3x3_patch_kernel's flat layout, in which tap (r, s) of pixel g is patch entry g + r (W + 1) + s — one shared
+// zero column serves as the right halo of a row and the left halo of the next.
+// Swizzle: the 64-byte half h of pixel p sits in half h ^ ((p >> 1) & 1): the four consecutive pixels a 16-lane group of a transposed read touches
+// then cover four different 16-bank groups whatever the tap's shift (p and p + 4 swizzle alike, as the second read of a fragment needs).
+//
+// The partial sums of a workgroup (36 864 floats) go to its slab of a workspace; wgrad_patch_reduce_kernel adds the slabs into dW. (Float atomics
+// straight into dW would be 37.7 MB of atomic traffic at ~1.3 TB/s: 29 us; slabs + reduction move the same bytes at HBM rate.)
+namespace {
+
+constexpr int WG_DYPIX = 256;                       // flat dy entries per strip = 16 k-steps of 16 (R (W + 1) <= 256; the K loop runs an even number of k-steps)
+constexpr int WG_XPIX = 376;                        // patch entries reachable: 255 + 2 (W + 1) + 2 <= 375 for W <= 58
+constexpr int WG_DYB = WG_DYPIX * PIXB, WG_XB = WG_XPIX * PIXB, WG_STAGE = WG_DYB + WG_XB;
+constexpr int WG_NI_DY = WG_DYPIX / 8, WG_NI_X = WG_XPIX / 8;             // DMA instructions per strip
+constexpr int WG_NW_DY = (WG_NI_DY + 7) / 8, WG_NW_X = (WG_NI_X + 7) / 8;  // ... per wave
+constexpr int WG_OUT = NTAP * PC * PC;              // 36 864 partial sums per workgroup
+static_assert(2 * WG_STAGE <= 160 * 1024, "LDS budget");
+
+struct WgradPatchArgs {
+  const void* dy;
+  const void* x;
+  uint32_t bytes;             // of either tensor
+  int N, H, W, R;
+  int strips_per_img, nstrips;
+  float* ws;                  // [gridDim.x][9][64][64] f32 slabs
+};
+
+// Fragment of a [pixel][64 ch] image: 32 channels starting at x0, 16 pixels starting at pixel pix0 + k0 (igemm_dma.h DmaXCStrided::frag_off /
+// frag_at with this kernel's swizzle). For k0 a multiple of 4 the swizzle bit of pixel pix0 + k0 + j equals that of pix0 + j, so the byte offset
+// is wg_frag_base(pix0, ...) + k0 * 128: the K loop adds a compile-time immediate to a per-lane base and spends no VALU on addresses (with them
+// computed per fragment the loop was issue-bound: ~60 VALU + 36 LDS instructions per k-step and SIMD against 9 MFMAs).
+DEV int wg_frag_base(int pix0, int x0, int lane) {
+  const int x = x0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int pix = pix0 + 8 * (lane >> 5) + ((lane >> 2) & 3);
+  const int b = x * 2;
+  return pix * PIXB + ((((b >> 6) ^ (pix >> 1)) & 1) << 6) + (b & 63);
+}
+DEV bf16x8 wg_frag_at(const char* p) {
+  const s16x4 lo = lds_read_tr16(p);
+  const s16x4 hi = lds_read_tr16(p + 4 * PIXB);
+  union { s16x4 v[2]; bf16x8 h; } u;
+  u.v[0] = lo; u.v[1] = hi;
+  return u.h;
+}
+
+__global__ __launch_bounds__(512) void conv3x3_wgrad_patch_kernel(WgradPatchArgs a, int strips_per_wg) {
+  __shared__ __attribute__((aligned(1024))) char smem[2 * WG_STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int W1 = a.W + 1;
+
+  int s_begin = blockIdx.x * strips_per_wg, s_end = s_begin + strips_per_wg;
+  if (s_end > a.nstrips) s_end = a.nstrips;
+
+  const rsrc_t rdy = make_rsrc(a.dy, a.bytes), rx = make_rsrc(a.x, a.bytes);
+  // per-lane constants of this wave's DMA instructions
+  int d_rel[WG_NW_DY], d_row[WG_NW_DY], x_rel[WG_NW_X], x_row[WG_NW_X];
+#pragma unroll
+  for (int k = 0; k < WG_NW_DY; ++k) {
+    const int i = wave + 8 * k;
+    const int pix = i * 8 + (lane >> 3);
+    const int oy = pix / W1, ox = pix - oy * W1;
+    const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
+    const bool ok = i < WG_NI_DY && ox < a.W && oy < a.R;
+    d_row[k] = ok ? oy : -1;
+    d_rel[k] = (oy * a.W + ox) * PC + chunk * 8;
+  }
+#pragma unroll
+  for (int k = 0; k < WG_NW_X; ++k) {
+    const int i = wave + 8 * k;
+    const int pix = i * 8 + (lane >> 3);
+    const int pr = pix / W1, pc = pix - pr * W1;
+    const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
+    const bool ok = i < WG_NI_X && pc >= 1 && pc <= a.W && pr <= a.R + 1;
+    x_row[k] = ok ? pr : -1;
+    x_rel[k] = ((pr - 1) * a.W + (pc - 1)) * PC + chunk * 8;
+  }
+  auto issue = [&](int strip, char* dst) {
+    const int n = strip / a.strips_per_img;
+    const int y0 = (strip - n * a.strips_per_img) * a.R;
+    const int base = (n * a.H + y0) * a.W * PC;
+#pragma unroll
+    for (int k = 0; k < WG_NW_DY; ++k) {
+      const int i = wave + 8 * k;
+      if (i < WG_NI_DY) {
+        const bool v = d_row[k] >= 0 && y0 + d_row[k] < a.H;
+        PATCH_LOAD(rdy, v ? (uint32_t)((base + d_rel[k]) * 2) : OOB_OFF, dst + i * 1024);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WG_NW_X; ++k) {
+      const int i = wave + 8 * k;
+      if (i < WG_NI_X) {
+        const bool v = x_row[k] >= 0 && (unsigned)(y0 + x_row[k] - 1) < (unsigned)a.H;
+        PATCH_LOAD(rx, v ? (uint32_t)((base + x_rel[k]) * 2) : OOB_OFF, dst + WG_DYB + i * 1024);
+      }
+    }
+  };
+
+  // this wave's blocks: its own tap (2 x 2 blocks of 32 x 32) and, for waves 0-3, block (wave >> 1, wave & 1) of tap 8
+  const int tap = wave;
+  const int shift = (tap / 3) * W1 + (tap % 3);
+  const int shift8 = 2 * W1 + 2;
+  const bool extra = wave < 4;
+  // per-lane byte offsets of the five fragments at k-step 0 (dy: both channel halves; x: this wave's tap, both halves; tap 8: one half)
+  const int oa0 = wg_frag_base(0, 0, lane), oa1 = wg_frag_base(0, 32, lane);
+  const int ob0 = wg_frag_base(shift, 0, lane), ob1 = wg_frag_base(shift, 32, lane), o8 = wg_frag_base(shift8, 32 * (wave & 1), lane);
+  f32x16 acc[2][2], acc8;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f; acc8[r] = 0.f; }
+
+  if (s_begin < s_end) issue(s_begin, smem);
+  for (int strip = s_begin; strip < s_end; ++strip) {
+    const int cur = (strip - s_begin) & 1;
+    wait_vmcnt<0>();
+    lds_barrier();          // strip's images landed (every wave's part); every wave is past the K loop that read the other stage
+    if (strip + 1 < s_end) issue(strip + 1, smem + (cur ^ 1) * WG_STAGE);
+    const char* dyi = smem + cur * WG_STAGE;
+    const char* xi = dyi + WG_DYB;
+    // 16 k-steps of 16 flat pixels, always (the dy image is zero past the strip), fully unrolled: immediate offsets, the next k-step's fragments
+    // requested ahead of this one's MFMAs; compile-time block count per wave class (no wave-uniform branch between reads and MFMAs)
+    auto kloop = [&](auto extra_tag) {
+      constexpr bool EXTRA = decltype(extra_tag)::value;
+      const char* pa0 = dyi + oa0; const char* pa1 = dyi + oa1;
+      const char* pb0 = xi + ob0; const char* pb1 = xi + ob1; const char* p8 = xi + o8;
+      bf16x8 fa[2][2], fb[2][2], f8[2];
+      auto load = [&](int set, int ks) {
+        fa[set][0] = wg_frag_at(pa0 + ks * 16 * PIXB); fa[set][1] = wg_frag_at(pa1 + ks * 16 * PIXB);
+        fb[set][0] = wg_frag_at(pb0 + ks * 16 * PIXB); fb[set][1] = wg_frag_at(pb1 + ks * 16 * PIXB);
+        if (EXTRA) f8[set] = wg_frag_at(p8 + ks * 16 * PIXB);
+      };
+      load(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < WG_DYPIX / 16; ++ks) {
+        const int c = ks & 1;
+        if (ks + 1 < WG_DYPIX / 16) load(c ^ 1, ks + 1);
+        acc[0][0] = mfma32_bf16(fa[c][0], fb[c][0], acc[0][0]);
+        acc[0][1] = mfma32_bf16(fa[c][0], fb[c][1], acc[0][1]);
+        acc[1][0] = mfma32_bf16(fa[c][1], fb[c][0], acc[1][0]);
+        acc[1][1] = mfma32_bf16(fa[c][1], fb[c][1], acc[1][1]);
+        if (EXTRA) acc8 = mfma32_bf16((wave >> 1) ? fa[c][1] : fa[c][0], f8[c], acc8);
+      }
+    };
+    if (extra) kloop(std::true_type{}); else kloop(std::false_type{});
+  }
+
+  // partial sums -> this workgroup's slab [tap][co][ci]; lane l holds D[co = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][ci = l & 31] of a block
+  float* slab = a.ws + (size_t)blockIdx.x * WG_OUT;
+  auto put = [&](const f32x16& v, int t, int cob, int cib) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = cob * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      slab[(t * PC + co) * PC + cib * 32 + (lane & 31)] = v[r];
+    }
+  };
+  put(acc[0][0], tap, 0, 0); put(acc[0][1], tap, 0, 1); put(acc[1][0], tap, 1, 0); put(acc[1][1], tap, 1, 1);
+  if (extra) put(acc8, 8, wave >> 1, wave & 1);
+}
+
+// dw[co][t][ci] += sum over slabs of ws[b][t][co][ci]; grid (144, 16): each workgroup sums a sixteenth of the slabs for 256 outputs (four independent
+// chains per thread: the loop is load latency, not arithmetic)
+__global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslabs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;          // index into [t][co][ci]
+  const int per = (nslabs + gridDim.y - 1) / gridDim.y;
+  int b0 = blockIdx.y * per, b1 = b0 + per;
+  if (b1 > nslabs) b1 = nslabs;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    s0 += ws[(size_t)b * WG_OUT + i]; s1 += ws[(size_t)(b + 1) * WG_OUT + i]; s2 += ws[(size_t)(b + 2) * WG_OUT + i]; s3 += ws[(size_t)(b + 3) * WG_OUT + i];
+  }
+  for (; b < b1; ++b) s0 += ws[(size_t)b * WG_OUT + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  const int t = i / (PC * PC), co = (i / PC) % PC, ci = i % PC;
+  if (b0 < b1) atomic_add_f32(dw + (co * NTAP + t) * PC + ci, s);
+}
+
+}  // namespace
+
+size_t clite::conv3x3_wgrad_patch_workspace() { return (size_t)CLITE_PATCH_WGS * WG_OUT * sizeof(float); }
+
+int clite::launch_conv3x3_wgrad_patch(const void* dy, const void* x, const clite_conv& c, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+#ifdef CLITE_NO_PATCH
+  return WIDE_NOT_TAKEN;
+#endif
+  if (c.dtype != CLITE_BF16 || c.C != PC || c.K != PC || c.R != 3 || c.S != 3 || c.stride != 1 || c.pad != 1 || c.Ho != c.H || c.Wo != c.W) return WIDE_NOT_TAKEN;
+  if (!ws || ws_bytes < conv3x3_wgrad_patch_workspace() || c.W + 1 > 59) return WIDE_NOT_TAKEN;
+  int R = WG_DYPIX / (c.W + 1);
+  if (R > c.H) R = c.H;
+  while (R >= 1 && ((R + 2) * (c.W + 1) + 1 > WG_XPIX || WG_DYPIX + 2 * (c.W + 1) + 2 > WG_XPIX)) --R;
+  if (R < 1) return WIDE_NOT_TAKEN;
+  WgradPatchArgs a;
+  a.dy = dy; a.x = x; a.bytes = (uint32_t)((size_t)c.N * c.H * c.W * PC * 2);
+  a.N = c.N; a.H = c.H; a.W = c.W; a.R = R;
+  a.strips_per_img = (c.H + R - 1) / R;
+  a.nstrips = c.N * a.strips_per_img;
+  a.ws = (float*)ws;
+  const int grid = a.nstrips < CLITE_PATCH_WGS ? a.nstrips : CLITE_PATCH_WGS;
+  const int per = (a.nstrips + grid - 1) / grid;
+  const int g2 = (a.nstrips + per - 1) / per;
+  hipLaunchKernelGGL(conv3x3_wgrad_patch_kernel, dim3(g2), dim3(512), 0, st, a, per);
+  hipLaunchKernelGGL(wgrad_patch_reduce_kernel, dim3(WG_OUT / 256, 16), dim3(256), 0, st, (const float*)ws, dw, g2);
   return (int)hipGetLastError();
 }

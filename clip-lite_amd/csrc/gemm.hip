@@ -730,6 +730,20 @@ extern "C" int clite_conv_wgrad(const void* dy, const void* x, const clite_conv*
   return cv->dtype == CLITE_BF16 ? conv_wgrad<bf16>(dy, x, *cv, dw, (hipStream_t)stream) : conv_wgrad<float>(dy, x, *cv, dw, (hipStream_t)stream);
 }
 
+// The 64 -> 64 3 x 3 / stride 1 weight gradient on the patch-resident kernel (conv_patch.hip). Returns 1 when the problem is not one it covers
+// (shape, dtype, workspace too small, deterministic mode, a forced tile policy): the caller then takes clite_conv_wgrad / the grouped launch.
+extern "C" int clite_conv_wgrad_patch_workspace(unsigned long long* nbytes) {
+  if (!nbytes) return -1;
+  *nbytes = (unsigned long long)conv3x3_wgrad_patch_workspace();
+  return 0;
+}
+extern "C" int clite_conv_wgrad_patch(const void* dy, const void* x, const clite_conv* cv, float* dw, void* ws, unsigned long long ws_bytes, void* stream) {
+  if (check_conv(cv) || !dw) return -1;
+  if (deterministic() || tile_policy_value() != 0) return 1;
+  const int rc = launch_conv3x3_wgrad_patch(dy, x, *cv, dw, ws, (size_t)ws_bytes, (hipStream_t)stream);
+  return rc == WIDE_NOT_TAKEN ? 1 : rc;
+}
+
 extern "C" int clite_stem_fwd(const void* xpad, const void* wv, int dtype, int N, int Hp, int Wp, int Ho, int Wo, const clite_epilogue* ep, void* stream) {
   if (check_stem(dtype, N, Hp, Wp, Ho, Wo) || check_ep(ep, 64)) return -1;
   return dtype == CLITE_BF16 ? stem_fwd<bf16>(xpad, wv, N, Hp, Wp, Ho, Wo, ep, (hipStream_t)stream)

@@ -49,6 +49,10 @@ DEV void buf_store4(rsrc_t r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_b
 DEV void buf_load16_lds(rsrc_t r, uint32_t off, void* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, off, 0, 0, 0);
 }
+// ... with the non-temporal cache policy (aux = 2, `nt`): for bytes that ONE CU reads once (MI355X_MICROARCH.md, nt-weights)
+DEV void buf_load16_lds_nt(rsrc_t r, uint32_t off, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, off, 0, 0, 2);
+}
 template <int N> DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // Makes a value opaque to the optimiser at this point (no instruction): everything derived from it afterwards is computed where it is used
 // instead of being hoisted out of an enclosing loop into dozens of live registers.

@@ -20,6 +20,9 @@ int launch_wide(const WideOperand& a, const WideOperand& b, const clite_epilogue
 // conv_patch.hip: the patch-resident 3 x 3 / stride 1 kernel for 64 -> 64 channels (bf16), forward (w = [K][3][3][C]) or input gradient on the
 // transposed weights (dgrad: x = dy, w = [C][3][3][K]). Returns WIDE_NOT_TAKEN for every launch it does not cover.
 int launch_conv3x3_patch(const void* x, const void* w, const clite_conv& c, const clite_epilogue& ep, bool dgrad, hipStream_t st);
+// ... and its weight gradient (dw f32 [K][3][3][C] += ...) through a workspace of conv3x3_wgrad_patch_workspace() bytes (per-workgroup partial sums)
+size_t conv3x3_wgrad_patch_workspace();
+int launch_conv3x3_wgrad_patch(const void* dy, const void* x, const clite_conv& c, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // the tile policy set by clite_set_tile_policy (gemm_wide.hip): 0 = automatic; the forced forms keep every launch on the kernel family they name
 int tile_policy_value();
 

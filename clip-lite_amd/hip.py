@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -81,6 +81,8 @@ _SIGNATURES = {
     "clite_conv_dgrad_s2class_wt": [_V, _V, _V, _I, _I, _V, _V],
     "clite_transpose_weights": [_V, _V, _V, _I, _U32, _V],
     "clite_conv_wgrad": [_V, _V, _V, _V, _V],
+    "clite_conv_wgrad_patch_workspace": [_V],
+    "clite_conv_wgrad_patch": [_V, _V, _V, _V, _V, _U64, _V],
     "clite_wgrad_group": [_I, _V, _I, _V, _V, _U64, _V],
     "clite_fp8_quantize": [_I, _V, _U64, _V, _V, _V, _V],
     "clite_gemm_nt_fp8": [_V, _I, _V, _I, _I, _I, _I, _V, _V, _V, _V],
@@ -310,6 +312,41 @@ def conv_wgrad(dy, x, cv, dw):
     check(lib().clite_conv_wgrad(p(dy), p(x), C.byref(cv), p(dw), stream_ptr(dy)), "conv_wgrad")
 
 
+_patch_ws = {}          # device -> scratch of clite_conv_wgrad_patch_workspace() bytes (the kernel's per-workgroup partial sums: no state between calls)
+
+
+def conv_wgrad_patch_applies(cv):
+    """The problems clite_conv_wgrad_patch covers by shape (bf16, 3 x 3 / stride 1 / pad 1, 64 -> 64, rows of at most 58 pixels); the library
+    still declines (returns 1) in the deterministic mode or under a forced tile policy."""
+    return cv.dtype == BF16 and cv.C == 64 and cv.K == 64 and cv.R == 3 and cv.S == 3 and cv.stride == 1 and cv.pad == 1 and cv.W <= 58
+
+
+def patch_workspace(device):
+    """The device's scratch for clite_conv_wgrad_patch (37.7 MB). DeviceRuntime creates it when the model moves to the GPU, i.e. before any
+    stream capture; a first use INSIDE a capture would put it into the graph's private pool."""
+    device = torch.device(device)
+    ws = _patch_ws.get(device)
+    if ws is None:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("clip_lite_amd: the patch-resident weight gradient's workspace must exist before a stream capture (hip.patch_workspace)")
+        n = C.c_uint64(0)
+        check(lib().clite_conv_wgrad_patch_workspace(C.byref(n)), "conv_wgrad_patch_workspace")
+        ws = _patch_ws[device] = torch.empty(n.value, dtype=torch.uint8, device=device)
+    return ws
+
+
+def conv_wgrad_patch(dy, x, cv, dw):
+    """dw += the weight gradient on the patch-resident kernel; falls back to clite_conv_wgrad when the library declines. Launches on the current
+    stream. Every call on one device shares one scratch buffer: the members of a backward pass that qualify (ResNet layer1's 3 x 3 convolutions)
+    all belong to ONE weight-gradient group, i.e. one stream, which orders them."""
+    ws = patch_workspace(dy.device)
+    rc = lib().clite_conv_wgrad_patch(p(dy), p(x), C.byref(cv), p(dw), p(ws), ws.numel(), stream_ptr(dy))
+    if rc == 1:
+        conv_wgrad(dy, x, cv, dw)
+    else:
+        check(rc, "conv_wgrad_patch")
+
+
 import collections
 _inflight_groups = collections.deque()
 _ws_pool = []          # [(event recorded behind the last launch that used it, device workspace, pinned host workspace)] of uncaptured WgradGroup launches
@@ -344,7 +381,20 @@ class WgradGroup:
         kt = (K + 31) // 32
         return ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * ((kt + KCHUNK_TILES - 1) // KCHUNK_TILES)
 
+    # class-wide switch: True sends the 64 -> 64 3 x 3 members to the patch-resident kernel (clite_conv_wgrad_patch) instead of the grouped launch.
+    # OFF: stand-alone the kernel takes 45 + 8 us per member where the member alone in a group takes 97 — but INSIDE layer1's group the three
+    # members cost ~25 us each of marginal time (they fill slots the HBM-bound 1 x 1 members leave idle), and three launches behind the group were
+    # measured 0.1 ms slower per step (same box, tools/ab_runtime.py hip.WgradGroup.patch=1: 15.34 / 15.46 vs 15.22 / 15.36 ms). Kept for the
+    # ungrouped paths (hip.conv_wgrad_patch) and as a tested entry point of the C ABI.
+    patch = False
+
     def conv(self, dy, x, cv, dw):
+        if self.patch and self.wide and conv_wgrad_patch_applies(cv) and not is_deterministic():
+            # the 64 -> 64 3 x 3 members run on the patch-resident kernel behind the grouped launch (97 -> ~30 us each): a launch of their own,
+            # on the stream of launch()
+            self.keep += [dy, x, dw]
+            self.extra.append(lambda: conv_wgrad_patch(dy, x, cv, dw))
+            return
         it = WgradItem()
         it.kind, it.a, it.b, it.out, it.cv = (0 if self.wide else 0x100), p(dy), p(x), p(dw), cv
         self.items.append(it)
@@ -364,7 +414,13 @@ class WgradGroup:
     def call(self, fn):
         self.extra.append(fn)
 
-    def launch(self):
+    def launch_extras(self):
+        """The members that are launches of their own (bias column sums, the stem's packed gradient, the patch-resident 3 x 3 weight gradients):
+        on the current stream. The captured step runs the last segment's on the text encoder's stream, beside the grouped launch."""
+        for fn in self.extra:
+            fn()
+
+    def launch(self, extras=True):
         if self.items:
             arr = (WgradItem * len(self.items))(*self.items)
             first = self.keep[0]
@@ -396,8 +452,8 @@ class WgradGroup:
                 while _inflight_groups and _inflight_groups[0][0].query():
                     _inflight_groups.popleft()
                 _inflight_groups.append((ev, self))
-        for fn in self.extra:
-            fn()
+        if extras:
+            self.launch_extras()
 
 
 class Fp8Tensor:

@@ -310,6 +310,8 @@ class DeviceRuntime:
         self.fp8_text = False              # ... and BERT's forward linears (stand-alone quantiser, current scaling: slower than bf16 — kept for the kernel's tests)
         self.fp8_nets = {}                 # id(ResNet) -> fp8.Fp8Forward
         self.group_wgrad = bool(lowp)      # weight gradients of a backward pass as grouped launches (hip.WgradGroup / clite_wgrad_group)
+        if lowp and self.device.type == "cuda":
+            hip.patch_workspace(self.device)          # scratch of the patch-resident 3 x 3 weight gradient: must exist before any stream capture
         self._aux_streams, self._aux_busy, self._aux_keep, self.overlap_wgrad = {}, set(), {}, False
         self.steps = 0
         self.seed_dev, self._capturing, self._slots, self.graph_slots, self._graph_next = None, False, 0, 0, -1

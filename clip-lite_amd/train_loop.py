@@ -257,7 +257,13 @@ class TrainStep:
             return fn
 
         def wgrad(i):
-            return lambda: keep["wg_" + segs[i]].launch()
+            # the last segment's members that are launches of their own (layer1's three patch-resident 3 x 3 weight gradients, the stem's weight
+            # gradient: ~0.35 ms) replay on the side stream, which is idle by then, beside the grouped launch on the main stream
+            last = i == len(segs) - 1
+            return lambda: keep["wg_" + segs[i]].launch(extras=not last)
+
+        def wgrad_last_extras():
+            keep["wg_" + segs[-1]].launch_extras()
 
         def text_bwd():
             keep["wg_t"] = hip.WgradGroup(rt.dt, ws["t"])          # BERT's 49 linear weight gradients: one grouped launch at the end of its backward
@@ -298,6 +304,7 @@ class TrainStep:
                 for i, sg in enumerate(segs):       # every segment's weight gradients but the last one's replay on the side stream
                     capture("image_bwd_" + sg, pool_main, image_bwd(i))
                     capture("wgrad_" + sg, pool_side if i < len(segs) - 1 else pool_main, wgrad(i))
+                capture("wgrad_last_extras", pool_side, wgrad_last_extras)
                 capture("norm", pool_main, norm)
                 capture("update_rest", pool_side, update_rest)
                 capture("update_img", pool_main, update_img)
@@ -350,10 +357,13 @@ class TrainStep:
             if ex is not None:                     # BatchNorm gradients came with the chain (main), weight gradients with the group (side, which waited for main)
                 ex.reduce_span(*self._seg_spans[i], after=side)
         G["image_bwd_" + self._segs[-1]].replay()
-        G["wgrad_" + self._segs[-1]].replay()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            G["wgrad_last_extras"].replay()        # three 3 x 3 weight gradients + the stem's, beside ...
+        G["wgrad_" + self._segs[-1]].replay()      # ... the grouped launch of the segment's 1 x 1 members
         if ex is not None:
-            ex.reduce_span(*self._seg_spans[-1], after=main)
             main.wait_stream(side)
+            ex.reduce_span(*self._seg_spans[-1], after=main)
             covered = sorted(self._regions.values())
             pos = 0
             for lo, hi in covered:                 # anything outside the three top-level modules (nothing, for VLInfoModel)

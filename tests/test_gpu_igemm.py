@@ -334,3 +334,26 @@ def test_patch_resident_conv3x3_64ch(N, H, W, tile_policy):
     d = dst.t.view(2, 3, C).sum(0)
     mean = by.float().sum(0) / M
     assert _rel(d[0], of.sum(0)) < 1e-3 and _rel(d[1], (of * (by.float() - mean)).sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("N,H,W", [(8, 56, 56), (5, 28, 28), (300, 14, 14)])
+def test_patch_resident_wgrad3x3_64ch(N, H, W, tile_policy):
+    """clite_conv_wgrad_patch (conv_patch.hip; through hip.conv_wgrad_patch, which falls back to clite_conv_wgrad when the library declines — under
+    every forced tile policy, so that path meets the same reference): dW [64][3][3][64] f32 += dy^T im2col(x) against torch's fp32 weight
+    gradient of the same bf16 operands, 2e-3 of max|ref|; accumulation into a non-zero dW."""
+    hip = _hip()
+    g = torch.Generator(device="cuda").manual_seed(N * H)
+    C = 64
+    x, dy = _t((N, H, W, C), g, BF16), _t((N, H, W, C), g, BF16)
+    cv = hip.conv_desc(BF16, N, H, W, C, C, 3, 3, 1, 1)
+    wz = torch.zeros(C, C, 3, 3, device="cuda", requires_grad=True)
+    ref = torch.autograd.grad(F.conv2d(x.float().permute(0, 3, 1, 2), wz, padding=1), wz, dy.float().permute(0, 3, 1, 2))[0].permute(0, 2, 3, 1)      # [K][R][S][C]
+    dw = torch.full((C, 3, 3, C), 0.25, device="cuda")
+    hip.conv_wgrad_patch(dy, x, cv, dw)
+    assert _rel(dw - 0.25, ref) < 2e-3
+    # as a member of a grouped launch (what the backward executors do)
+    dw2 = torch.zeros(C, 3, 3, C, device="cuda")
+    grp = hip.WgradGroup(BF16)
+    grp.conv(dy, x, cv, dw2)
+    grp.launch()
+    assert _rel(dw2, ref) < 2e-3

@@ -579,3 +579,32 @@ def test_patch_resident_conv3x3_64ch(N, H, W):
     _close(d[0], gv.sum(0), 1e-4)
     _close(d[1], (gv * (yb_v - fstats[:, 0].sum(0) / M)).sum(0), 2e-3)
     assert not d[2].any()
+
+
+@pytest.mark.policy_independent
+@pytest.mark.parametrize("N,H,W", [(3, 10, 12), (2, 9, 40), (1, 8, 56)])
+def test_patch_resident_wgrad3x3_64ch(N, H, W):
+    """conv_patch.hip, weight gradient (clite_conv_wgrad_patch, ABI v10): dW [64][3][3][64] f32 += dy^T * im2col(x) with the whole output held by
+    each persistent workgroup and both operands read from per-strip LDS images by transposed reads; per-workgroup slabs + the reduction kernel.
+    Against the numpy reference and against clite_conv_wgrad on the same operands; accumulation into a non-zero dW; the workspace-too-small and
+    wrong-shape refusals (return 1, nothing launched)."""
+    assert lib().clite_set_tile_policy(0) == 0
+    rng = np.random.default_rng(H + W)
+    Cc = K = 64
+    cv = Conv(BF16, N, H, W, Cc, K, 3, 3, 1, 1, H, W)
+    x, xb = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), BF16)
+    dy, dyb = _prep(rng.standard_normal((N, H, W, K), dtype=np.float32), BF16)
+    nb = C.c_uint64(0)
+    assert lib().clite_conv_wgrad_patch_workspace(C.byref(nb)) == 0 and nb.value == 2 * 9 * 64 * 64 * 4          # the simulator build runs 2 workgroups
+    ws = np.full(nb.value // 4, np.nan, np.float32)          # scratch arrives dirty
+    dw = np.full((K, 3, 3, Cc), 0.5, np.float32)
+    lib().clite_conv_wgrad_patch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    assert lib().clite_conv_wgrad_patch(ptr(dyb), ptr(xb), C.byref(cv), ptr(dw), ptr(ws), nb.value, None) == 0
+    ref = conv_wgrad_ref(dy, x, (K, 3, 3, Cc), 1, 1)
+    _close(dw - 0.5, ref, 2e-3)
+    dw2 = np.zeros((K, 3, 3, Cc), np.float32)
+    assert lib().clite_conv_wgrad(ptr(dyb), ptr(xb), C.byref(cv), ptr(dw2), None) == 0
+    _close(dw - 0.5, dw2, 2e-3)
+    assert lib().clite_conv_wgrad_patch(ptr(dyb), ptr(xb), C.byref(cv), ptr(dw), ptr(ws), nb.value - 4, None) == 1
+    cv2 = Conv(BF16, N, H, W, Cc, K, 3, 3, 2, 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
+    assert lib().clite_conv_wgrad_patch(ptr(dyb), ptr(xb), C.byref(cv2), ptr(dw), ptr(ws), nb.value, None) == 1

@@ -170,6 +170,7 @@ inline void buf_load16_lds(rsrc_t r, uint32_t off, void* lds_wave_base) {
   u32x4 v = buf_load16(r, off);
   memcpy((char*)lds_wave_base + wavesim::g_lane * 16, &v, 16);
 }
+inline void buf_load16_lds_nt(rsrc_t r, uint32_t off, void* lds_wave_base) { buf_load16_lds(r, off, lds_wave_base); }
 template <int N> inline void wait_vmcnt() {}
 inline void opaque_i(int&) {}
 inline void barrier_raw() { __syncthreads(); }

@@ -2,7 +2,15 @@
 # Ablation variants of the product library that differ in csrc/conv_patch.hip only: build/var{1,2,4,3}/libclite_hip_var.so (run after `make hip`).
 set -e
 cd "$(dirname "$0")/.."
-for v in 1 2 4 3; do
+mkdir -p build/varnt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_PATCH_NT=0 -c clip-lite_amd/csrc/conv_patch.hip -o build/varnt/conv_patch.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/varnt/libclite_hip_var.so build/varnt/conv_patch.o $(ls build/hip/*.o | grep -v conv_patch.o)
+# the round-3 kernel selection on this round's sources: no patch-resident kernels, no compile-time BERT epilogue forms (same-box A/B of the step)
+mkdir -p build/varr3
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_NO_PATCH -c clip-lite_amd/csrc/conv_patch.hip -o build/varr3/conv_patch.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_NO_BERT_FORMS -c clip-lite_amd/csrc/gemm_wide.hip -o build/varr3/gemm_wide.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/varr3/libclite_hip_var.so build/varr3/conv_patch.o build/varr3/gemm_wide.o $(ls build/hip/*.o | grep -v -e conv_patch.o -e gemm_wide.o)
+for v in ${PATCH_VARIANTS:-1 2 4 3}; do
   mkdir -p build/var$v
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_PATCH_ABLATE=$v -c clip-lite_amd/csrc/conv_patch.hip -o build/var$v/conv_patch.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var$v/libclite_hip_var.so build/var$v/conv_patch.o $(ls build/hip/*.o | grep -v conv_patch.o)

@@ -41,11 +41,20 @@ def main():
     flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
     ep_f = hip.epilogue(y, C, colsum=st)
     ep_b = hip.epilogue(y, C, relu_bits=bits, colsum=dst, bn=(by, fst, M))
+    dw = torch.zeros(C, 3, 3, C, device="cuda")
+
+    def grouped():
+        grp = hip.WgradGroup(hip.BF16)
+        grp.conv(dy, x, cv, dw)
+        grp.launch()
     for pol, name in ((0, "patch-resident"), (4, "implicit GEMM (4-wave)")):
         hip.set_tile_policy(pol)
         tf = timed(lambda: hip.conv_fwd(x, w, cv, ep_f), flush)
         tb = timed(lambda: hip.conv_dgrad(dy, wt, cv, ep_b, wt=True), flush)
-        print(f"{name:24s} batch {N}: forward {tf:7.1f} us   BatchNorm-backward dgrad {tb:7.1f} us   (lib {os.path.basename(hip.LIB_PATH)})")
+        hip.WgradGroup.patch = pol == 0
+        tw = timed(grouped, flush)
+        print(f"{name:24s} batch {N}: forward {tf:7.1f} us   BatchNorm-backward dgrad {tb:7.1f} us   weight gradient {tw:7.1f} us   (lib {os.path.basename(hip.LIB_PATH)})")
+    hip.WgradGroup.patch = False
     hip.set_tile_policy(0)
 
 
