@@ -201,7 +201,7 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
         int form = 0;
         if (sizeof(T) == 2 && kc_b && ep.relu_bits && ep.bn_y && !ep.dact_aux && !ep.out_f32 && ep.alpha == 1.f) {
           if (!ep.residual && !ep.mask_after_residual) form = 1;
-          else if (ep.residual && ep.mask_after_residual) form = 2;
+          else if (ep.residual && ep.mask_after_residual) form = rm.on == 2 ? 3 : 2;
         }
         // row-range persistent form (igemm_dma_bn_kernel) for the short-K (1 x 1) dgrads whose tile count exceeds the resident slots — two
         // workgroups per CU, three for the specialised forms on the 128 x 128 tile (half-tile staging: 48 KB of LDS, 168 registers); one
@@ -219,6 +219,7 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
         if constexpr (sizeof(T) == 2 && kc_b) {
           if (form == 1) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 1>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
           else if (form == 2) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 2>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+          else if (form == 3) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 3>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
           else hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
         } else {
           hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
@@ -279,6 +280,7 @@ int check_ep(const clite_epilogue* ep, int N) {
   if (ep->atomic && !ep->out_f32) return -1;
   // packed relu' bits exist in the BatchNorm-backward form only, and exclude the tensor form of the same mask
   if (ep->relu_bits && (!(ep->bn_y || ep->mask_after_residual) || ep->dact_aux)) return -1;
+  if (ep->residual_subsample < 0 || ep->residual_subsample > 2) return -1;
   return 0;
 }
 
@@ -514,15 +516,24 @@ int conv_dgrad(const void* dy, const void* w, const clite_conv& c, const clite_e
       GatherKC<T, 128, BK, false> lb{w, wb, geom_dense(c.C, c.K)};
       return launch<T, typename Cfg<T>::C128>(la, lb, *ep, P, c.C, c.K, 1, st, rm);
     }
+    RowMap rm{};
+    if (ep->residual_subsample > 1) {
+      // clite_epilogue.residual_subsample: the compact gradient of a stride-2 shortcut as the residual of this (dense, 1 x 1 / stride 1) dgrad
+      if (ep->residual_subsample != 2 || c.R != 1 || c.S != 1 || c.stride != 1 || c.pad != 0 || (c.H & 1) || (c.W & 1) || !ep->residual || !ep->bn_y ||
+          !ep->mask_after_residual)
+        return -1;
+      rm.on = 2; rm.div_hw = fastdiv_make(c.H * c.W); rm.div_w = fastdiv_make(c.W); rm.H = c.H; rm.W = c.W; rm.stride = 2; rm.off_h = 0; rm.off_w = 0;
+    }
     if (c.C <= 64) {
       GatherKC<T, 256, BK, true> la{dy, yb, geom_dgrad(c)};
       GatherKC<T, 64, BK, false> lb{w, wb, geom_dense(c.C, Ktot)};
-      return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, c.C, Ktot, 1, st);
+      return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, c.C, Ktot, 1, st, rm);
     }
     GatherKC<T, 128, BK, true> la{dy, yb, geom_dgrad(c)};
     GatherKC<T, 128, BK, false> lb{w, wb, geom_dense(c.C, Ktot)};
-    return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.C, Ktot, 1, st);
+    return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, c.C, Ktot, 1, st, rm);
   }
+  if (ep->residual_subsample > 1) return -1;          // (the transposed-weight entry point only)
   if (c.R == 1 && c.S == 1 && c.pad == 0 && c.stride > 1 && ep->residual == ep->out && !ep->colsum && !ep->preact && !ep->dact_aux) {
     // 1x1 / stride-s shortcut conv accumulated in place (dx += dgrad): only every s-th pixel of dx receives a contribution, so run
     // the dense GEMM dy[P][K] * W[K][C] over the P output pixels and scatter-add its rows (RowMap) instead of gathering a mostly
@@ -670,6 +681,7 @@ __global__ __launch_bounds__(256) void stem_unpack_kernel(const float* dwv, floa
 }
 
 int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K, int lda, int ldb, int rows_a, int rows_b) {
+  if (ep && ep->residual_subsample > 1) return -1;          // clite_conv_dgrad_wt only
   if (dtype != CLITE_BF16 && dtype != CLITE_F32) return -1;
   if (M <= 0 || N <= 0 || K <= 0 || lda % 8 || ldb % 8) return -1;
   if (!fits32((size_t)rows_a * lda, 4) || !fits32((size_t)rows_b * ldb, 4)) return -1;
@@ -700,7 +712,7 @@ extern "C" int clite_gemm_tn(const void* A, int lda, const void* B, int ldb, int
   return dtype == CLITE_BF16 ? gemm_tn<bf16>(A, lda, B, ldb, M, N, K, ep, (hipStream_t)stream) : gemm_tn<float>(A, lda, B, ldb, M, N, K, ep, (hipStream_t)stream);
 }
 extern "C" int clite_conv_fwd(const void* x, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
-  if (check_conv(cv) || check_ep(ep, cv->K)) return -1;
+  if (check_conv(cv) || check_ep(ep, cv->K) || ep->residual_subsample > 1) return -1;
   return cv->dtype == CLITE_BF16 ? conv_fwd<bf16>(x, w, *cv, ep, (hipStream_t)stream) : conv_fwd<float>(x, w, *cv, ep, (hipStream_t)stream);
 }
 extern "C" int clite_conv_dgrad(const void* dy, const void* w, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
@@ -710,7 +722,7 @@ extern "C" int clite_conv_dgrad(const void* dy, const void* w, const clite_conv*
 extern "C" int clite_conv_dgrad_s2class(const void* dy, const void* wsub, const clite_conv* cv, int ph, int pw, const clite_epilogue* ep, void* stream) {
   if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
   if (cv->R != 3 || cv->S != 3 || cv->stride != 2 || cv->pad != 1 || (cv->H & 1) || (cv->W & 1) || (unsigned)ph > 1 || (unsigned)pw > 1) return -1;
-  if (cv->C % 64 || cv->K % 64) return -1;
+  if (cv->C % 64 || cv->K % 64 || ep->residual_subsample > 1) return -1;
   return cv->dtype == CLITE_BF16 ? conv_dgrad_s2class<bf16>(dy, wsub, *cv, ph, pw, ep, (hipStream_t)stream)
                                  : conv_dgrad_s2class<float>(dy, wsub, *cv, ph, pw, ep, (hipStream_t)stream);
 }
@@ -721,7 +733,7 @@ extern "C" int clite_conv_dgrad_wt(const void* dy, const void* wt, const clite_c
 extern "C" int clite_conv_dgrad_s2class_wt(const void* dy, const void* wtsub, const clite_conv* cv, int ph, int pw, const clite_epilogue* ep, void* stream) {
   if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
   if (cv->R != 3 || cv->S != 3 || cv->stride != 2 || cv->pad != 1 || (cv->H & 1) || (cv->W & 1) || (unsigned)ph > 1 || (unsigned)pw > 1) return -1;
-  if (cv->C % 64 || cv->K % 64) return -1;
+  if (cv->C % 64 || cv->K % 64 || ep->residual_subsample > 1) return -1;
   return cv->dtype == CLITE_BF16 ? conv_dgrad_s2class<bf16, true>(dy, wtsub, *cv, ph, pw, ep, (hipStream_t)stream)
                                  : conv_dgrad_s2class<float, true>(dy, wtsub, *cv, ph, pw, ep, (hipStream_t)stream);
 }

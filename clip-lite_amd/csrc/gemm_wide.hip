@@ -128,7 +128,7 @@ bool clite_group_wide_enabled() { return g_tile_policy.load(std::memory_order_re
 
 int clite::launch_wide(const WideOperand& a, const WideOperand& b, const clite_epilogue& ep, const RowMap& rm, int M, int N, int Ktot, int splits, hipStream_t st) {
   const int policy = g_tile_policy.load(std::memory_order_relaxed);
-  if (policy == 4 || !operand_ok(a) || !operand_ok(b)) return WIDE_NOT_TAKEN;
+  if (policy == 4 || !operand_ok(a) || !operand_ok(b) || rm.on == 2) return WIDE_NOT_TAKEN;          // (the subsampled-residual form: 4-wave kernels only)
   // weight gradients (XC x XC operands, f32 atomic split-K accumulation) have no wide instantiation: measured slower (61 vs 49 us on the
   // BERT 2304 x 768 x 3840 gradient) — many small workgroups hide the atomic epilogue better
   if (a.kind == WOP_XC_STRIDED || ep.atomic) return WIDE_NOT_TAKEN;

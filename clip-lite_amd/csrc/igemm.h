@@ -322,14 +322,24 @@ template <typename T> DEV float gelu_grad_t(float x) {
 // Optional remap of GEMM rows to rows of the output (and of the residual / aux tensors): GEMM row p = (n, ho, wo) over an
 // [N][Ho][Wo] grid lands on pixel (n, ho*stride, wo*stride) of an [N][H][W] tensor. Used by the 1x1 / stride-2 dgrad, which is a
 // dense GEMM over the output pixels scattered into every stride-th input pixel.
+// on = 2 (BatchNorm-backward epilogue only): the OUTPUT rows are dense, and the RESIDUAL is a compact tensor over every second pixel of the
+// [N][H][W] grid the rows run over (clite_epilogue.residual_subsample): div_hw / div_w divide by H * W and W here.
 struct RowMap {
   int on;
   FastDiv div_hw, div_w;   // by Ho*Wo and by Wo
   int H, W, stride;
   int off_h, off_w;        // pixel (n, ho*stride + off_h, wo*stride + off_w)
 };
+// rm.on == 2: row of the compact residual tensor [N][H/2][W/2] that is added to output row `row` of the [N][H][W] grid, or -1 (odd h or w)
+DEV int subsampled_row(const RowMap& rm, int row) {
+  const uint32_t n = fd_div(row, rm.div_hw);
+  const uint32_t rem = row - n * rm.div_hw.d;
+  const uint32_t h = fd_div(rem, rm.div_w);
+  const uint32_t w = rem - h * rm.div_w.d;
+  return ((h | w) & 1u) ? -1 : (int)((n * (uint32_t)(rm.H >> 1) + (h >> 1)) * (uint32_t)(rm.W >> 1) + (w >> 1));
+}
 DEV size_t map_row(const RowMap& rm, int row) {
-  if (!rm.on) return (size_t)row;
+  if (rm.on != 1) return (size_t)row;
   uint32_t n = fd_div(row, rm.div_hw);
   uint32_t rem = row - n * rm.div_hw.d;
   uint32_t ho = fd_div(rem, rm.div_w);
@@ -676,7 +686,7 @@ struct BnRows {
   DEV void request(int q, const Epilogue& ep, const RowMap& rm, int M, int N, int m0, int n0, int tid) {
     const int gcol = n0 + (tid % CPRE) * 8;
     const bool has_bits = FORM ? true : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? true : ep.bn_y != nullptr,
-               has_res = FORM ? FORM == 2 : ep.residual != nullptr;
+               has_res = FORM ? FORM >= 2 : ep.residual != nullptr;
     const rsrc_t r_bits = make_rsrc(ep.relu_bits, RSRC_WHOLE), r_aux = make_rsrc(ep.dact_aux, RSRC_WHOLE), r_y = make_rsrc(ep.bn_y, RSRC_WHOLE),
                  r_res = make_rsrc(ep.residual, RSRC_WHOLE);
     const int grow = m0 + tid / CPRE + q * RPSE;
@@ -689,10 +699,23 @@ struct BnRows {
     pb[q] = buf_load1(r_bits, (okr[q] && has_bits && !(CLITE_EPI_ABLATE & 1)) ? (gix[q] >> 3) : OOB_OFF);
     if constexpr (FORM == 0) pa[q].ldb(r_aux, (okr[q] && has_aux && !has_bits) ? eoff : OOB_OFF);
     py[q].ldb(r_y, (okr[q] && has_y) ? eoff : OOB_OFF);
-    if constexpr (FORM != 1) pr[q].ldb(r_res, (okr[q] && has_res) ? eoff : OOB_OFF);
+    if constexpr (FORM == 3) {          // residual = the compact gradient of the stride-2 shortcut: present on every second pixel only
+      const int rr = subsampled_row(rm, grow);
+      pr[q].ldb(r_res, (okr[q] && rr >= 0 && !(CLITE_EPI_ABLATE & 1)) ? (uint32_t)(rr * ep.ldc + gcol) * (uint32_t)sizeof(T) : OOB_OFF);
+    } else if constexpr (FORM == 0) {
+      uint32_t roff = eoff;
+      if (rm.on == 2) {
+        const int rr = subsampled_row(rm, grow);
+        roff = rr >= 0 ? (uint32_t)(rr * ep.ldc + gcol) * (uint32_t)sizeof(T) : OOB_OFF;
+      }
+      pr[q].ldb(r_res, (okr[q] && has_res) ? roff : OOB_OFF);
+    } else if constexpr (FORM == 2) {
+      pr[q].ldb(r_res, okr[q] ? eoff : OOB_OFF);
+    }
   }
 };
 
+// (FORM 3, round 4 = FORM 2 with the residual read through RowMap's subsampled-row map: the block-input gradient of a stride-2 downsample block.)
 // FORM: what the launch needs, fixed at compile time. 0 = every combination clite_epilogue allows in this form, decided by run-time flags and
 // selects (tests, f32, the tensor form of the mask). 1 / 2 = the two forms the bf16 ResNet backward launches — packed relu' bits, BatchNorm input,
 // bf16 output, alpha = 1; 2 adds the residual with the mask applied after it (the block-input gradient). The ISA of the run-time form had ~400
@@ -752,7 +775,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, BnRo
   constexpr int AHEAD = (FORM && CLITE_BN_HALF) ? 2 : (FORM ? CLITE_BN_AHEAD_FORM : CLITE_BN_AHEAD);
   static_assert(NREQ == 0 || NP == 1, "early requests assume the whole-tile staging order");
   const bool has_bits = FORM ? true : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? true : ep.bn_y != nullptr;
-  const bool mask_after = FORM ? FORM == 2 : ep.mask_after_residual != 0;
+  const bool mask_after = FORM ? FORM >= 2 : ep.mask_after_residual != 0;
   const bool to_f32 = FORM ? false : (ep.out_f32 || sizeof(T) == 4);
   const rsrc_t r_out = make_rsrc(ep.out, RSRC_WHOLE);
   Raw8<T> (&pa)[ROWS_PT] = rows.pa, (&py)[ROWS_PT] = rows.py, (&pr)[ROWS_PT] = rows.pr;
@@ -793,7 +816,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, BnRo
     } else {
       // out-of-range rows / columns need no select: their accumulators are zero (operand rows / columns past the range gather as zeros) and
       // every operand load returned zeros, so v = 0 and nothing is added to the statistics; the store offset is OOB_OFF
-      if constexpr (FORM == 2) {
+      if constexpr (FORM >= 2) {
         pr[q].get(rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (pb[q] >> e) & 1u ? v[e] + rv[e] : 0.f;

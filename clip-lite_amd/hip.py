@@ -28,7 +28,7 @@ class Epilogue(C.Structure):
         ("drop_site", C.c_uint32), ("residual", C.c_void_p), ("colsum", C.c_void_p),
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32), ("colsum_rows", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
-        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("relu_bits", C.c_void_p), ("splitk_ws", C.c_void_p),
+        ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("relu_bits", C.c_void_p), ("splitk_ws", C.c_void_p), ("residual_subsample", C.c_int32),
     ]
 
 
@@ -221,7 +221,8 @@ class Stats:
 
 
 def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
-             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False, ws=None, relu_bits=None, colsum_rows=0):
+             drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False, ws=None, relu_bits=None, colsum_rows=0,
+             residual_subsample=0):
     """bn = (y, stats: Stats, rows): accumulate the BatchNorm-backward reductions (sum v, sum v*(y - mean)) into `colsum`.
     relu_bits: the relu' mask of that form as packed bits (uint8 [M][ldc / 8], written by bn_apply) instead of dact_aux."""
     ep = Epilogue()
@@ -248,6 +249,7 @@ def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, pr
         ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = p(y), p(st.t), st.R, st.rstride, 1.0 / rows
     ep.mask_after_residual = int(mask_after_residual)
     ep.relu_bits = p(relu_bits)
+    ep.residual_subsample = residual_subsample      # 2: `residual` is the compact [N][H/2][W/2][ldc] gradient of a stride-2 shortcut (clite_epilogue.residual_subsample)
     ep.splitk_ws = p(ws)        # zeroed f32 [M][N] workspace: allows split-K for GEMMs of few output tiles (clite_epilogue.splitk_ws)
     return ep
 

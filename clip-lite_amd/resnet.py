@@ -380,6 +380,25 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                     hip.conv_dgrad(dy, wd, u.cv,
                                    hip.epilogue(dx, Cin, residual=dz, relu_bits=pl.bits, mask_after_residual=True, colsum=pre,
                                                 bn=(pl.y, pl.stats, pl.y.shape[0])), wt=wt)
+                elif (ud is not None and bi > 0 and rt.fuse_bn_backward and rt.lowp and wt and ud.cv.stride == 2 and ud.cv.R == 1 and u.cv.R == 1
+                      and u.cv.stride == 1 and u.cv.H % 2 == 0 and u.cv.W % 2 == 0 and not hip.is_deterministic() and rt.compact_shortcut):
+                    # First block of a stride-2 stage (Bottleneck): the block-input gradient is conv1's dgrad (dense, full resolution) plus the
+                    # strided 1 x 1 shortcut's dgrad, which only reaches every second pixel. The shortcut's gradient stays COMPACT ([N][H/2][W/2][Cin],
+                    # one forward-form GEMM) and enters conv1's dgrad as a row-mapped residual (clite_epilogue.residual_subsample) of the
+                    # BatchNorm-backward epilogue — so the gradient reaching the previous block is already masked and comes with the two
+                    # reductions of that block's last BatchNorm, like behind every identity block: no scatter-add read-modify-write over the
+                    # full-size gradient and no separate reduction pass (3 of the step's 11 bn_bwd_reduce launches, the largest ones)
+                    pl = recs[bi - 1][0][-1]
+                    if ud.conv.weight.requires_grad:
+                        wgrad(dyd, ud)
+                    wdd, _ = _wd(rt, ud.conv)          # [Cin][1][1][K]
+                    P, Kd = dyd.shape[0], ud.cv.K
+                    dsc = _alloc(rt, P, Cin)
+                    hip.gemm_nt(dt, dyd, wdd.view(Cin, Kd), P, Cin, Kd, hip.epilogue(dsc, Cin))
+                    pre = rt.new_stats(Cin, pl.y.shape[0])
+                    hip.conv_dgrad(dy, wd, u.cv,
+                                   hip.epilogue(dx, Cin, residual=dsc, residual_subsample=2, relu_bits=pl.bits, mask_after_residual=True, colsum=pre,
+                                                bn=(pl.y, pl.stats, pl.y.shape[0])), wt=wt)
                 else:
                     hip.conv_dgrad(dy, wd, u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None), wt=wt)
                     if ud is not None:

@@ -96,6 +96,11 @@ typedef struct clite_epilogue {
   float* splitk_ws;         /* optional f32 [M][N] workspace, ZERO on entry (left dirty): lets clite_gemm_nt / _nn run a GEMM of few output tiles
                              * (the M = 128/256-row GEMMs of the projection heads and prior discriminators) as split-K over all CUs — partial
                              * sums accumulate here with float atomics and a second small kernel applies this epilogue. NULL: never split. */
+  int32_t residual_subsample; /* ABI v10. 0 / 1: `residual` has the output's rows. 2: clite_conv_dgrad_wt of a 1 x 1 / stride 1 convolution in the
+                             * BatchNorm-backward form only (bn_y + relu_bits + mask_after_residual, bf16): `residual` is the COMPACT tensor
+                             * [N][H/2][W/2][ldc] whose pixel (n, h/2, w/2) is added to output pixel (n, h, w) for even h, w and nothing elsewhere —
+                             * the input gradient of the block's stride-2 1 x 1 shortcut, kept compact instead of scatter-added into the full-size
+                             * gradient (which cost a read-modify-write pass and, before it, a separate BatchNorm-backward reduction pass). */
 } clite_epilogue;
 
 /* NHWC convolution problem. x: [N][H][W][C], w: [K][R][S][C], y: [N][Ho][Wo][K], all of `dtype`. */

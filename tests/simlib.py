@@ -23,6 +23,7 @@ class Epilogue(C.Structure):
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32), ("colsum_rows", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
         ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("relu_bits", C.c_void_p), ("splitk_ws", C.c_void_p),
+        ("residual_subsample", C.c_int32),
     ]
 
 

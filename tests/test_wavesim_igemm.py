@@ -608,3 +608,45 @@ def test_patch_resident_wgrad3x3_64ch(N, H, W):
     assert lib().clite_conv_wgrad_patch(ptr(dyb), ptr(xb), C.byref(cv), ptr(dw), ptr(ws), nb.value - 4, None) == 1
     cv2 = Conv(BF16, N, H, W, Cc, K, 3, 3, 2, 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1)
     assert lib().clite_conv_wgrad_patch(ptr(dyb), ptr(xb), C.byref(cv2), ptr(dw), ptr(ws), nb.value, None) == 1
+
+
+@pytest.mark.policy_independent
+@pytest.mark.parametrize("dtype,N,H,W,Cc,K", [(BF16, 2, 8, 6, 64, 32), (BF16, 3, 6, 10, 136, 64), (F32, 2, 4, 6, 64, 32)])
+def test_bn_backward_dgrad_with_subsampled_residual(dtype, N, H, W, Cc, K):
+    """clite_epilogue.residual_subsample = 2 (ABI v10): the BatchNorm-backward form of a dense 1 x 1 dgrad whose residual is the COMPACT
+    [N][H/2][W/2][C] gradient of the block's stride-2 shortcut — added at the even pixels only, then masked, with both reductions. bf16 with packed
+    bits and a bf16 output runs the compile-time FORM 3 of igemm_epilogue_bn, the f32 case the run-time form; row-range persistent launches
+    included (the simulator build has 4 resident slots). Entry points that do not implement it refuse."""
+    rng = np.random.default_rng(H * W + Cc)
+    cv = Conv(dtype, N, H, W, Cc, K, 1, 1, 1, 0, H, W)
+    M, P = N * H * W, N * (H // 2) * (W // 2)
+    w, _ = _prep(rng.standard_normal((K, 1, 1, Cc), dtype=np.float32) * 0.3, dtype)
+    wt, wtb = _prep(np.ascontiguousarray(w.transpose(3, 1, 2, 0)), dtype)
+    dy, dyb = _prep(rng.standard_normal((N, H, W, K), dtype=np.float32), dtype)
+    aux = rng.standard_normal((M, Cc)).astype(np.float32)
+    bits = pack_relu_bits(aux)
+    res, resb = _prep(rng.standard_normal((P, Cc), dtype=np.float32), dtype)
+    y, yb = _prep(rng.standard_normal((M, Cc), dtype=np.float32) + 2.0, dtype)
+    fstats = np.zeros((2, 3, Cc), np.float32)
+    fstats[:, 0] = y.sum(0) / 2
+    g = conv_dgrad_ref(dy, w, (N, H, W, Cc), 1, 0)
+    full = np.zeros((N, H, W, Cc), np.float32)
+    full[:, ::2, ::2] = res.reshape(N, H // 2, W // 2, Cc)
+    want = ((g + full).reshape(M, Cc)) * (aux > 0)
+    out = outbuf_like(dtype, (M, Cc))
+    dst = np.zeros((2, 3, Cc), np.float32)
+    ep = make_ep(out, Cc, residual=resb, colsum=dst, relu_bits=bits)
+    ep.colsum_replicas, ep.colsum_stride = 2, 3 * Cc
+    ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count, ep.mask_after_residual = ptr(yb), ptr(fstats), 2, 3 * Cc, 1.0 / M, 1
+    ep.residual_subsample = 2
+    assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == 0
+    got = from_bf16(out) if dtype == BF16 else out
+    _close(got, want, 8e-3 if dtype == BF16 else 2e-3)
+    d = dst.sum(0)
+    _close(d[0], got.sum(0), 1e-3)
+    _close(d[1], (got * (y - fstats[:, 0].sum(0) / M)).sum(0), 5e-3)
+    # refusals: the other entry points, odd extents, a windowed convolution
+    assert lib().clite_conv_dgrad(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == -1
+    assert lib().clite_conv_fwd(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == -1
+    ep.mask_after_residual = 0
+    assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == -1
