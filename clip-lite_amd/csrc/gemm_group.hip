@@ -31,6 +31,7 @@ struct GroupItem {
   LB lb;
   float* out;
   int ldc, M, N, ktiles, chunk;
+  int zeroed;          // CLITE_WGRAD_ZEROED: `out` is known to hold zeros on entry
 };
 struct WgEntry { uint32_t item, tile_m, tile_n, kchunk; };      // one per workgroup
 
@@ -120,6 +121,17 @@ __global__ __launch_bounds__(256) void igemm_group_kernel(const GroupItem<LA, LB
   }
   float* out = it.out;
   const int ldc = it.ldc;
+  // A member whose contraction fits ONE chunk has exactly one workgroup per output element in this launch; when the caller also vouches that
+  // the gradient buffer holds zeros (CLITE_WGRAD_ZEROED: the captured train step, whose update kernel leaves the arena zeroed and which visits
+  // every weight once), `+=` is a plain store. Float atomics execute at the memory side at ~1.3 TB/s chip-wide — ~5 GB/s per CU — so the 256 KB
+  // accumulator tile of a BERT weight gradient took ~50 us to drain, about as long as its main loop: 437 MB of atomic traffic per step for the
+  // 109 M BERT parameters. (A plain read-modify-write instead of the store was measured SLOWER than the atomics: 15.29 vs 15.11 ms per step —
+  // the loads put a round trip to HBM in front of every store.)
+#ifdef CLITE_GROUP_ATOMIC_ALWAYS          // A/B builds only
+  const bool single = false;
+#else
+  const bool single = wave_uniform((int)(it.ktiles <= it.chunk && it.zeroed));
+#endif
 #pragma unroll
   for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -128,7 +140,10 @@ __global__ __launch_bounds__(256) void igemm_group_kernel(const GroupItem<LA, LB
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < N) atomic_add_f32(out + (size_t)row * ldc + col, acc[i][j][r]);
+        if (row < M && col < N) {
+          float* q = out + (size_t)row * ldc + col;
+          if (single) *q = acc[i][j][r]; else atomic_add_f32(q, acc[i][j][r]);
+        }
       }
     }
 }
@@ -222,6 +237,17 @@ __global__ __launch_bounds__(512) void igemm_group_wide_kernel(const GroupItem<L
   }
   float* out = it.out;
   const int ldc = it.ldc;
+  // A member whose contraction fits ONE chunk has exactly one workgroup per output element in this launch; when the caller also vouches that
+  // the gradient buffer holds zeros (CLITE_WGRAD_ZEROED: the captured train step, whose update kernel leaves the arena zeroed and which visits
+  // every weight once), `+=` is a plain store. Float atomics execute at the memory side at ~1.3 TB/s chip-wide — ~5 GB/s per CU — so the 256 KB
+  // accumulator tile of a BERT weight gradient took ~50 us to drain, about as long as its main loop: 437 MB of atomic traffic per step for the
+  // 109 M BERT parameters. (A plain read-modify-write instead of the store was measured SLOWER than the atomics: 15.29 vs 15.11 ms per step —
+  // the loads put a round trip to HBM in front of every store.)
+#ifdef CLITE_GROUP_ATOMIC_ALWAYS          // A/B builds only
+  const bool single = false;
+#else
+  const bool single = wave_uniform((int)(it.ktiles <= it.chunk && it.zeroed));
+#endif
 #pragma unroll
   for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -230,7 +256,10 @@ __global__ __launch_bounds__(512) void igemm_group_wide_kernel(const GroupItem<L
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M && col < N) atomic_add_f32(out + (size_t)row * ldc + col, acc[i][j][r]);
+        if (row < M && col < N) {
+          float* q = out + (size_t)row * ldc + col;
+          if (single) *q = acc[i][j][r]; else atomic_add_f32(q, acc[i][j][r]);
+        }
       }
     }
 }
@@ -290,9 +319,9 @@ struct Bucket {
   std::vector<GroupItem<LA, LB>> items;
   std::vector<Plan> plans;
   std::vector<WgEntry> map;
-  void add(const LA& la, const LB& lb, float* out, int ldc, const Plan& p) {
+  void add(const LA& la, const LB& lb, float* out, int ldc, const Plan& p, int zeroed) {
     GroupItem<LA, LB> it;
-    it.la = la; it.lb = lb; it.out = out; it.ldc = ldc; it.M = p.M; it.N = p.N; it.ktiles = p.ktiles; it.chunk = p.chunk;
+    it.la = la; it.lb = lb; it.out = out; it.ldc = ldc; it.M = p.M; it.N = p.N; it.ktiles = p.ktiles; it.chunk = p.chunk; it.zeroed = zeroed;
     items.push_back(it);
     plans.push_back(p);
   }
@@ -368,7 +397,7 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
     for (int i = 0; i < n; ++i) {
       const clite_wgrad_item& w = items[i];
       int rc;
-      if ((w.kind & ~CLITE_WGRAD_NARROW) == 0) {
+      if ((w.kind & ~(CLITE_WGRAD_NARROW | CLITE_WGRAD_ZEROED)) == 0) {
         rc = clite_conv_wgrad(w.a, w.b, &w.cv, w.out, stream);
       } else {
         clite_epilogue ep = {};
@@ -390,23 +419,24 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
     const clite_wgrad_item& w = items[i];
     if (!w.a || !w.b || !w.out) return -1;
     const bool wide = wide_all && !(w.kind & CLITE_WGRAD_NARROW);
-    const int kind = w.kind & ~CLITE_WGRAD_NARROW;
+    const int zeroed = (w.kind & CLITE_WGRAD_ZEROED) ? 1 : 0;
+    const int kind = w.kind & ~(CLITE_WGRAD_NARROW | CLITE_WGRAD_ZEROED);
     if (kind == 0) {
       const clite_conv& c = w.cv;
       if (c.dtype != CLITE_BF16 || c.C % 8 || c.K % 8 || (c.R * c.S > 1 && (c.C % 32 || c.K % 32))) return -1;
       if (!fits32((size_t)c.N * c.H * c.W * c.C, 4) || !fits32((size_t)c.N * c.Ho * c.Wo * c.K, 4)) return -1;
       const int P = c.N * c.Ho * c.Wo, Ncols = c.R * c.S * c.C;
       const uint32_t yb = (uint32_t)((size_t)P * c.K * 2), xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * 2);
-      if (wide && c.K >= 256 && Ncols >= 256) conv_w256.add(WS256{w.a, yb, c.K, c.K, P, 1}, WG256{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 256, 256, WIDE_BK, WKCHUNK));
-      else if (c.K <= 64) conv_fewk.add(XS64{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 64, 128));
-      else if (Ncols <= 64) conv_fewc.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG64{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 64));
-      else conv_full.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 128));
+      if (wide && c.K >= 256 && Ncols >= 256) conv_w256.add(WS256{w.a, yb, c.K, c.K, P, 1}, WG256{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 256, 256, WIDE_BK, WKCHUNK), zeroed);
+      else if (c.K <= 64) conv_fewk.add(XS64{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 64, 128), zeroed);
+      else if (Ncols <= 64) conv_fewc.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG64{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 64), zeroed);
+      else conv_full.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 128), zeroed);
     } else if (kind == 1) {
       if (w.M <= 0 || w.N <= 0 || w.K <= 0 || w.M % 8 || w.N % 8 || w.lda % 8 || w.ldb % 8 || w.lda < w.M || w.ldb < w.N) return -1;
       if (!fits32((size_t)w.K * w.lda, 4) || !fits32((size_t)w.K * w.ldb, 4)) return -1;
       const uint32_t ab = (uint32_t)((((size_t)w.K - 1) * w.lda + w.M) * 2), bb = (uint32_t)((((size_t)w.K - 1) * w.ldb + w.N) * 2);
-      if (wide && w.M >= 256 && w.N >= 256) linear_w256.add(WS256{w.a, ab, w.lda, w.M, w.K, 1}, WS256{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 256, 256, WIDE_BK, WKCHUNK));
-      else linear.add(XS128{w.a, ab, w.lda, w.M, w.K, 1}, XS128{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 128, 128));
+      if (wide && w.M >= 256 && w.N >= 256) linear_w256.add(WS256{w.a, ab, w.lda, w.M, w.K, 1}, WS256{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 256, 256, WIDE_BK, WKCHUNK), zeroed);
+      else linear.add(XS128{w.a, ab, w.lda, w.M, w.K, 1}, XS128{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 128, 128), zeroed);
     } else {
       return -1;
     }

@@ -366,10 +366,13 @@ class WgradGroup:
 
     wide = True          # class-wide switch (tools/ab_runtime.py hip.WgradGroup.wide=0): False keeps every member on the 4-wave tiles (CLITE_WGRAD_NARROW)
 
-    def __init__(self, dt, workspace=None):
+    def __init__(self, dt, workspace=None, zeroed=False):
         """workspace: optional pre-allocated (device uint8 tensor, pinned host uint8 tensor) of equal size — required when launch() runs
-        inside a stream capture, where pinned memory cannot be allocated (alloc_workspace())."""
+        inside a stream capture, where pinned memory cannot be allocated (alloc_workspace()). zeroed: the caller vouches that every member's
+        gradient buffer holds zeros when the group is launched (CLITE_WGRAD_ZEROED: plain stores instead of float atomics for the members whose
+        contraction fits one K chunk) — the captured train step, which visits every weight once per step behind an update that zeroes the arena."""
         self.dt, self.items, self.extra, self.keep, self.wgs = dt, [], [], [], 0
+        self.kflags = 0x200 if zeroed else 0
         self.ws_dev, self.ws_host = workspace if workspace is not None else (None, None)
 
     @staticmethod
@@ -398,7 +401,7 @@ class WgradGroup:
             self.extra.append(lambda: conv_wgrad_patch(dy, x, cv, dw))
             return
         it = WgradItem()
-        it.kind, it.a, it.b, it.out, it.cv = (0 if self.wide else 0x100), p(dy), p(x), p(dw), cv
+        it.kind, it.a, it.b, it.out, it.cv = (0 if self.wide else 0x100) | self.kflags, p(dy), p(x), p(dw), cv
         self.items.append(it)
         self.keep += [dy, x, dw]
         ncols = cv.R * cv.S * cv.C
@@ -407,7 +410,7 @@ class WgradGroup:
     def linear(self, A, B, M, N, K, out, lda=None, ldb=None, ldc=None):
         """out[M][N] += A[K][M]^T B[K][N] (f32 accumulate)."""
         it = WgradItem()
-        it.kind, it.a, it.b, it.out = (1 if self.wide else 0x101), p(A), p(B), p(out)
+        it.kind, it.a, it.b, it.out = (1 if self.wide else 0x101) | self.kflags, p(A), p(B), p(out)
         it.M, it.N, it.K, it.lda, it.ldb, it.ldc = M, N, K, lda or M, ldb or N, ldc or N
         self.items.append(it)
         self.keep += [A, B, out]

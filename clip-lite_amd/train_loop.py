@@ -251,7 +251,8 @@ class TrainStep:
 
         def image_bwd(i):
             def fn():
-                keep["wg_" + segs[i]] = hip.WgradGroup(rt.dt, ws[segs[i]])
+                # (zeroed: this capture visits every weight once per step and the update kernel leaves the gradient arena zeroed)
+                keep["wg_" + segs[i]] = hip.WgradGroup(rt.dt, ws[segs[i]], zeroed=True)
                 resnet_backward(rt, inet, keep["ctx_i"], keep["dimg"].contiguous() if i == 0 else None, defer=keep["wg_" + segs[i]],
                                 stop_block=cuts[i], resume=i > 0)
             return fn
@@ -266,7 +267,7 @@ class TrainStep:
             keep["wg_" + segs[-1]].launch_extras()
 
         def text_bwd():
-            keep["wg_t"] = hip.WgradGroup(rt.dt, ws["t"])          # BERT's 49 linear weight gradients: one grouped launch at the end of its backward
+            keep["wg_t"] = hip.WgradGroup(rt.dt, ws["t"], zeroed=True)          # BERT's 49 linear weight gradients: one grouped launch at the end of its backward
             bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous(), defer=keep["wg_t"])
             keep["wg_t"].launch()
 

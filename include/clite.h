@@ -158,6 +158,10 @@ int clite_conv_wgrad_patch(const void* dy, const void* x, const clite_conv* cv, 
  * with ws_dev / ws_host NULL the members are launched one by one. Returns 0, -1 (bad member), -2 (workspace too small) or a HIP status. */
 #define CLITE_WGRAD_NARROW 0x100   /* OR-ed into `kind`: keep this member on the 4-wave 128 x 128 x 32 tiles (members with >= 256 rows and columns
                                     * otherwise take the 8-wave 256 x 256 tile); for A/B timing and parity tests */
+#define CLITE_WGRAD_ZEROED 0x200   /* ABI v10, OR-ed into `kind`: the caller vouches that `out` holds ZEROS on entry (the train step's update kernel leaves the
+                                    * gradient arena zeroed and the step visits this weight once). A member whose contraction fits one K chunk — every BERT
+                                    * matrix, the 7 x 7-resolution convolutions — then writes its result with plain stores instead of float atomics
+                                    * (memory-side, ~1.3 TB/s chip-wide: 437 MB per step for BERT's 109 M parameters). Same values; without the flag `+=`. */
 typedef struct clite_wgrad_item {
   int32_t kind;
   const void* a;

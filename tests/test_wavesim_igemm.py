@@ -343,6 +343,15 @@ def test_grouped_weight_gradients():
     for got, ref in zip(outs, refs):
         _close(got, ref)
     assert L.clite_wgrad_group(BF16, arr, len(items), ptr(ws_dev), ptr(ws_host), 64, None) == -2          # workspace too small: refused, nothing launched
+    # CLITE_WGRAD_ZEROED (ABI v10): the caller vouches for zeroed outputs; single-chunk members then store instead of adding atomically, the
+    # k-chunked member (the 4th) keeps its atomics. Same values.
+    for it, o in zip(items, outs):
+        it.kind |= 0x200
+        o[...] = 0.0
+    arr = (Item * len(items))(*items)
+    assert L.clite_wgrad_group(BF16, arr, len(items), ptr(ws_dev), ptr(ws_host), nb.value, None) == 0
+    for got, ref in zip(outs, refs):
+        _close(got, ref - 1)
 
 
 class TransposeItem(C.Structure):

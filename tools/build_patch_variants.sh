@@ -10,6 +10,9 @@ mkdir -p build/varr3
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_NO_PATCH -c clip-lite_amd/csrc/conv_patch.hip -o build/varr3/conv_patch.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_NO_BERT_FORMS -c clip-lite_amd/csrc/gemm_wide.hip -o build/varr3/gemm_wide.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/varr3/libclite_hip_var.so build/varr3/conv_patch.o build/varr3/gemm_wide.o $(ls build/hip/*.o | grep -v -e conv_patch.o -e gemm_wide.o)
+mkdir -p build/varat
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_GROUP_ATOMIC_ALWAYS -c clip-lite_amd/csrc/gemm_group.hip -o build/varat/gemm_group.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/varat/libclite_hip_var.so build/varat/gemm_group.o $(ls build/hip/*.o | grep -v gemm_group.o)
 for v in ${PATCH_VARIANTS:-1 2 4 3}; do
   mkdir -p build/var$v
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_PATCH_ABLATE=$v -c clip-lite_amd/csrc/conv_patch.hip -o build/var$v/conv_patch.o
