@@ -228,7 +228,7 @@ def side_record(base_args, device, steps, **override):
     args = argparse.Namespace(**{**vars(base_args), **override})
     with contextlib.redirect_stdout(sys.stderr):
         model, opt, sched = build(args, device)
-    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, None, graph=True)
+    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, None, graph=True, defer_update=True)
     batches = synthetic_batches(args, device, 0)
     for i in range(3):
         step(batches[i % len(batches)])
@@ -269,8 +269,9 @@ def main():
     ap.add_argument("--no-side-records", action="store_true", help="skip the two extra single-GPU records of the default run (the whole bs = 1024 step on "
                     "one GPU; the exact-f32 parity mode): profiling runs and A/B loops")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python each step instead of replaying the captured hipGraph of the step")
-    ap.add_argument("--defer-update", action="store_true", help="run the text encoder's and heads' share of the update at the start of the NEXT step, beside "
-                    "the image forward (TrainStep defer_update; measured neutral: DESIGN.md §5.1)")
+    ap.add_argument("--no-defer-update", action="store_true", help="keep the whole update at the end of the step. Default (round 4): the text encoder's and "
+                    "heads' share of the update runs at the start of the NEXT step on the text encoder's stream, beside the image forward "
+                    "(TrainStep defer_update; -0.1 ms per step, same-box A/B; step.finish() completes the last one inside the timed region)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL over xGMI); gloo is for single-GPU logic tests")
     ap.add_argument("--single-device", action="store_true", help="logic test only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--host-input", action="store_true", help="batches start in pinned host memory and cross PCIe every step through the train loop's "
@@ -320,10 +321,10 @@ def main():
     if dist_on:
         exchange = cdist.GradientExchange(model.runtime.arena, algorithm=args.exchange)
         model.runtime.exchange = exchange
-    # --defer-update: the step's last kernel (the update of the text encoder and the heads) runs at the start of the next step, beside the image
-    # forward; step.finish() below then completes the last timed step's update INSIDE the timed region. Measured: 17.32 vs 17.35 ms — both are
-    # HBM-bound at that point of the step, the overlap is zero-sum — so it is off by default
-    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange, graph=not args.no_graph, defer_update=args.defer_update)
+    # defer_update: the step's last kernel (the update of the text encoder and the heads) runs at the start of the next step, beside the image
+    # forward; step.finish() below then completes the last timed step's update INSIDE the timed region. Round 3 measured it neutral (17.32 vs
+    # 17.35 ms); with round 4's shorter side stream it is worth 0.1 ms (15.14 -> 15.04, same box) and is on by default
+    step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange, graph=not args.no_graph, defer_update=not args.no_defer_update)
     eager_step = TrainStep(model, opt, sched, GradScaler(True), 10.0, exchange)      # per-launch timing needs eager launches
     batches = synthetic_batches(args, device, rank)
     if args.host_input:

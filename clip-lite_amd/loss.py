@@ -167,8 +167,10 @@ def mi_block_forward(rt, blk, x, training, updates=2):
     return out, (x, z, stats, a, t, lst)
 
 
-def mi_block_backward(rt, blk, ctx, dout, dx_residual=None):
-    """Returns dx [B][F] (+ dx_residual if given). Parameter gradients accumulate into the arena."""
+def mi_block_backward(rt, blk, ctx, dout, dx_residual=None, defer=None):
+    """Returns dx [B][F] (+ dx_residual if given). Parameter gradients accumulate into the arena. defer: a hip.WgradGroup that collects the three
+    Linear weight gradients (and their bias sums) instead of launching them between the input-gradient GEMMs — they feed nothing but the arena,
+    and in the captured step this chain sits between the encoders' forward and backward with nothing else on the chip."""
     from .bert import _linear_grads
     dt, A = rt.dt, rt.arena
     x, z, stats, a, t, lst = ctx
@@ -181,11 +183,10 @@ def mi_block_backward(rt, blk, ctx, dout, dx_residual=None):
     else:
         dtt = dout
     sc = blk.feature_shortcut
-    _linear_grads(rt, sc, dtt, x, B)
+    _linear_grads(rt, sc, dtt, x, B, defer=defer)
     dx = _alloc(rt, B, Fin)
     hip.gemm_nn(dt, dtt, A.w(sc.weight), B, Fin, U, hip.epilogue(dx, Fin, residual=dx_residual, ws=rt.gemm_ws(B, Fin)))
-    hip.gemm_tn(dt, dtt, a, U, U, B, hip.epilogue(A.g(l2.weight), U, atomic=True, out_f32=True))
-    hip.colsum(dt, dtt, A.g(l2.bias), B, U)
+    _linear_grads(rt, l2, dtt, a, B, defer=defer)
     da = _alloc(rt, B, U)
     hip.gemm_nn(dt, dtt, A.w(l2.weight), B, U, U, hip.epilogue(da, U, ws=rt.gemm_ws(B, U)))
     dstats = rt.new_stats(U, B)
@@ -193,7 +194,7 @@ def mi_block_backward(rt, blk, ctx, dout, dx_residual=None):
     dz = _alloc(rt, B, U)
     desc = hip.bn_desc(B, U, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn)
     hip.bn_bwd_apply(dt, desc, da, a, z, dstats, dz, None, A.g(bn.weight), A.g(bn.bias))
-    hip.gemm_tn(dt, dz, x, U, Fin, B, hip.epilogue(A.g(l1.weight), Fin, atomic=True, out_f32=True))
+    _linear_grads(rt, l1, dz, x, B, defer=defer)
     dx2 = _alloc(rt, B, Fin)
     hip.gemm_nn(dt, dz, A.w(l1.weight), B, Fin, U, hip.epilogue(dx2, Fin, residual=dx, ws=rt.gemm_ws(B, Fin)))
     return dx2
@@ -228,7 +229,7 @@ def _mlp_tail_forward(rt, net, x2, half, acc_slot, softplus):
     return (x2, h0, h1, logit)
 
 
-def _mlp_tail_backward(rt, net, ctx, gout, scale):
+def _mlp_tail_backward(rt, net, ctx, gout, scale, defer=None):
     """Parameter gradients of the three layers into the arena; returns dh0 [2*half][n0] (gradient at l0's pre-activation)."""
     from .bert import _linear_grads
     dt, A = rt.dt, rt.arena
@@ -237,19 +238,19 @@ def _mlp_tail_backward(rt, net, ctx, gout, scale):
     n0, n1 = net.l0.weight.shape[0], net.l1.weight.shape[0]
     dh1 = _alloc(rt, R, n1)
     hip.prior_tail_bwd(dt, h1, net.l2.weight, logit, gout, scale, R // 2, n1, dh1, A.g(net.l2.weight), A.g(net.l2.bias))
-    _linear_grads(rt, net.l1, dh1, h0, R)
+    _linear_grads(rt, net.l1, dh1, h0, R, defer=defer)
     dh0 = _alloc(rt, R, n0)
     hip.gemm_nn(dt, dh1, A.w(net.l1.weight), R, n0, n1, hip.epilogue(dh0, n0, dact_aux=h0, dact=hip.DACT_RELU, ws=rt.gemm_ws(R, n0)))
-    _linear_grads(rt, net.l0, dh0, x2, R)
+    _linear_grads(rt, net.l0, dh0, x2, R, defer=defer)
     return dh0
 
 
-def prior_backward(rt, pd, ctx, gout, scale, dfeat_residual):
+def prior_backward(rt, pd, ctx, gout, scale, dfeat_residual, defer=None):
     """Returns d(feat) [B][sz] + dfeat_residual."""
     dt, A = rt.dt, rt.arena
     B2, sz = ctx[0].shape
     B = B2 // 2
-    dh0 = _mlp_tail_backward(rt, pd, ctx, gout, scale)
+    dh0 = _mlp_tail_backward(rt, pd, ctx, gout, scale, defer=defer)
     dfeat = _alloc(rt, B, sz)
     # only the feature rows (B..2B) need an input gradient; the noise rows have none
     hip.gemm_nn(dt, dh0[B:], A.w(pd.l0.weight), B, sz, dh0.shape[1], hip.epilogue(dfeat, sz, residual=dfeat_residual, ws=rt.gemm_ws(B, sz)))
@@ -329,15 +330,15 @@ def jsd_backward(rt, mod, saved, gout):
 # those of the text features — and the prior terms' gradients need nothing but their own forward (dL/d total is the constant 1). So the
 # text half runs on the text encoder's stream: its forward (and the prior's backward) right behind BERT's forward, hidden under the tail of
 # the ResNet forward; its block backward right behind the critic, beside the image half. Only the critic sits on the join.
-def jsd_half_forward(rt, mod, feat, which, step, site, acc, gout):
+def jsd_half_forward(rt, mod, feat, which, step, site, acc, gout, defer=None):
     """which: "image" | "text". Prior discriminator forward + backward and MI-block forward of one modality. acc: the step's 8 zeroed
     accumulators (slot 2 / 3 = this prior's term). Returns the state jsd_join / jsd_half_backward need."""
     half = jsd_half_block(rt, mod, feat, which, step)
-    half["dprior"] = jsd_half_prior(rt, mod, feat, which, step, site, acc, gout)
+    half["dprior"] = jsd_half_prior(rt, mod, feat, which, step, site, acc, gout, defer=defer)
     return half
 
 
-def jsd_half_prior(rt, mod, feat, which, step, site, acc, gout):
+def jsd_half_prior(rt, mod, feat, which, step, site, acc, gout, defer=None):
     """The prior discriminator of one modality, forward and backward (its term goes to acc[2] / acc[3], its weight gradients to the arena);
     returns the gradient it sends to the features, or None when that prior is off. Independent of jsd_half_block: a captured step runs the
     two on different streams (train_loop.TrainStep)."""
@@ -348,7 +349,7 @@ def jsd_half_prior(rt, mod, feat, which, step, site, acc, gout):
     noise = (mod._noise or (None, None))[0 if img else 1]
     pd = mod.prior_d if img else mod.text_prior_d
     pctx = prior_forward(rt, pd, feat, noise, acc[2:3] if img else acc[3:4], step, site)
-    return prior_backward(rt, pd, pctx, gout, mod.prior_weight, None)
+    return prior_backward(rt, pd, pctx, gout, mod.prior_weight, None, defer=defer)
 
 
 def jsd_half_block(rt, mod, feat, which, step):
@@ -393,9 +394,9 @@ def jsd_join(rt, mod, hi, ht, acc, gout):
     return out, df1, df2
 
 
-def jsd_half_backward(rt, half, df):
-    """MI-block backward of one modality; returns the gradient of its features (prior part included)."""
-    return mi_block_backward(rt, half["blk"], half["c"], df, half["dprior"])
+def jsd_half_backward(rt, half, df, defer=None):
+    """MI-block backward of one modality; returns the gradient of its features (prior part included). defer: see mi_block_backward."""
+    return mi_block_backward(rt, half["blk"], half["c"], df, half["dprior"], defer=defer)
 
 
 class _JSDLossFn(torch.autograd.Function):

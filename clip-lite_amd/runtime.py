@@ -305,6 +305,7 @@ class DeviceRuntime:
         import os
         self.s2_classes = True             # 3x3/stride-2 dgrads as four parity-class GEMMs (attribute: tools flip it for A/B runs)
         self.fuse_bn_backward = True       # BatchNorm-backward reductions inside the dgrad epilogues (resnet.py)
+        self.defer_head_wgrads = True      # captured step: the loss heads' Linear weight gradients ride in the encoders' grouped launches (train_loop.py)
         self.compact_shortcut = True       # stride-2 shortcuts' input gradients kept compact, added by the main branch's BatchNorm-backward dgrad (resnet.py; bf16)
         self.stat_replicas_fixed = False   # True: 8 statistics replicas everywhere (new_stats; tools/ab_runtime.py stat_replicas_fixed=1 for the A/B)
         self.fp8 = False                   # image-encoder forward convs on OCP e4m3 operands, quantised by their producers (BASELINE configs[4]; fp8.py); bf16 mode only

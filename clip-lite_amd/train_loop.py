@@ -81,9 +81,10 @@ class TrainStep:
         # defer_update the step ends after [norm + update of the image encoder]; the text encoder's and the heads' share (85 % of the parameters,
         # 0.7 of the 0.87 ms) runs as the FIRST thing of the next step on the text encoder's stream, which idles ~1 ms there while the image
         # forward is still going. Same kernels, same arguments, every tensor updated exactly once per step: parameters are bit-identical to the
-        # undeferred step once finish() has run. Anything that reads parameters between steps (checkpoint, evaluation, state_dict) must call
-        # finish() first; train_loop.main and bench.py do. MEASURED NEUTRAL on MI355X (17.32 vs 17.35 ms: the update and the first stages of the
-        # image forward are both HBM-bound, so the overlap is zero-sum) and therefore OFF by default; kept as an option with its exactness test.
+        # undeferred step once finish() has run. Anything that reads parameters between steps (checkpoint, evaluation, state_dict) completes it
+        # first: Arena.flush_pending (state_dict / load_state_dict / refresh_lowp / eval forward call it), train_loop.main and bench.py call
+        # finish(). Round 3 measured it neutral (17.32 vs 17.35 ms); with round 4's shorter side stream it gains 0.1 ms (15.14 -> 15.04, same box):
+        # train_loop.main and bench.py switch it on; the constructor default stays off (tests build TrainStep directly).
         self.defer_update = bool(defer_update)
         self._pending_rest = False
         if self.defer_update:          # readers of the parameters outside the step complete the update first (Arena.flush_pending)
@@ -211,12 +212,17 @@ class TrainStep:
             keep["sites"] = (st.site() if m.loss.image_prior else None, st.site() if m.loss.text_prior else None)
             keep["acc"] = torch.zeros(8, device=rt.device, dtype=torch.float32)
             keep["gout"] = torch.ones(1, device=rt.device, dtype=torch.float32)
-            keep["ht"] = jsd_half_forward(rt, m.loss, keep["txt"], "text", st, keep["sites"][1], keep["acc"], keep["gout"])
+            # the heads' weight gradients (9 Linear layers per modality incl. the priors: ~0.07 ms of latency-bound launches per chain) are collected:
+            # the text half's ride in BERT's group, the image half's in a group of their own that replays with the first image segment's
+            keep["wg_t"] = hip.WgradGroup(rt.dt, ws["t"], zeroed=True)
+            keep["wg_h"] = hip.WgradGroup(rt.dt, ws["h"], zeroed=True)
+            keep["dh_t"], keep["dh_i"] = (keep["wg_t"], keep["wg_h"]) if rt.defer_head_wgrads else (None, None)
+            keep["ht"] = jsd_half_forward(rt, m.loss, keep["txt"], "text", st, keep["sites"][1], keep["acc"], keep["gout"], defer=keep["dh_t"])
 
         # the image half in two pieces that do not depend on each other: the prior discriminator (forward + backward, ~12 latency-bound launches)
         # on the side stream, idle between the text heads and the text backward, beside the MI block's forward on the main stream
         def heads_p1():
-            keep["dprior_i"] = jsd_half_prior(rt, m.loss, keep["img"], "image", keep["step_h"], keep["sites"][0], keep["acc"], keep["gout"])
+            keep["dprior_i"] = jsd_half_prior(rt, m.loss, keep["img"], "image", keep["step_h"], keep["sites"][0], keep["acc"], keep["gout"], defer=keep["dh_i"])
 
         def heads_b1():
             keep["hi"] = jsd_half_block(rt, m.loss, keep["img"], "image", keep["step_h"])
@@ -231,10 +237,10 @@ class TrainStep:
                                                                   "visual_loss": out[3], "textual_loss": out[4]}}
 
         def heads_m2():
-            keep["dimg"] = jsd_half_backward(rt, keep["hi"], keep["df1"])
+            keep["dimg"] = jsd_half_backward(rt, keep["hi"], keep["df1"], defer=keep["dh_i"])
 
         def heads_t2():
-            keep["dtxt"] = jsd_half_backward(rt, keep["ht"], keep["df2"])
+            keep["dtxt"] = jsd_half_backward(rt, keep["ht"], keep["df2"], defer=keep["dh_t"])
 
         # image backward in chain segments with the weight gradients collected instead of launched (resnet_backward's `defer`): each segment's
         # replay as one grouped launch on the text encoder's stream — after BERT's backward, beside the HBM-bound BatchNorm chain of the
@@ -247,7 +253,7 @@ class TrainStep:
         cuts = [n1 + n2, n1, 0]
         segs = [f"s{i}" for i in range(len(cuts))]
         from . import hip
-        ws = {k: hip.WgradGroup.alloc_workspace(rt.device) for k in segs + ["t"]}      # pinned staging cannot be allocated inside a capture
+        ws = {k: hip.WgradGroup.alloc_workspace(rt.device) for k in segs + ["t", "h"]}      # pinned staging cannot be allocated inside a capture
 
         def image_bwd(i):
             def fn():
@@ -256,6 +262,9 @@ class TrainStep:
                 resnet_backward(rt, inet, keep["ctx_i"], keep["dimg"].contiguous() if i == 0 else None, defer=keep["wg_" + segs[i]],
                                 stop_block=cuts[i], resume=i > 0)
             return fn
+
+        def wgrad_heads():
+            keep["wg_h"].launch()
 
         def wgrad(i):
             # the last segment's members that are launches of their own (layer1's three patch-resident 3 x 3 weight gradients, the stem's weight
@@ -267,7 +276,7 @@ class TrainStep:
             keep["wg_" + segs[-1]].launch_extras()
 
         def text_bwd():
-            keep["wg_t"] = hip.WgradGroup(rt.dt, ws["t"], zeroed=True)          # BERT's 49 linear weight gradients: one grouped launch at the end of its backward
+            # BERT's 49 linear weight gradients (+ the text heads', collected in heads_t1 / heads_t2): one grouped launch at the end of its backward
             bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous(), defer=keep["wg_t"])
             keep["wg_t"].launch()
 
@@ -304,6 +313,8 @@ class TrainStep:
                 capture("text_bwd", pool_side, text_bwd)
                 for i, sg in enumerate(segs):       # every segment's weight gradients but the last one's replay on the side stream
                     capture("image_bwd_" + sg, pool_main, image_bwd(i))
+                    if i == 0:
+                        capture("wgrad_heads", pool_side, wgrad_heads)          # (capture order = replay order on a stream: shared pool)
                     capture("wgrad_" + sg, pool_side if i < len(segs) - 1 else pool_main, wgrad(i))
                 capture("wgrad_last_extras", pool_side, wgrad_last_extras)
                 capture("norm", pool_main, norm)
@@ -341,19 +352,20 @@ class TrainStep:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             G["heads_t2"].replay()                 # text block backward ...
-            if ex is not None:
-                ev_t2 = torch.cuda.Event()
-                ev_t2.record(side)
             G["text_bwd"].replay()                 # ... straight into BERT's backward
         G["heads_m2"].replay()                     # image block backward, beside it
         if ex is not None:
-            main.wait_event(ev_t2)                 # the heads' gradients are final once both halves' backward ran
-            ex.reduce_span(*self._regions["loss"], after=main)
             ex.reduce_span(*self._regions["text_encoder"], after=side)          # ordered after BERT's backward only (the event is taken now)
         for i, sg in enumerate(self._segs[:-1]):   # a segment's weight gradients go to the side stream as soon as its chain is enqueued
             G["image_bwd_" + sg].replay()
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                if i == 0:
+                    # the image heads' weight gradients (collected by heads_p1 / heads_m2; the text heads' rode in BERT's group): behind BERT's
+                    # backward and behind the main stream's heads_m2. Every gradient of the loss module is final after this launch
+                    G["wgrad_heads"].replay()
+                    if ex is not None:
+                        ex.reduce_span(*self._regions["loss"], after=side)
                 G["wgrad_" + sg].replay()
             if ex is not None:                     # BatchNorm gradients came with the chain (main), weight gradients with the group (side, which waited for main)
                 ex.reduce_span(*self._seg_spans[i], after=side)
@@ -553,7 +565,7 @@ def main(_A: argparse.Namespace):
         checkpoint_manager = CheckpointManager(_A.checkpoints_dir + _C.RUN_ID, model=model, optimizer=optimizer, scheduler=scheduler, scaler=scaler)
 
     step = TrainStep(model, optimizer, scheduler, scaler, _C.OPTIM.CLIP_GRAD_NORM, exchange, graph=not _A.no_hip_graph,
-                     pad_to=min(int(_C.DATA.MAX_CAPTION_LENGTH), 32), allow_eager_fallback=_A.allow_eager_fallback)
+                     pad_to=min(int(_C.DATA.MAX_CAPTION_LENGTH), 32), allow_eager_fallback=_A.allow_eager_fallback, defer_update=True)
     for iteration in range(start_iteration + 1, _C.OPTIM.NUM_ITERATIONS + 1):
         timer.tic()
         batch = next(train_dataloader_iter)
