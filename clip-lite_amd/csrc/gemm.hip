@@ -160,6 +160,10 @@ int colstats_det(const clite_epilogue& ep, const RowMap& rm, int M, int N, hipSt
   return (int)hipGetLastError();
 }
 
+// Split-bf16 form of the exact-f32 mode's MFMA loops (igemm_dma.h split_bf16x3): process-wide switch like the deterministic mode
+static std::atomic<int> g_f32_split{0};
+bool f32_split() { return g_f32_split.load(std::memory_order_relaxed) != 0; }
+
 template <typename T, class CFG, class LA, class LB>
 int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, int Ktot, int splits, hipStream_t st, RowMap rm = RowMap{}) {
   if (deterministic()) {
@@ -222,7 +226,15 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
           else if (form == 3) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 3>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
           else hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
         } else {
-          hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+          bool done = false;
+          if constexpr (sizeof(T) == 4) {
+            if (f32_split()) {
+              hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0, true>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+              done = true;
+            }
+          }
+          if (!done)
+            hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
         }
         return (int)hipGetLastError();
       } else {
@@ -236,6 +248,15 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
       hipLaunchKernelGGL((igemm_dma_kernel_g2<T, CFG, DA, DB, 3>), grid, dim3(512), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm,
                          M, N, ktiles, per, xsplits);
       return (int)hipGetLastError();
+    }
+    if constexpr (sizeof(T) == 4) {
+      if (f32_split()) {          // f32 storage, three bf16 MFMAs per product (clite_set_f32_split)
+        if (4 * STAGE <= 65536 && (long)tiles * splits <= 2 * 256 && per >= 4)
+          hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 4, 0, true>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, per, xsplits);
+        else
+          hipLaunchKernelGGL((igemm_dma_kernel<T, CFG, DA, DB, 3, 0, true>), grid, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, per, xsplits);
+        return (int)hipGetLastError();
+      }
     }
     bool deep = 4 * STAGE <= 65536 && (long)tiles * splits <= 2 * 256 && per >= 4 && stages_pref() != 3;
     if (deep || (stages_pref() == 4 && 4 * STAGE <= 65536))
@@ -693,6 +714,8 @@ int check_gemm(const clite_epilogue* ep, int dtype, int M, int N, int K, int lda
 extern "C" int clite_abi_version(void) { return CLITE_ABI_VERSION; }
 extern "C" int clite_set_deterministic(int on) { g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed); return 0; }
 extern "C" int clite_get_deterministic(void) { return deterministic() ? 1 : 0; }
+extern "C" int clite_set_f32_split(int on) { g_f32_split.store(on ? 1 : 0, std::memory_order_relaxed); return 0; }
+extern "C" int clite_get_f32_split(void) { return f32_split() ? 1 : 0; }
 #if CLITE_STAMP
 extern "C" int clite_dbg_read(unsigned long long* host, int n) {     // diagnostic builds only
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(clite_dbg), (size_t)n * 8, 0, hipMemcpyDeviceToHost);

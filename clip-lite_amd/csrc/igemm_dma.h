@@ -131,6 +131,13 @@ struct DmaKC {
     int r = x0 + (lane & 31), k = kk * 2 + (lane >> 5);           // k in [0,16)
     return *(const float*)(lds + r * 64 + (((k >> 2) ^ ((r >> 2) & 3)) << 4) + (k & 3) * 4);
   }
+  // f32 only (a K tile = 16 values = one bf16 32 x 32 x 16 k-step): the 8 consecutive k = 8 (lane >> 5) .. + 7 of row x0 + (lane & 31) — the operand
+  // of one MFMA of the split-bf16 form (split_bf16x3): two 16-byte reads
+  DEV static void frag8_f32(const char* lds, int x0, int lane, float (&v)[8]) {
+    const int r = x0 + (lane & 31), h = lane >> 5, sw = (r >> 2) & 3;
+    const f32x4 a = *(const f32x4*)(lds + r * 64 + (((2 * h) ^ sw) << 4)), b = *(const f32x4*)(lds + r * 64 + (((2 * h + 1) ^ sw) << 4));
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  }
 };
 
 // 64-byte-segment swizzle of an XC image row k (row = COLS*sizeof(T) bytes)
@@ -209,6 +216,12 @@ struct DmaXCStrided {
     int c = (x * 4) >> 4, within = (x * 4) & 15;
     return *(const float*)(lds + k * ROWB + ((c ^ (xc_seg_xor<ROWB>(k) << 2)) << 4) + within);
   }
+  // (f32, split-bf16 form) the 8 k-rows 8 (lane >> 5) .. + 7 of column x0 + (lane & 31): eight 4-byte reads — the contraction index is the slow one
+  DEV static void frag8_f32(const char* lds, int x0, int lane, float (&v)[8]) {
+    const int x = x0 + (lane & 31), c = (x * 4) >> 4, within = (x * 4) & 15, k0 = 8 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *(const float*)(lds + (k0 + j) * ROWB + ((c ^ (xc_seg_xor<ROWB>(k0 + j) << 2)) << 4) + within);
+  }
 };
 
 // ---- XC gather (wgrad's activation operand): k = output pixel p, x = (r, s, ci)
@@ -262,6 +275,7 @@ struct DmaXCGather {
   DEV static int frag_off(int x0, int ks, int lane) { return L::frag_off(x0, ks, lane); }
   DEV static bf16x8 frag_at(const char* p) { return L::frag_at(p); }
   DEV static float frag32(const char* lds, int x0, int kk, int lane) { return L::frag32(lds, x0, kk, lane); }
+  DEV static void frag8_f32(const char* lds, int x0, int lane, float (&v)[8]) { L::frag8_f32(lds, x0, lane, v); }
 };
 
 // uniform issue() signature over the three loaders
@@ -273,9 +287,49 @@ template <typename T, int ROWS, int BK, bool D> struct DmaIssue<DmaKC<T, ROWS, B
   DEV static void go(const L& l, typename L::State& st, char* lds, int wave, int, int) { l.issue(st, lds, wave); }
 };
 
+// Split-bf16 form of an f32 product (round 4): x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi); a b ~ lo_a hi_b + hi_a lo_b + hi_a hi_b
+// on three bf16 MFMAs (products of bf16 values are exact in f32, the accumulation is f32): relative error ~2^-17 per product instead of the
+// bf16 path's 2^-9, at 3/16 of the f32 MFMA's matrix-pipe time per product. f32 storage is untouched. Selected at run time for the exact-f32
+// mode's launches (clite_set_f32_split); the default f32 form stays the k-ordered fmaf chain of v_mfma_f32_32x32x2_f32.
+DEV void split_bf16x3(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bf16 h = f2bf(v[e]);
+    hi[e] = h;
+    lo[e] = f2bf(v[e] - bf2f(h));
+  }
+}
+// one K tile (16 f32 = one bf16 k-step) of the split form: fragments from the f32 LDS images, split in registers, 3 MFMAs per block
+template <class CFG, class LA, class LB>
+DEV void mma_tile_f32_split(const char* abuf, const char* bbuf, int wm0, int wn0, int lane, f32x16 (&acc)[CFG::RM][CFG::RN]) {
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    float v[8];
+    LA::frag8_f32(abuf, wm0 + i * 32, lane, v);
+    split_bf16x3(v, ah[i], al[i]);
+  }
+#pragma unroll
+  for (int j = 0; j < RN; ++j) {
+    float v[8];
+    LB::frag8_f32(bbuf, wn0 + j * 32, lane, v);
+    split_bf16x3(v, bh[j], bl[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {          // small terms first
+      acc[i][j] = mfma32_bf16(al[i], bh[j], acc[i][j]);
+      acc[i][j] = mfma32_bf16(ah[i], bl[j], acc[i][j]);
+      acc[i][j] = mfma32_bf16(ah[i], bh[j], acc[i][j]);
+    }
+}
+
 // EPI: 0 = generic fused epilogue, 1 = BatchNorm-backward epilogue (igemm_epilogue_bn), 2 = plain bf16 store (+ bias, + column statistics)
-template <typename T, class CFG, class LA, class LB, int NSTAGE, int EPI = 0>
+template <typename T, class CFG, class LA, class LB, int NSTAGE, int EPI = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int ktiles_per_split, int xsplits) {
+  static_assert(!SPLIT || (sizeof(T) == 4 && CFG::BK == 16), "the split-bf16 form is an f32 form: one K tile = one bf16 k-step");
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
   constexpr int STAGE = LA::BYTES + LB::BYTES;
@@ -396,17 +450,21 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
         DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
       }
 #endif
+      if constexpr (SPLIT) {
+        mma_tile_f32_split<CFG, LA, LB>(abuf, bbuf, wm0, wn0, lane, acc);
+      } else {
 #pragma unroll
-      for (int kk = 0; kk < BK / 2; ++kk) {
-        float af[RM], bfr[RN];
+        for (int kk = 0; kk < BK / 2; ++kk) {
+          float af[RM], bfr[RN];
 #pragma unroll
-        for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
+          for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
 #pragma unroll
-        for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
+          for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+          for (int i = 0; i < RM; ++i)
 #pragma unroll
-          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+            for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+        }
       }
     }
 #else
@@ -436,7 +494,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
 // range read as zero / are not stored), which costs a short main loop and an epilogue proportional to its rows. With rows_per_wg =
 // ceil(M / (512 / column tiles)) all workgroups are resident at once and finish together. rows_per_wg = BM is the plain one-tile form
 // (windowed convs, whose main loop is long: a partial tile would cost a whole one).
-template <typename T, class CFG, class LA, class LB, int FORM = 0>
+template <typename T, class CFG, class LA, class LB, int FORM = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dma_bn_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int rows_per_wg) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
@@ -558,17 +616,21 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
           DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
           DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
         }
+        if constexpr (SPLIT) {
+          mma_tile_f32_split<CFG, LA, LB>(abuf, bbuf, wm0, wn0, lane, acc);
+        } else {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-          float af[RM], bfr[RN];
+          for (int kk = 0; kk < BK / 2; ++kk) {
+            float af[RM], bfr[RN];
 #pragma unroll
-          for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
+            for (int i = 0; i < RM; ++i) af[i] = LA::frag32(abuf, wm0 + i * 32, kk, lane);
 #pragma unroll
-          for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
+            for (int j = 0; j < RN; ++j) bfr[j] = LB::frag32(bbuf, wn0 + j * 32, kk, lane);
 #pragma unroll
-          for (int i = 0; i < RM; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+              for (int j = 0; j < RN; ++j) acc[i][j] = mfma32_f32(af[i], bfr[j], acc[i][j]);
+          }
         }
       }
       if (++buf == NSTAGE) buf = 0;

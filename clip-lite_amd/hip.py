@@ -71,6 +71,8 @@ _SIGNATURES = {
     "clite_set_deterministic": [_I],
     "clite_get_deterministic": [],
     "clite_set_tile_policy": [_I],
+    "clite_set_f32_split": [_I],
+    "clite_get_f32_split": [],
     "clite_gemm_nt": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
     "clite_gemm_nn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
     "clite_gemm_tn": [_V, _I, _V, _I, _I, _I, _I, _I, _V, _V],
@@ -156,6 +158,8 @@ def lib():
         _lib = l
         if os.environ.get("CLITE_DETERMINISTIC", "0") not in ("", "0"):
             l.clite_set_deterministic(1)
+        if os.environ.get("CLITE_F32_SPLIT", "0") not in ("", "0"):
+            l.clite_set_f32_split(1)
     return _lib
 
 
@@ -167,6 +171,16 @@ def set_deterministic(on=True):
 
 def is_deterministic():
     return bool(lib().clite_get_deterministic())
+
+
+def set_f32_split(on=True):
+    """Split-bf16 form of the exact-f32 mode's matrix products (include/clite.h: clite_set_f32_split): f32 storage, three bf16 MFMAs per product,
+    ~2^-17 relative error per product. Also switched on by the environment variable CLITE_F32_SPLIT=1."""
+    lib().clite_set_f32_split(int(bool(on)))
+
+
+def is_f32_split():
+    return bool(lib().clite_get_f32_split())
 
 
 TILE_AUTO, TILE_W128, TILE_W256x128, TILE_W256, TILE_NARROW = 0, 1, 2, 3, 4

@@ -40,6 +40,15 @@ int clite_abi_version(void);
 int clite_set_deterministic(int on);
 int clite_get_deterministic(void);
 
+/* ABI v10 — split-bf16 form of the exact-f32 mode (process-wide, like the deterministic switch). With dtype CLITE_F32 the GEMM / convolution entry
+ * points keep f32 storage, f32 accumulation and f32 epilogues, but form every product on three bf16 MFMAs: x = hi + lo with hi = bf16(x),
+ * lo = bf16(x - hi), a b ~ lo_a hi_b + hi_a lo_b + hi_a hi_b (bf16 x bf16 products are exact in f32). Relative error ~2^-17 per product — between the
+ * bf16 path's 2^-9 and the default f32 path's exact fmaf chain (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 matrix rate) — at 3/16 of the default's
+ * matrix-pipe time. The full-size parity test (tests/test_gpu_model.py) holds this form to the same 1e-4 loss bar as the exact form. Off by default;
+ * bf16 launches are unaffected. */
+int clite_set_f32_split(int on);
+int clite_get_f32_split(void);
+
 /* Tile-shape policy of the bf16 GEMM / conv launchers (process-wide, default 0). 0: automatic — per launch, the largest of the 128 x 128,
  * 256 x 128 and 256 x 256 wide-K tiles (K tile 64 = whole 128-byte lines, 8 waves; clip-lite_amd/csrc/igemm_wide.h) that still fills the
  * 256 CUs. 1 / 2 / 3: force that wide tile wherever an instantiation exists. 4: keep every launch on the 4-wave 128 x 128 x 32 kernels.

@@ -659,3 +659,66 @@ def test_bn_backward_dgrad_with_subsampled_residual(dtype, N, H, W, Cc, K):
     assert lib().clite_conv_fwd(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == -1
     ep.mask_after_residual = 0
     assert lib().clite_conv_dgrad_wt(ptr(dyb), ptr(wtb), C.byref(cv), C.byref(ep), None) == -1
+
+
+@pytest.mark.policy_independent
+def test_f32_split_bf16_form():
+    """clite_set_f32_split (ABI v10): the exact-f32 mode's launches with every product formed on three bf16 MFMAs (hi/lo split in registers, f32
+    storage and accumulation). Against float64 numpy on f32 inputs: GEMM nt / nn / tn (k-contiguous and k-strided LDS images, ragged edges, a K
+    that is not a multiple of the tile), a 3 x 3 convolution forward / input gradient / weight gradient, and the BatchNorm-backward dgrad epilogue.
+    Bar: 3e-5 of max|ref| (the split form's ~2^-17 per product; the bf16 path sits at ~4e-3, the exact form at ~1e-6 on these sizes)."""
+    L = lib()
+    L.clite_set_f32_split.argtypes = [C.c_int]
+    rng = np.random.default_rng(11)
+    try:
+        assert L.clite_set_f32_split(1) == 0 and L.clite_get_f32_split() == 1
+        M, N, K = 200, 136, 104
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = rng.standard_normal((N, K)).astype(np.float32)
+        out = np.zeros((M, N), np.float32)
+        assert L.clite_gemm_nt(ptr(A), K, ptr(B), K, M, N, K, F32, C.byref(make_ep(out, N, out_f32=True)), None) == 0
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        err_nt = np.abs(out - ref).max() / np.abs(ref).max()
+        assert err_nt < 3e-5, err_nt
+        Bn = np.ascontiguousarray(B.T)
+        out2 = np.zeros((M, N), np.float32)
+        assert L.clite_gemm_nn(ptr(A), K, ptr(Bn), N, M, N, K, F32, C.byref(make_ep(out2, N, out_f32=True)), None) == 0
+        assert np.abs(out2 - ref).max() / np.abs(ref).max() < 3e-5
+        At = np.ascontiguousarray(A.T)          # [K][M]
+        out3 = np.ones((M, N), np.float32)
+        assert L.clite_gemm_tn(ptr(At), M, ptr(Bn), N, M, N, K, F32, C.byref(make_ep(out3, N, out_f32=True, atomic=True)), None) == 0
+        assert np.abs(out3 - 1 - ref).max() / np.abs(ref).max() < 3e-5
+        # convolution, all three directions, and the BatchNorm-backward epilogue (run-time form)
+        Nn, H, W, Cc, Kc = 2, 9, 7, 64, 32
+        cv = Conv(F32, Nn, H, W, Cc, Kc, 3, 3, 1, 1, H, W)
+        x = rng.standard_normal((Nn, H, W, Cc)).astype(np.float32)
+        w = (rng.standard_normal((Kc, 3, 3, Cc)) * 0.2).astype(np.float32)
+        dy = rng.standard_normal((Nn, H, W, Kc)).astype(np.float32)
+        y = np.zeros((Nn, H, W, Kc), np.float32)
+        assert L.clite_conv_fwd(ptr(x), ptr(w), C.byref(cv), C.byref(make_ep(y, Kc, out_f32=True)), None) == 0
+        r = conv_ref(x.astype(np.float64), w.astype(np.float64), 1, 1)
+        assert np.abs(y - r).max() / np.abs(r).max() < 3e-5
+        Mr = Nn * H * W
+        aux = rng.standard_normal((Mr, Cc)).astype(np.float32)
+        yb = (rng.standard_normal((Mr, Cc)) + 2).astype(np.float32)
+        fst = np.zeros((2, 3, Cc), np.float32)
+        fst[:, 0] = yb.sum(0) / 2
+        dx = np.zeros((Mr, Cc), np.float32)
+        dst = np.zeros((2, 3, Cc), np.float32)
+        ep = make_ep(dx, Cc, out_f32=True, dact_aux=aux, dact=1, colsum=dst)
+        ep.colsum_replicas, ep.colsum_stride = 2, 3 * Cc
+        ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = ptr(yb), ptr(fst), 2, 3 * Cc, 1.0 / Mr
+        assert L.clite_conv_dgrad(ptr(dy), ptr(w), C.byref(cv), C.byref(ep), None) == 0
+        g = conv_dgrad_ref(dy.astype(np.float64), w.astype(np.float64), (Nn, H, W, Cc), 1, 1).reshape(Mr, Cc) * (aux > 0)
+        assert np.abs(dx - g).max() / np.abs(g).max() < 3e-5
+        assert np.abs(dst.sum(0)[0] - g.sum(0)).max() / np.abs(g.sum(0)).max() < 1e-4
+        dw = np.zeros((Kc, 3, 3, Cc), np.float32)
+        assert L.clite_conv_wgrad(ptr(dy), ptr(x), C.byref(cv), ptr(dw), None) == 0
+        rw = conv_wgrad_ref(dy.astype(np.float64), x.astype(np.float64), (Kc, 3, 3, Cc), 1, 1)
+        assert np.abs(dw - rw).max() / np.abs(rw).max() < 3e-5
+    finally:
+        L.clite_set_f32_split(0)
+    # the default (exact) form on the first problem, for scale
+    out_e = np.zeros((M, N), np.float32)
+    assert L.clite_gemm_nt(ptr(A), K, ptr(B), K, M, N, K, F32, C.byref(make_ep(out_e, N, out_f32=True)), None) == 0
+    assert np.abs(out_e - ref).max() / np.abs(ref).max() < 2e-6
