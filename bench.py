@@ -106,7 +106,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_hbm_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r4_hbm_traffic.json")
 
 
 def pmc_traffic(args):
@@ -120,10 +120,10 @@ def pmc_traffic(args):
         with open(TRAFFIC_JSON) as f:
             d = json.load(f)
     except Exception:      # noqa: BLE001
-        return None, "profiles/r3_hbm_traffic.json absent"
+        return None, "profiles/r4_hbm_traffic.json absent"
     if d.get("kernel_source_hash") != kernel_source_hash():
         return None, f"PMC passes of {d.get('date')} were taken on other kernel sources (hash {d.get('kernel_source_hash')}): re-run tools/pmc_traffic.py"
-    return d["igemm_hbm_GB_per_step"] * 1e9, f"rocprofv3 PMC passes of {d.get('date')}, kernel sources {d['kernel_source_hash']} (profiles/r3_hbm_traffic.json)"
+    return d["igemm_hbm_GB_per_step"] * 1e9, f"rocprofv3 PMC passes of {d.get('date')}, kernel sources {d['kernel_source_hash']} (profiles/r4_hbm_traffic.json)"
 
 
 def describe_launch(name, a, esz):

@@ -17,6 +17,8 @@ def table(db, counter):
 
 
 def family(n):
+    if "conv3x3_" in n:
+        return "patch-resident 3 x 3 kernels"
     if "igemm_group" in n:
         return "igemm grouped weight gradients"
     if "igemm_wide" in n:

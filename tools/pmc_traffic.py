@@ -2,7 +2,7 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_f -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_w -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline
-    python tools/pmc_traffic.py <fetch .db> <write .db> profiles/r3_hbm_traffic.json
+    python tools/pmc_traffic.py <fetch .db> <write .db> profiles/r4_hbm_traffic.json
 
 The output records the date and bench.kernel_source_hash() (sha256 over csrc/, include/clite.h and the Python executors): bench.py reports
 `roofline.traffic` only while that hash matches the tree it runs from, so a kernel change without new PMC passes yields null, not a stale number.
@@ -26,7 +26,7 @@ def per_family(db, counter):
     for name, val, n in rows:
         if "sgd_step_kernel" in name:
             steps = n
-        key = "igemm" if ("igemm" in name or "splitk_finish" in name or "colstats_det" in name) else "bn" if "bn_" in name else "other"
+        key = "igemm" if ("igemm" in name or "splitk_finish" in name or "colstats_det" in name or "conv3x3_" in name or "wgrad_patch_reduce" in name) else "bn" if "bn_" in name else "other"
         fam[key][0] += val
         fam[key][1] += n
     return fam, steps
