@@ -767,12 +767,12 @@ extern "C" int clite_conv_wgrad(const void* dy, const void* x, const clite_conv*
 
 // The 64 -> 64 3 x 3 / stride 1 weight gradient on the patch-resident kernel (conv_patch.hip). Returns 1 when the problem is not one it covers
 // (shape, dtype, workspace too small, deterministic mode, a forced tile policy): the caller then takes clite_conv_wgrad / the grouped launch.
-extern "C" int clite_conv_wgrad_patch_workspace(unsigned long long* nbytes) {
+extern "C" int clite_conv_wgrad_patch_workspace(uint64_t* nbytes) {
   if (!nbytes) return -1;
-  *nbytes = (unsigned long long)conv3x3_wgrad_patch_workspace();
+  *nbytes = (uint64_t)conv3x3_wgrad_patch_workspace();
   return 0;
 }
-extern "C" int clite_conv_wgrad_patch(const void* dy, const void* x, const clite_conv* cv, float* dw, void* ws, unsigned long long ws_bytes, void* stream) {
+extern "C" int clite_conv_wgrad_patch(const void* dy, const void* x, const clite_conv* cv, float* dw, void* ws, uint64_t ws_bytes, void* stream) {
   if (check_conv(cv) || !dw) return -1;
   if (deterministic() || tile_policy_value() != 0) return 1;
   const int rc = launch_conv3x3_wgrad_patch(dy, x, *cv, dw, ws, (size_t)ws_bytes, (hipStream_t)stream);

@@ -153,8 +153,8 @@ int clite_conv_wgrad(const void* dy, const void* x, const clite_conv* cv, float*
  * ws: caller-owned scratch of at least clite_conv_wgrad_patch_workspace() bytes (per-workgroup partial sums; contents undefined afterwards).
  * Returns 0 when launched, 1 when the problem is not one it covers (other shape / dtype, workspace too small, deterministic mode, forced tile
  * policy): nothing was launched and the caller takes clite_conv_wgrad or clite_wgrad_group; < 0 on errors. */
-int clite_conv_wgrad_patch_workspace(unsigned long long* nbytes);
-int clite_conv_wgrad_patch(const void* dy, const void* x, const clite_conv* cv, float* dw, void* ws, unsigned long long ws_bytes, void* stream);
+int clite_conv_wgrad_patch_workspace(uint64_t* nbytes);
+int clite_conv_wgrad_patch(const void* dy, const void* x, const clite_conv* cv, float* dw, void* ws, uint64_t ws_bytes, void* stream);
 
 /* Grouped weight gradients: every member is one independent dW (f32) += A^T B of the backward pass, all enqueued as ONE launch per tile
  * family so that thousands of workgroups exist without splitting the short-K members (a lone weight gradient has a few dozen output tiles
