@@ -166,47 +166,66 @@ def bert_forward(rt, net, input_ids, attention_mask, step):
     s0 = _alloc(rt, M, Hd)
     hip.embed_fwd(dt, ids, A.w(emb.word_embeddings.weight), A.w(emb.position_embeddings.weight), A.w(emb.token_type_embeddings.weight),
                   s0, M, L, Hd, net.vocab)
-    h = _alloc(rt, M, Hd)
-    st0 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
-    d0 = drop(p_h)
-    hip.layernorm_fwd(dt, s0, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, h, st0, M, Hd, d0)
-    ctx = {"B": B, "L": L, "ids": ids, "mask": mask, "s0": s0, "st0": st0, "d0": d0, "layers": []}
-    fp8 = rt.fp8_text and rt.lowp
+    # fp8 forward (BASELINE configs[4]; fp8.Fp8Text): QKV, FFN1 and FFN2 read e4m3 copies their producers wrote (LayerNorm forward, FFN1's epilogue)
+    from .fp8 import text_state
+    f8 = text_state(rt, net)
+    if f8 is not None:
+        f8.begin_step()
+    nl = len(net.encoder.layer)
+    prod = (lambda l, j, Cc: f8.producer(l, j, M, Cc, training)) if f8 is not None else (lambda l, j, Cc: (None, None))
 
-    def linear(x, w, Mr, N, K, ep):
-        """x [Mr][K] @ w[N][K]^T through the fused epilogue: bf16 MFMA, or OCP e4m3 operands with per-tensor current scaling (clite_gemm_nt_fp8)."""
-        if fp8:
-            hip.gemm_nt_fp8(hip.Fp8Tensor(x, dt), hip.Fp8Tensor(w, dt), Mr, N, K, ep)
+    def linear(x, x8, w, w8, Mr, N, K, ep):
+        """x [Mr][K] @ w[N][K]^T through the fused epilogue: bf16 MFMA, or OCP e4m3 operands when the producer of x left its e4m3 copy x8."""
+        if x8 is not None:
+            hip.gemm_nt_fp8(x8, w8(), Mr, N, K, ep)
         else:
             hip.gemm_nt(dt, x, w, Mr, N, K, ep)
 
-    for layer in net.encoder.layer:
+    h = _alloc(rt, M, Hd)
+    st0 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
+    d0 = drop(p_h)
+    q, h8 = prod(0, 0, Hd) if nl else (None, None)
+    hip.layernorm_fwd(dt, s0, emb.LayerNorm.weight, emb.LayerNorm.bias, emb.LayerNorm.eps, h, st0, M, Hd, d0, fp8=q)
+    ctx = {"B": B, "L": L, "ids": ids, "mask": mask, "s0": s0, "st0": st0, "d0": d0, "layers": []}
+
+    for l, layer in enumerate(net.encoder.layer):
         sa, so = layer.attention.self, layer.attention.output
         wqkv = A.span([sa.query.weight, sa.key.weight, sa.value.weight])
         bqkv = A.span([sa.query.bias, sa.key.bias, sa.value.bias], lowp=False)
         qkv = _alloc(rt, M, 3 * Hd)
-        linear(h, wqkv, M, 3 * Hd, Hd, hip.epilogue(qkv, 3 * Hd, bias=bqkv))
+        linear(h, h8, wqkv, lambda: f8.weight(l, 0, (3 * Hd, Hd)), M, 3 * Hd, Hd, hip.epilogue(qkv, 3 * Hd, bias=bqkv))
         ctxt = _alloc(rt, M, Hd)
         da = drop(p_a)
         hip.attention_fwd(dt, qkv, mask, ctxt, B, L, heads, da)
         s1 = _alloc(rt, M, Hd)
         d1 = drop(p_h)
-        linear(ctxt, A.w(so.dense.weight), M, Hd, Hd, hip.epilogue(s1, Hd, bias=so.dense.bias, drop=d1, residual=h))
+        hip.gemm_nt(dt, ctxt, A.w(so.dense.weight), M, Hd, Hd, hip.epilogue(s1, Hd, bias=so.dense.bias, drop=d1, residual=h))
         h1 = _alloc(rt, M, Hd)
         st1 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
-        hip.layernorm_fwd(dt, s1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, h1, st1, M, Hd)
+        q, h18 = prod(l, 1, Hd)
+        hip.layernorm_fwd(dt, s1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.eps, h1, st1, M, Hd, fp8=q)
         f = _alloc(rt, M, inner)      # FFN pre-activation (kept for GELU')
         g = _alloc(rt, M, inner)
-        linear(h1, A.w(layer.intermediate.dense.weight), M, inner, Hd,
-               hip.epilogue(g, inner, bias=layer.intermediate.dense.bias, act=hip.ACT_GELU, preact=f))
+        q, g8 = prod(l, 2, inner)
+        if h18 is None and q is not None:
+            # FFN1 itself still runs in bf16 (no scale for its input yet): its GELU output's amax / e4m3 copy come from the stand-alone quantiser's
+            # path next step - record nothing here (the bf16 launch has no fused quantiser), so that slot becomes ready one step after h1's
+            f8._seen.discard(3 * l + 2)
+            q, g8 = None, None
+        linear(h1, h18, A.w(layer.intermediate.dense.weight), lambda: f8.weight(l, 1, (inner, Hd)), M, inner, Hd,
+               hip.epilogue(g, inner, bias=layer.intermediate.dense.bias, act=hip.ACT_GELU, preact=f, fp8=q))
         s2 = _alloc(rt, M, Hd)
         d2 = drop(p_h)
-        linear(g, A.w(layer.output.dense.weight), M, Hd, inner, hip.epilogue(s2, Hd, bias=layer.output.dense.bias, drop=d2, residual=h1))
+        linear(g, g8, A.w(layer.output.dense.weight), lambda: f8.weight(l, 2, (Hd, inner)), M, Hd, inner,
+               hip.epilogue(s2, Hd, bias=layer.output.dense.bias, drop=d2, residual=h1))
         h2 = _alloc(rt, M, Hd)
         st2 = torch.empty(M, 2, device=rt.device, dtype=torch.float32)
-        hip.layernorm_fwd(dt, s2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, h2, st2, M, Hd)
+        q, h28 = prod(l + 1, 0, Hd) if l + 1 < nl else (None, None)
+        hip.layernorm_fwd(dt, s2, layer.output.LayerNorm.weight, layer.output.LayerNorm.bias, layer.output.LayerNorm.eps, h2, st2, M, Hd, fp8=q)
         ctx["layers"].append((layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2))
-        h = h2
+        h, h8 = h2, h28
+    if f8 is not None and training:          # (an eval forward leaves the delayed-scaling state alone)
+        f8.end_step()
     pooled = _alloc(rt, B, Hd)
     hip.gemm_nt(dt, h, A.w(net.pooler.dense.weight), B, Hd, Hd, hip.epilogue(pooled, Hd, bias=net.pooler.dense.bias, act=hip.ACT_TANH, ws=rt.gemm_ws(B, Hd)), lda=L * Hd)
     ctx["h_last"], ctx["pooled"] = h, pooled

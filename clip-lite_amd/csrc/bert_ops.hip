@@ -24,9 +24,15 @@ DEV void apply_dropout8(const Drop& d, size_t idx, float (&v)[8]) {
 }
 
 // one wave per row; out = dropout((x - mean) * rstd * gamma + beta); stats[row] = (mean, rstd)
-template <typename T, int NCH>      // NCH = 8-element chunks per lane: C <= 64*NCH*8 (2 covers BERT's 768, 4 the 2048-wide heads)
+// Q (bf16, clite_layernorm_fwd_q8): the producer-fused e4m3 quantiser of the fp8 linears that read `out` - the e4m3 copy of the stored value at a
+// delayed scale and the call's max |out| (one integer atomic max per workgroup), as bn_apply's (resnet_ops.hip)
+struct LnQ8 { uint8_t* out; const float* scale; float* amax; };
+template <typename T, int NCH, bool Q = false>      // NCH = 8-element chunks per lane: C <= 64*NCH*8 (2 covers BERT's 768, 4 the 2048-wide heads)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const float* gamma, const float* beta, float eps, T* out,
-                                                            float* stats, int M, int C, Drop drop) {
+                                                            float* stats, int M, int C, Drop drop, LnQ8 q8) {
+  float qmax = 0.f;
+  bool qnan = false;
+  const float qscale = (Q && q8.out) ? q8.scale[0] : 1.f;
   seed_resolve(drop.seed, drop.site);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = C / 8;
@@ -66,9 +72,39 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* x, const fl
         size_t idx = (size_t)row * C + c * 8;
         if (drop.p > 0.f) apply_dropout8(drop, idx, o);
         store8(out + idx, o);
+        if constexpr (Q) {
+          round8_bf16(o);          // quantise / measure the value as stored
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { qmax = fmaxf(qmax, fabsf(o[e])); qnan = qnan || o[e] != o[e]; }
+          if (q8.out) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float p0 = o[2 * e] * qscale, q0 = o[2 * e + 1] * qscale;          // (a NaN passes the clamp untouched: fp8_ops.hip)
+              const float pp = p0 != p0 ? p0 : fminf(fmaxf(p0, -448.f), 448.f), qq = q0 != q0 ? q0 : fminf(fmaxf(q0, -448.f), 448.f);
+              w[e] = cvt2_fp8(pp, qq);
+            }
+            *(u32x2*)(q8.out + idx) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+          }
+        }
       }
     }
     if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  }
+  if constexpr (Q) {
+    if (q8.amax) {
+      __shared__ uint32_t red[4];
+      uint32_t mb = qnan ? 0x7FC00000u : f32_bits(qmax);
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)wave_shfl_xor_i((int)mb, sh); mb = o > mb ? o : mb; }
+      if (lane == 0) red[wave] = mb;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t b = red[0];
+        for (int w = 1; w < 4; ++w) b = red[w] > b ? red[w] : b;
+        atomic_max_u32((uint32_t*)q8.amax + (blockIdx.x % CLITE_FP8_AMAX_REPLICAS) * CLITE_FP8_AMAX_STRIDE, b);
+      }
+    }
   }
 }
 
@@ -620,14 +656,26 @@ extern "C" int clite_layernorm_fwd(int dtype, const void* x, const float* gamma,
   if (C <= 1024) {
     constexpr int NCHV = 2;
     DISPATCH(dtype,
-             hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d),
-             hipLaunchKernelGGL((layernorm_fwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, eps, (float*)out, stats, M, C, d));
+             hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d, LnQ8{}),
+             hipLaunchKernelGGL((layernorm_fwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, eps, (float*)out, stats, M, C, d, LnQ8{}));
   } else {
     constexpr int NCHV = 4;
     DISPATCH(dtype,
-             hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d),
-             hipLaunchKernelGGL((layernorm_fwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, eps, (float*)out, stats, M, C, d));
+             hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, NCHV>), dim3(grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d, LnQ8{}),
+             hipLaunchKernelGGL((layernorm_fwd_kernel<float, NCHV>), dim3(grid), dim3(256), 0, st, (const float*)x, gamma, beta, eps, (float*)out, stats, M, C, d, LnQ8{}));
   }
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_layernorm_fwd_q8(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* out, float* stats,
+                                      int M, int C, float drop_p, uint64_t drop_seed, uint32_t drop_site, uint8_t* fp8_out, const float* fp8_scale,
+                                      float* fp8_amax, void* stream) {
+  if (dtype != CLITE_BF16 || !ln_ok(M, C) || C > 1024 || !x || !out || (fp8_out && !fp8_scale)) return -1;
+  int grid = (M + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  Drop d{drop_p, drop_seed, drop_site};
+  hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, gamma, beta, eps, (bf16*)out, stats, M, C, d,
+                     LnQ8{fp8_out, fp8_scale, fp8_amax});
   return (int)hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 //                        ds_read_b64 (8 fp8 per lane and k-step), epilogue of igemm.h applied to acc * a_scales[1] * b_scales[1].
 #include "igemm_dma.h"
 #include "clite.h"
+#include "wide_api.h"
 
 using namespace clite;
 
@@ -156,7 +157,15 @@ DEV int fp8_frag_off(int x0, int ks, int lane) {
   return r * 64 + ((ks ^ ((r >> 2) & 3)) << 4) + 8 * (lane >> 5);
 }
 
-template <class CFG, int ROWS_A, int ROWS_B, int EPI>
+// The same image read for v_mfma_scale_f32_32x32x64_f8f6f4 (intrin.h): lane (r, h) takes the 16-byte chunks h and 2 + h of row r, one K tile = ONE
+// instruction per 32 x 32 block.
+DEV int fp8_frag_off64(int x0, int half, int lane) {
+  const int r = x0 + (lane & 31);
+  return r * 64 + (((2 * half + (lane >> 5)) ^ ((r >> 2) & 3)) << 4);
+}
+
+// SCALED: the block-scaled instruction at unit scales (twice the matrix rate; default) / the non-scaled 32x32x16 form (-DCLITE_FP8_SCALED=0, A/B)
+template <class CFG, int ROWS_A, int ROWS_B, int EPI, bool SCALED>
 __global__ __launch_bounds__(256) void igemm_fp8_kernel(FKC<ROWS_A> la, FKC<ROWS_B> lb, Epilogue ep, RowMap rm, const float* sa_scales, const float* sb_scales,
                                                         int M, int N, int ktiles) {
   typedef FKC<ROWS_A> LA;
@@ -196,9 +205,9 @@ __global__ __launch_bounds__(256) void igemm_fp8_kernel(FKC<ROWS_A> la, FKC<ROWS
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
-    for (int i = 0; i < RM; ++i) aoff[i][ks] = fp8_frag_off(wm0 + i * 32, ks, lane);
+    for (int i = 0; i < RM; ++i) aoff[i][ks] = SCALED ? fp8_frag_off64(wm0 + i * 32, ks & 1, lane) : fp8_frag_off(wm0 + i * 32, ks, lane);
 #pragma unroll
-    for (int j = 0; j < RN; ++j) boff[j][ks] = fp8_frag_off(wn0 + j * 32, ks, lane);
+    for (int j = 0; j < RN; ++j) boff[j][ks] = SCALED ? fp8_frag_off64(wn0 + j * 32, ks & 1, lane) : fp8_frag_off(wn0 + j * 32, ks, lane);
   }
 #pragma unroll
   for (int pz = 0; pz < NSTAGE - 1; ++pz) {
@@ -214,6 +223,24 @@ __global__ __launch_bounds__(256) void igemm_fp8_kernel(FKC<ROWS_A> la, FKC<ROWS
     barrier_raw();
     const char* abuf = smem + buf * STAGE;
     const char* bbuf = abuf + LA::BYTES;
+    if constexpr (SCALED) {
+      u32x4 alo[RM], ahi[RM], blo[RN], bhi[RN];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) { alo[i] = *(const u32x4*)(abuf + aoff[i][0]); ahi[i] = *(const u32x4*)(abuf + aoff[i][1]); }
+#pragma unroll
+      for (int j = 0; j < RN; ++j) { blo[j] = *(const u32x4*)(bbuf + boff[j][0]); bhi[j] = *(const u32x4*)(bbuf + boff[j][1]); }
+      if (t + NSTAGE - 1 < ktiles) {
+        int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+        la.issue(sa, smem + nb * STAGE, wave);
+        lb.issue(sb, smem + nb * STAGE + LA::BYTES, wave);
+      }
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = mfma32x64_fp8(alo[i], ahi[i], blo[j], bhi[j], acc[i][j]);
+      if (++buf == NSTAGE) buf = 0;
+      continue;
+    }
     uint64_t af0[RM], bf0[RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i) af0[i] = *(const uint64_t*)(abuf + aoff[i][0]);
@@ -240,7 +267,7 @@ __global__ __launch_bounds__(256) void igemm_fp8_kernel(FKC<ROWS_A> la, FKC<ROWS
   }
   barrier_raw();
   if constexpr (EPI == 2) igemm_epilogue_plain<bf16, CFG>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
-  else igemm_epilogue<bf16, CFG, false>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
+  else igemm_epilogue<bf16, CFG, false, true>(acc, ep, rm, smem, M, N, m0, n0, tid, lane, wave, wm0, wn0);
 }
 
 FastDiv fastdiv_make(uint32_t d) {
@@ -276,33 +303,46 @@ ConvGeom geom_fwd(const clite_conv& c) {
 
 typedef TileCfg<128, 128, 64, 64, 64> F128;       // BK = 64 fp8 elements = 64 bytes per row
 typedef TileCfg<256, 64, 64, 64, 64> F256x64;
+typedef TileCfg<256, 128, 64, 128, 64> F256x128;
 
 bool plain(const clite_epilogue& ep) {
-  return !ep.out_f32 && !ep.preact && ep.act == CLITE_ACT_NONE && !ep.dact_aux && ep.drop_p <= 0.f && !ep.residual;
+  return !ep.out_f32 && !ep.preact && ep.act == CLITE_ACT_NONE && !ep.dact_aux && ep.drop_p <= 0.f && !ep.residual && !ep.fp8_out && !ep.fp8_amax;
 }
-int check_ep8(const clite_epilogue* ep, int N) {
-  if (!ep || !ep->out || ep->atomic || ep->bn_y || ep->mask_after_residual || ep->splitk_ws) return -1;
+int check_ep8(const clite_epilogue* ep, int N, bool q8 = false) {
+  if (!ep || !ep->out || ep->atomic || ep->bn_y || ep->mask_after_residual || ep->splitk_ws || ep->residual_subsample > 1) return -1;
   if (N % 8 || ep->ldc % 8) return -1;
+  if ((ep->fp8_out || ep->fp8_amax || ep->fp8_scale) && (!q8 || ep->out_f32 || (ep->fp8_out && !ep->fp8_scale))) return -1;
   return 0;
+}
+
+#ifndef CLITE_FP8_SCALED
+#define CLITE_FP8_SCALED 1
+#endif
+template <class CFG, int RA, int RB>
+void go8(const void* A, uint32_t ab, const ConvGeom& ga, const void* B, uint32_t bb, const ConvGeom& gb, const clite_epilogue& ep, const float* sa,
+         const float* sb, int M, int N, int ktiles, hipStream_t st) {
+  RowMap rm{};
+  const int tiles = ((M + CFG::BM - 1) / CFG::BM) * ((N + CFG::BN - 1) / CFG::BN);
+  FKC<RA> la{A, ab, ga};
+  FKC<RB> lb{B, bb, gb};
+  constexpr bool S = CLITE_FP8_SCALED != 0;
+  if (plain(ep)) hipLaunchKernelGGL((igemm_fp8_kernel<CFG, RA, RB, 2, S>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
+  else hipLaunchKernelGGL((igemm_fp8_kernel<CFG, RA, RB, 0, S>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
 }
 
 int launch8(const void* A, uint32_t ab, const ConvGeom& ga, const void* B, uint32_t bb, const ConvGeom& gb, const clite_epilogue& ep, const float* sa,
             const float* sb, int M, int N, int Ktot, hipStream_t st) {
   const int ktiles = (Ktot + 63) / 64;
-  RowMap rm{};
-  if (N <= 64) {
-    const int tiles = ((M + 255) / 256) * ((N + 63) / 64);
-    FKC<256> la{A, ab, ga};
-    FKC<64> lb{B, bb, gb};
-    if (plain(ep)) hipLaunchKernelGGL((igemm_fp8_kernel<F256x64, 256, 64, 2>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
-    else hipLaunchKernelGGL((igemm_fp8_kernel<F256x64, 256, 64, 0>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
-  } else {
-    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    FKC<128> la{A, ab, ga};
-    FKC<128> lb{B, bb, gb};
-    if (plain(ep)) hipLaunchKernelGGL((igemm_fp8_kernel<F128, 128, 128, 2>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
-    else hipLaunchKernelGGL((igemm_fp8_kernel<F128, 128, 128, 0>), dim3(tiles), dim3(256), 0, st, la, lb, ep, rm, sa, sb, M, N, ktiles);
-  }
+  // tile: 256 x 64 for narrow outputs; otherwise 128 x 128, or 256 x 128 (one instruction of the scaled form does the work of four, so a K tile of
+  // the 128 x 128 tile is 4 instructions per wave between two barriers: the taller tile halves the barriers and the L2 -> LDS bytes per product)
+  // for deep-K launches that still fill the chip with it (tools/probe_fp8.py, batch 256: 3 x 3 256 -> 256 at 14 x 14 48.1 -> 38.9 us, 1 x 1
+  // 1024 -> 256 27.8 -> 25.5; batch 128: 3 x 3 128 -> 128 at 28 x 28 32.1 -> 27.5; launches of < 256 tall tiles lose 15 - 45 %).
+  // clite_set_tile_policy: 1 forces 128 x 128, 2 forces 256 x 128.
+  const int pol = tile_policy_value();
+  const long tiles_tall = (long)((M + 255) / 256) * ((N + 127) / 128);
+  if (N <= 64) go8<F256x64, 256, 64>(A, ab, ga, B, bb, gb, ep, sa, sb, M, N, ktiles, st);
+  else if (pol == 2 || (pol == 0 && CLITE_FP8_SCALED && tiles_tall >= 320 && Ktot >= 1024)) go8<F256x128, 256, 128>(A, ab, ga, B, bb, gb, ep, sa, sb, M, N, ktiles, st);
+  else go8<F128, 128, 128>(A, ab, ga, B, bb, gb, ep, sa, sb, M, N, ktiles, st);
   return (int)hipGetLastError();
 }
 
@@ -343,7 +383,7 @@ extern "C" int clite_fp8_quantize_group(const void* base, const clite_fp8_item* 
 
 extern "C" int clite_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* a_scales, const float* b_scales,
                                  const clite_epilogue* ep, void* stream) {
-  if (!A || !B || !a_scales || !b_scales || M <= 0 || N <= 0 || K <= 0 || K % 16 || lda % 16 || ldb % 16 || lda < K || ldb < K || check_ep8(ep, N)) return -1;
+  if (!A || !B || !a_scales || !b_scales || M <= 0 || N <= 0 || K <= 0 || K % 16 || lda % 16 || ldb % 16 || lda < K || ldb < K || check_ep8(ep, N, true)) return -1;
   if ((size_t)M * lda >= 0xF0000000ull || (size_t)N * ldb >= 0xF0000000ull) return -1;
   const uint32_t ab = (uint32_t)((size_t)(M - 1) * lda + K), bb = (uint32_t)((size_t)(N - 1) * ldb + K);
   return launch8(A, ab, geom_dense(M, K, lda), B, bb, geom_dense(N, K, ldb), *ep, a_scales, b_scales, M, N, K, (hipStream_t)stream);

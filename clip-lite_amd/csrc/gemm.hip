@@ -302,6 +302,7 @@ int check_ep(const clite_epilogue* ep, int N) {
   // packed relu' bits exist in the BatchNorm-backward form only, and exclude the tensor form of the same mask
   if (ep->relu_bits && (!(ep->bn_y || ep->mask_after_residual) || ep->dact_aux)) return -1;
   if (ep->residual_subsample < 0 || ep->residual_subsample > 2) return -1;
+  if (ep->fp8_out || ep->fp8_scale || ep->fp8_amax) return -1;          // clite_gemm_nt_fp8 only
   return 0;
 }
 

@@ -362,7 +362,9 @@ struct TileCfg {
 // HEAVY = the BatchNorm-backward form (clite_epilogue.bn_y / mask_after_residual, operands prefetched two rows at a time). It costs
 // ~45 more registers than the plain form, which would take every kernel from 3 to 2 workgroups per CU, so it is a separate
 // instantiation used only by the launches that ask for it (conv dgrad inside the ResNet backward).
-template <typename T, class CFG, bool HEAVY = false>
+// Q8 (clite_gemm_nt_fp8's instantiation only): clite_epilogue.fp8_out / fp8_scale / fp8_amax - the e4m3 copy of the stored bf16 value at a
+// delayed scale and the call's max |out|, as bn_apply's producer-fused quantiser (resnet_ops.hip).
+template <typename T, class CFG, bool HEAVY = false, bool Q8 = false>
 DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, const RowMap& rm, char* smem, int M, int N, int m0, int n0,
                         int tid, int lane, int wave, int wm0, int wn0) {
   constexpr int BN = CFG::BN;
@@ -394,6 +396,9 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
   float csum[8], csq[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; }
+  float qmax = 0.f;
+  bool qnan = false;
+  const float qscale = (Q8 && ep.fp8_out) ? ep.fp8_scale[0] : 1.f;
 
   // per-column constants of this thread's 8 columns
   const int gcol = n0 + ecol;
@@ -510,6 +515,21 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
       } else {
         store8((bf16*)ep.out + gidx, v);
         round8_bf16(v);   // statistics of what was stored
+        if constexpr (Q8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { qmax = fmaxf(qmax, fabsf(v[e])); qnan = qnan || v[e] != v[e]; }
+          if (ep.fp8_out) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // (a NaN passes the clamp untouched and converts to e4m3's NaN, as in fp8_ops.hip)
+              const float p0 = v[2 * e] * qscale, q0 = v[2 * e + 1] * qscale;
+              const float pp = p0 != p0 ? p0 : fminf(fmaxf(p0, -448.f), 448.f), qq = q0 != q0 ? q0 : fminf(fmaxf(q0, -448.f), 448.f);
+              w[e] = cvt2_fp8(pp, qq);
+            }
+            *(u32x2*)(ep.fp8_out + gidx) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+          }
+        }
       }
       if (HEAVY && ep.bn_y) {
         float yv[8];
@@ -526,6 +546,22 @@ DEV void igemm_epilogue(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& ep, con
     lds_barrier();
   }
 
+  if constexpr (Q8) {
+    if (ep.fp8_amax) {          // one integer atomic max per workgroup on the bit pattern (non-negative floats order like their bits; the quiet-NaN pattern above all)
+      uint32_t mb = qnan ? 0x7FC00000u : f32_bits(qmax);
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)wave_shfl_xor_i((int)mb, sh); mb = o > mb ? o : mb; }
+      uint32_t* red = (uint32_t*)smem;
+      if (lane == 0) red[wave] = mb;
+      lds_barrier();
+      if (tid == 0) {
+        uint32_t b = red[0];
+        for (int w = 1; w < 4; ++w) b = red[w] > b ? red[w] : b;
+        atomic_max_u32((uint32_t*)ep.fp8_amax + (blockIdx.x % CLITE_FP8_AMAX_REPLICAS) * CLITE_FP8_AMAX_STRIDE, b);
+      }
+      lds_barrier();
+    }
+  }
   if (ep.colsum) {
     // threads sharing a column chunk are tid, tid+CPRE, ...: fold them through LDS, one atomic per column. The accumulator
     // is replicated (workgroup b adds into replica b % R) because thousands of tiles adding to the same few addresses

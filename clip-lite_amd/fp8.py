@@ -83,6 +83,74 @@ class Fp8Forward:
             self._seen = set()
 
 
+class Fp8Text:
+    """The fp8 forward of the text encoder (DeviceRuntime.fp8_text, bf16 mode): BERT's QKV projection, FFN1 and FFN2 of every layer on e4m3 operands
+    (clite_gemm_nt_fp8; the 768 x 768 attention output projection stays bf16: its A operand comes out of the attention kernel, and the launch is
+    the smallest of the four). Weights: per-tensor current scaling, all 36 matrices in the two launches of one hip.Fp8WeightGroup per step (q / k / v
+    as ONE tensor: the fused projection has one B scale). Activations: delayed scaling, quantised by their producers - the LayerNorm forward
+    (clite_layernorm_fwd_q8: the layer input for QKV, the attention block's output for FFN1) and FFN1's own epilogue (clite_epilogue.fp8_*: the
+    GELU output for FFN2); slot 3 l + {0, 1, 2} of layer l. A tensor without a scale yet (the first step) is recorded only and its consumer runs
+    in bf16 that once."""
+
+    def __init__(self, rt, net):
+        self.rt = rt
+        A = rt.arena
+        spans = []
+        self.windex = {}
+        for l, layer in enumerate(net.encoder.layer):
+            sa = layer.attention.self
+            qkv = [A.index[p._clite[1]] for p in (sa.query.weight, sa.key.weight, sa.value.weight)]
+            for (o, n), (o2, _) in zip(qkv[:-1], qkv[1:]):
+                assert o + n == o2, "q / k / v weights are not contiguous in the arena"
+            self.windex[(l, 0)] = len(spans)
+            spans.append((qkv[0][0], sum(n for _, n in qkv)))
+            for j, lin in ((1, layer.intermediate.dense), (2, layer.output.dense)):
+                self.windex[(l, j)] = len(spans)
+                spans.append(A.index[lin.weight._clite[1]])
+        self.wgroup = hip.Fp8WeightGroup(A.flat_lp, spans)
+        n = 3 * len(net.encoder.layer)
+        self.amax = torch.zeros(n, hip.FP8_AMAX_WORDS, dtype=torch.float32, device=rt.device)
+        self.scales = torch.ones(n, 2, dtype=torch.float32, device=rt.device)
+        self.ready, self._seen = set(), set()
+
+    def begin_step(self):
+        self.wgroup.quantize()
+
+    def weight(self, l, j, shape):
+        return self.wgroup.view(self.windex[(l, j)], shape)
+
+    def producer(self, l, j, M, Cc, training=True):
+        """((q, scales, amax) for the producer's fp8 arguments, the Fp8View the consumer reads - None: run it in bf16) for activation j of layer l.
+        Eval-mode forwards use the scales read-only, as Fp8Forward.producer."""
+        s = 3 * l + j
+        if not training:
+            if s not in self.ready:
+                return None, None
+            q = torch.empty(M, Cc, dtype=torch.uint8, device=self.rt.device)
+            return (q, self.scales[s], None), hip.Fp8View(q, self.scales[s])
+        self._seen.add(s)
+        if s not in self.ready:
+            return (None, None, self.amax[s]), None
+        q = torch.empty(M, Cc, dtype=torch.uint8, device=self.rt.device)
+        return (q, self.scales[s], self.amax[s]), hip.Fp8View(q, self.scales[s])
+
+    def end_step(self):
+        if self._seen:
+            hip.fp8_scale_update(self.amax, self.scales)
+            self.ready |= self._seen
+            self._seen = set()
+
+
+def text_state(rt, net):
+    """The text encoder's Fp8Text when DeviceRuntime.fp8_text is on (bf16 mode only), else None."""
+    if not (rt.fp8_text and rt.lowp):
+        return None
+    st = rt.fp8_nets.get(id(net))
+    if st is None:
+        st = rt.fp8_nets[id(net)] = Fp8Text(rt, net)
+    return st
+
+
 def forward_state(rt, net):
     """The network's Fp8Forward when the runtime's fp8 forward is on (bf16 mode only), else None."""
     if not (rt.fp8 and rt.lowp):

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -29,6 +29,7 @@ class Epilogue(C.Structure):
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32), ("colsum_rows", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
         ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("relu_bits", C.c_void_p), ("splitk_ws", C.c_void_p), ("residual_subsample", C.c_int32),
+        ("fp8_out", C.c_void_p), ("fp8_scale", C.c_void_p), ("fp8_amax", C.c_void_p),
     ]
 
 
@@ -109,6 +110,7 @@ _SIGNATURES = {
     "clite_image_to_nhwc4": [_I, _V, _V, _I, _I, _I, _I, _I, _I, _V],
     "clite_colsum": [_I, _V, _V, _I, _I, _V],
     "clite_layernorm_fwd": [_I, _V, _V, _V, _F, _V, _V, _I, _I, _F, _U64, _U32, _V],
+    "clite_layernorm_fwd_q8": [_I, _V, _V, _V, _F, _V, _V, _I, _I, _F, _U64, _U32, _V, _V, _V, _V],
     "clite_layernorm_bwd": [_I, _V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _I, _F, _U64, _U32, _F, _U64, _U32, _V],
     "clite_embed_fwd": [_I, _V, _V, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_embed_bwd": [_I, _V, _V, _V, _V, _I, _I, _I, _I, _I, _V],
@@ -236,8 +238,10 @@ class Stats:
 
 def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, preact=None, dact_aux=None, dact=0,
              drop=None, residual=None, colsum=None, out_f32=None, bn=None, mask_after_residual=False, ws=None, relu_bits=None, colsum_rows=0,
-             residual_subsample=0):
-    """bn = (y, stats: Stats, rows): accumulate the BatchNorm-backward reductions (sum v, sum v*(y - mean)) into `colsum`.
+             residual_subsample=0, fp8=None):
+    """fp8 = (q uint8 [M][ldc] | None, scales f32[2] | None, amax slot | None): clite_gemm_nt_fp8 only - the e4m3 copy of `out` for the next fp8
+    GEMM at a delayed scale, and this call's max |out| (clite_epilogue.fp8_*).
+    bn = (y, stats: Stats, rows): accumulate the BatchNorm-backward reductions (sum v, sum v*(y - mean)) into `colsum`.
     relu_bits: the relu' mask of that form as packed bits (uint8 [M][ldc / 8], written by bn_apply) instead of dact_aux."""
     ep = Epilogue()
     ep.out = p(out)
@@ -264,6 +268,8 @@ def epilogue(out, ldc=None, atomic=False, alpha=1.0, bias=None, act=ACT_NONE, pr
     ep.mask_after_residual = int(mask_after_residual)
     ep.relu_bits = p(relu_bits)
     ep.residual_subsample = residual_subsample      # 2: `residual` is the compact [N][H/2][W/2][ldc] gradient of a stride-2 shortcut (clite_epilogue.residual_subsample)
+    if fp8 is not None:
+        ep.fp8_out, ep.fp8_scale, ep.fp8_amax = p(fp8[0]), p(fp8[1]), p(fp8[2])
     ep.splitk_ws = p(ws)        # zeroed f32 [M][N] workspace: allows split-K for GEMMs of few output tiles (clite_epilogue.splitk_ws)
     return ep
 
@@ -648,7 +654,12 @@ def colsum(dt, x, out, M, N):
 NO_DROP = (0.0, 0, 0)
 
 
-def layernorm_fwd(dt, x, gamma, beta, eps, out, stats, M, Cc, drop=NO_DROP):
+def layernorm_fwd(dt, x, gamma, beta, eps, out, stats, M, Cc, drop=NO_DROP, fp8=None):
+    """fp8 = (q | None, scales | None, amax slot | None): also leave the e4m3 copy of `out` / record max |out| (clite_layernorm_fwd_q8, bf16)."""
+    if fp8 is not None:
+        check(lib().clite_layernorm_fwd_q8(dt, p(x), p(gamma), p(beta), eps, p(out), p(stats), M, Cc, drop[0], drop[1], drop[2],
+                                           p(fp8[0]), p(fp8[1]), p(fp8[2]), stream_ptr(x)), "layernorm_fwd_q8")
+        return
     check(lib().clite_layernorm_fwd(dt, p(x), p(gamma), p(beta), eps, p(out), p(stats), M, Cc, drop[0], drop[1], drop[2], stream_ptr(x)),
           "layernorm_fwd")
 

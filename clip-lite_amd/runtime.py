@@ -309,7 +309,7 @@ class DeviceRuntime:
         self.compact_shortcut = True       # stride-2 shortcuts' input gradients kept compact, added by the main branch's BatchNorm-backward dgrad (resnet.py; bf16)
         self.stat_replicas_fixed = False   # True: 8 statistics replicas everywhere (new_stats; tools/ab_runtime.py stat_replicas_fixed=1 for the A/B)
         self.fp8 = False                   # image-encoder forward convs on OCP e4m3 operands, quantised by their producers (BASELINE configs[4]; fp8.py); bf16 mode only
-        self.fp8_text = False              # ... and BERT's forward linears (stand-alone quantiser, current scaling: slower than bf16 — kept for the kernel's tests)
+        self.fp8_text = False              # ... and BERT's QKV / FFN1 / FFN2 forward linears, quantised by the LayerNorm forward and FFN1's epilogue (fp8.Fp8Text)
         self.fp8_nets = {}                 # id(ResNet) -> fp8.Fp8Forward
         self.group_wgrad = bool(lowp)      # weight gradients of a backward pass as grouped launches (hip.WgradGroup / clite_wgrad_group)
         if lowp and self.device.type == "cuda":

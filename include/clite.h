@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 10
+#define CLITE_ABI_VERSION 11
 int clite_abi_version(void);
 
 /* Deterministic-reduction mode (process-wide, default off; the counterpart of torch.use_deterministic_algorithms for this library).
@@ -110,6 +110,14 @@ typedef struct clite_epilogue {
                              * [N][H/2][W/2][ldc] whose pixel (n, h/2, w/2) is added to output pixel (n, h, w) for even h, w and nothing elsewhere —
                              * the input gradient of the block's stride-2 1 x 1 shortcut, kept compact instead of scatter-added into the full-size
                              * gradient (which cost a read-modify-write pass and, before it, a separate BatchNorm-backward reduction pass). */
+  /* ABI v11, clite_gemm_nt_fp8 only (every other entry point returns -1 when one of them is set): the producer-fused e4m3 quantiser of the NEXT
+   * GEMM's A operand, as clite_bn.fp8_* for clite_bn_apply — BERT's FFN1 launch leaves the e4m3 copy of its GELU output for FFN2.
+   *   fp8_out   [M][ldc] bytes: e4m3(clamp(out * fp8_scale[0], +-448)) of the bf16 value as stored (bf16 out only);
+   *   fp8_scale device f32[2] = {scale, 1 / scale}, delayed scaling (clite_fp8_scale_update); required with fp8_out;
+   *   fp8_amax  one amax slot (CLITE_FP8_AMAX_REPLICAS x CLITE_FP8_AMAX_STRIDE words): max |out| of this call. Any of the three may be NULL. */
+  uint8_t* fp8_out;
+  const float* fp8_scale;
+  float* fp8_amax;
 } clite_epilogue;
 
 /* NHWC convolution problem. x: [N][H][W][C], w: [K][R][S][C], y: [N][Ho][Wo][K], all of `dtype`. */
@@ -309,6 +317,11 @@ int clite_colsum(int dtype, const void* x, float* out, int M, int N, void* strea
 /* out = dropout(LayerNorm(x)); stats[row] = (mean, rstd) f32. C % 8 == 0, C <= 2048. Also nn.LayerNorm at loss.py:23. */
 int clite_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* out, float* stats,
                         int M, int C, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* stream);
+/* ABI v11. The same pass (bf16 only) that also leaves the e4m3 copy of `out` for the fp8 linears that read it (BERT's QKV projection and FFN1)
+ * and / or records max |out|: fp8_out / fp8_scale / fp8_amax as in clite_epilogue (delayed scaling; any may be NULL, fp8_out needs fp8_scale). */
+int clite_layernorm_fwd_q8(int dtype, const void* x, const float* gamma, const float* beta, float eps, void* out, float* stats,
+                           int M, int C, float drop_p, uint64_t drop_seed, uint32_t drop_site, uint8_t* fp8_out, const float* fp8_scale, float* fp8_amax,
+                           void* stream);
 /* dx = LayerNorm backward of dropout_in(dy); dx_masked (optional) = dropout_out(dx); dgamma/dbeta (optional) += .
  * dcolsum (optional, f32 [C]) += column sums of dx_masked (of dx when there is no masked output) as stored: the bias gradient of the
  * nn.Linear whose output this LayerNorm normalised (BertSelfOutput.dense / BertOutput.dense; the token-type row of BertEmbeddings). */

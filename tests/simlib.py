@@ -23,7 +23,7 @@ class Epilogue(C.Structure):
         ("colsum_replicas", C.c_int32), ("colsum_stride", C.c_int32), ("colsum_rows", C.c_int32),
         ("bn_y", C.c_void_p), ("bn_stats", C.c_void_p), ("bn_replicas", C.c_int32), ("bn_rstride", C.c_int32),
         ("bn_inv_count", C.c_float), ("mask_after_residual", C.c_int32), ("relu_bits", C.c_void_p), ("splitk_ws", C.c_void_p),
-        ("residual_subsample", C.c_int32),
+        ("residual_subsample", C.c_int32), ("fp8_out", C.c_void_p), ("fp8_scale", C.c_void_p), ("fp8_amax", C.c_void_p),
     ]
 
 
@@ -67,12 +67,14 @@ def ptr(a):
 
 
 def make_ep(out, ldc, out_f32=False, atomic=False, alpha=1.0, bias=None, act=0, preact=None, dact_aux=None,
-            dact=0, drop_p=0.0, drop_seed=0, drop_site=0, residual=None, colsum=None, relu_bits=None):
+            dact=0, drop_p=0.0, drop_seed=0, drop_site=0, residual=None, colsum=None, relu_bits=None, fp8=None):
     ep = Epilogue()
     ep.out = ptr(out); ep.ldc = ldc; ep.out_f32 = int(out_f32); ep.atomic = int(atomic); ep.alpha = alpha
     ep.bias = ptr(bias); ep.act = act; ep.preact = ptr(preact); ep.dact_aux = ptr(dact_aux); ep.dact = dact
     ep.drop_p = drop_p; ep.drop_seed = drop_seed; ep.drop_site = drop_site
     ep.residual = ptr(residual); ep.colsum = ptr(colsum); ep.relu_bits = ptr(relu_bits)
+    if fp8 is not None:
+        ep.fp8_out, ep.fp8_scale, ep.fp8_amax = ptr(fp8[0]), ptr(fp8[1]), ptr(fp8[2])
     return ep
 
 

@@ -157,8 +157,8 @@ def test_resnet101_with_fp8_forward_tracks_its_bf16_step():
             # bn_apply writes the e4m3 copies itself at the scale made from the previous forward's amax (delayed scaling, fp8.py). Same weights,
             # same batch: the delayed scale IS the current one, so the fused step repeats the first up to what two runs of this 101-layer problem differ by
             # anyway (float-atomic order through 101 ReLU layers: loss +- 5e-3, gradient cosine ~0.88, measured; bars at 2e-2 and 0.80)
-            (st,) = M.runtime.fp8_nets.values()
-            assert st.ready and not st._seen
+            for st in M.runtime.fp8_nets.values():          # the image encoder's state and the text encoder's
+                assert st.ready and not st._seen
             M.runtime.arena.flat_g.zero_()
             out2 = M(batch)
             out2["loss"].backward()
@@ -216,6 +216,57 @@ def test_bn_apply_fused_e4m3_copy_matches_torch_cast(M, Cc, res):
     assert not amax.any() and abs(scales[0].item() * amax_true.item() / 448.0 - 1) < 1e-6
 
 
+def test_bert_producers_leave_the_e4m3_copies_at_full_size():
+    """The text encoder's fused quantisers at the benchmark's size (M = 3840 tokens; ABI v11): clite_layernorm_fwd_q8 and the fp8 FFN1 launch
+    (bias + pre-activation store + GELU) leave torch's float8_e4m3fn cast of their STORED bf16 outputs at the given scale, record max |out|, and
+    change nothing else (outputs bit-identical to the plain calls)."""
+    hip = _hip()
+    M, Hd, inner = 3840, 768, 3072
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(M, Hd, device="cuda", generator=g) * 2 + 0.3).bfloat16()
+    gamma, beta = 1 + 0.1 * torch.randn(Hd, device="cuda", generator=g), 0.1 * torch.randn(Hd, device="cuda", generator=g)
+
+    def check(q, out, scales, amax):
+        ref = (out.float() * scales[0]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        same = (q == ref) | ((q & 0x7f == 0) & (ref & 0x7f == 0))
+        assert same.all(), (~same).sum().item()
+        assert amax.max().item() == out.float().abs().max().item()
+
+    def ln(fp8):
+        out, st = torch.empty(M, Hd, device="cuda", dtype=torch.bfloat16), torch.empty(M, 2, device="cuda")
+        hip.layernorm_fwd(BF16, x, gamma, beta, 1e-12, out, st, M, Hd, (0.1, 77, 3), fp8=fp8)
+        torch.cuda.synchronize()
+        return out, st
+
+    out0, st0 = ln(None)
+    a = out0.float().abs().max().item()
+    scales = torch.tensor([448.0 / (0.8 * a), 0.8 * a / 448.0], device="cuda")
+    q, amax = torch.full((M, Hd), 0x55, device="cuda", dtype=torch.uint8), torch.zeros(hip.FP8_AMAX_WORDS, device="cuda")
+    out1, st1 = ln((q, scales, amax))
+    assert torch.equal(out0, out1) and torch.equal(st0, st1)
+    check(q, out0, scales, amax)
+
+    w = (torch.randn(inner, Hd, device="cuda", generator=g) * 0.05).bfloat16()
+    bias = torch.randn(inner, device="cuda", generator=g)
+    a8, w8 = hip.Fp8Tensor(out0, BF16), hip.Fp8Tensor(w, BF16)
+
+    def ffn1(fp8):
+        out, pre = torch.empty(M, inner, device="cuda", dtype=torch.bfloat16), torch.empty(M, inner, device="cuda", dtype=torch.bfloat16)
+        hip.gemm_nt_fp8(a8, w8, M, inner, Hd, hip.epilogue(out, inner, bias=bias, act=hip.ACT_GELU, preact=pre, fp8=fp8))
+        torch.cuda.synchronize()
+        return out, pre
+
+    g0, f0 = ffn1(None)
+    a = g0.float().abs().max().item()
+    scales = torch.tensor([448.0 / (0.8 * a), 0.8 * a / 448.0], device="cuda")
+    q, amax = torch.full((M, inner), 0x55, device="cuda", dtype=torch.uint8), torch.zeros(hip.FP8_AMAX_WORDS, device="cuda")
+    g1, f1 = ffn1((q, scales, amax))
+    assert torch.equal(g0, g1) and torch.equal(f0, f1)
+    check(q, g0, scales, amax)
+    with pytest.raises(RuntimeError):          # the bf16 entry point refuses the fields
+        hip.gemm_nt(BF16, out0, w, M, inner, Hd, hip.epilogue(g1, inner, fp8=(None, None, amax)))
+
+
 def test_fp8_forward_through_captured_graphs_tracks_eager_steps():
     """The producer-fused fp8 forward inside the captured per-phase graphs (fp8.py: grouped weight quantiser, bn_apply's e4m3 copies at the
     delayed scale, the per-step scale update — all graph nodes, replayed): six steps of ResNet-18 + 2-layer BERT + heads with fp8 on, eager
@@ -243,7 +294,7 @@ def test_fp8_forward_through_captured_graphs_tracks_eager_steps():
         te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
         te.strans.hidden_dropout_prob = te.strans.attention_probs_dropout_prob = 0.0
         M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=True)).to("cuda").train()
-        M.runtime.fp8 = True
+        M.runtime.fp8 = M.runtime.fp8_text = True
         groups = [{"params": [p], "lr": 1e-3 if "image_encoder" in n else 1e-4, "weight_decay": 1e-4} for n, p in M.named_parameters()]
         opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
         sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
@@ -251,9 +302,13 @@ def test_fp8_forward_through_captured_graphs_tracks_eager_steps():
         losses = [step(batches[s % 3])["loss"].item() for s in range(6)]
         torch.cuda.synchronize()
         assert step.graph == graph
-        (st,) = M.runtime.fp8_nets.values()
-        assert st.ready and not st.amax.any() and torch.isfinite(st.scales).all() and torch.isfinite(st.wgroup.scales).all()
-        assert (st.scales[sorted(st.ready), 0] != 1.0).all()          # every fused tensor got a real scale
+        states = list(M.runtime.fp8_nets.values())
+        assert len(states) == 2          # the image encoder's Fp8Forward and the text encoder's Fp8Text
+        for st in states:
+            assert st.ready and not st.amax.any() and torch.isfinite(st.scales).all() and torch.isfinite(st.wgroup.scales).all()
+            assert (st.scales[sorted(st.ready), 0] != 1.0).all()          # every fused tensor got a real scale
+        text = [st for st in states if hasattr(st, "windex") and (0, 0) in st.windex][0]
+        assert text.ready == set(range(6))          # both layers' three activations (layer input, attention-block output, GELU output)
         runs.append(losses)
     print("fp8 eager", [round(x, 4) for x in runs[0]], "graph", [round(x, 4) for x in runs[1]])
     assert all(np.isfinite(x) for r in runs for x in r)

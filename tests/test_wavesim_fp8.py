@@ -88,9 +88,15 @@ def test_quantizer_keeps_non_finite_inputs_visible(dtype, bad):
     assert L.clite_fp8_quantize(F32, ptr(buf), 12, ptr(np.zeros(1, np.float32)), ptr(np.zeros(2, np.float32)), ptr(np.zeros(12, np.uint8)), None) == -1
 
 
+@pytest.mark.parametrize("pol", [0, 2])          # 2: the 256 x 128 tile, which the shape rule takes only for launches of >= 448 such tiles
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 208), (300, 64, 96), (70, 1000, 64)])
-def test_gemm_nt_fp8(M, N, K):
+def test_gemm_nt_fp8(M, N, K, pol):
+    """clite_gemm_nt_fp8 on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; the simulator executes the operand map
+    tools/micro/mfma_scale_probe.hip measured on the hardware) against the f64 product of the dequantised operands."""
+    if pol and (N <= 64 or M * N > 70000):
+        pytest.skip("narrow outputs have one tile; the wide case repeats the 200 x 136 one")
     L = lib()
+    assert L.clite_set_tile_policy(pol) == 0
     L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.clite_gemm_nt_fp8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(M + N + K)
@@ -114,12 +120,17 @@ def test_gemm_nt_fp8(M, N, K):
     got = from_bf16(o16)
     assert np.abs(got - ref2).max() <= 6e-3 * np.abs(ref2).max()
     assert np.abs(cs[0] - got.sum(0)).max() <= 1e-4 * max(np.abs(got.sum(0)).max(), 1e-6)
+    assert L.clite_set_tile_policy(0) == 0
 
 
 @pytest.mark.parametrize("N,H,W,Cc,K,R,st,pad", [(2, 8, 8, 64, 64, 3, 1, 1), (3, 6, 6, 48, 136, 1, 1, 0), (2, 9, 7, 128, 32, 3, 2, 1)])
-def test_conv_fwd_fp8(N, H, W, Cc, K, R, st, pad):
+@pytest.mark.parametrize("pol", [0, 2])
+def test_conv_fwd_fp8(N, H, W, Cc, K, R, st, pad, pol):
     from test_wavesim_igemm import conv_ref
+    if pol and K <= 64:
+        pytest.skip("narrow outputs have one tile")
     L = lib()
+    assert L.clite_set_tile_policy(pol) == 0
     L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.clite_conv_fwd_fp8.argtypes = [C.c_void_p] * 7
     rng = np.random.default_rng(H * W + K)
@@ -133,6 +144,7 @@ def test_conv_fwd_fp8(N, H, W, Cc, K, R, st, pad):
     assert L.clite_conv_fwd_fp8(ptr(qx), ptr(qw), C.byref(cv), ptr(sx), ptr(sw), C.byref(make_ep(y, K, out_f32=True)), None) == 0
     ref = conv_ref(E4M3[qx], E4M3[qw], st, pad) * (sx[1] * sw[1])
     assert np.abs(y - ref).max() <= 2e-5 * np.abs(ref).max()
+    assert L.clite_set_tile_policy(0) == 0
 
 
 SLOT = 16 * 32          # one amax slot: CLITE_FP8_AMAX_REPLICAS x CLITE_FP8_AMAX_STRIDE words (include/clite.h)
@@ -203,6 +215,83 @@ def test_bn_apply_writes_the_e4m3_copy_and_the_amax(M, Cc, res):
     p = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(np.zeros(Cc, np.float32)), ptr(np.ones(Cc, np.float32)), 1, 0, 0.1, 1e-5, 1, 1, 3 * Cc, 0)
     p.fp8_amax = ptr(amax3)
     assert L.clite_bn_apply(C.byref(p), F32, ptr(y), None, ptr(np.zeros((M, Cc), np.float32)), None) != 0
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 136, 128), (70, 264, 64)])
+def test_gemm_nt_fp8_epilogue_leaves_the_e4m3_copy_and_the_amax(M, N, K):
+    """clite_epilogue.fp8_out / fp8_scale / fp8_amax (ABI v11, clite_gemm_nt_fp8 only): BERT's FFN1 launch - bias, pre-activation store, GELU, bf16
+    store - also leaves the e4m3 codes of the STORED bf16 output at a delayed scale (values beyond its range saturate) and max |out| of the call in
+    the amax slot; the bf16 output and the pre-activation are those of the call without the three fields, bit for bit. Every other GEMM entry
+    point refuses the fields."""
+    L = lib()
+    L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.clite_gemm_nt_fp8.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(M + N)
+    A, B = rng.standard_normal((M, K)).astype(np.float32), (rng.standard_normal((N, K)) * 0.2).astype(np.float32)
+    qa, sa, _ = _quant(L, A, F32)
+    qb, sb, _ = _quant(L, B, F32)
+    bias = rng.standard_normal(N).astype(np.float32)
+
+    def run(fp8):
+        out, pre = np.zeros((M, N), np.uint16), np.zeros((M, N), np.uint16)
+        assert L.clite_gemm_nt_fp8(ptr(qa), K, ptr(qb), K, M, N, K, ptr(sa), ptr(sb), C.byref(make_ep(out, N, bias=bias, act=2, preact=pre, fp8=fp8)), None) == 0
+        return out, pre
+
+    out0, pre0 = run(None)
+    a = from_bf16(out0)
+    scale = np.float32(448.0 / (0.6 * np.abs(a).max()))          # a stale scale: the top of the range saturates
+    q = np.full((M, N), 0x55, np.uint8)
+    scales = np.array([scale, 1 / scale], np.float32)
+    amax = np.zeros(SLOT, np.float32)
+    amax[64] = 0.0625
+    out1, pre1 = run((q, scales, amax))
+    assert np.array_equal(out0, out1) and np.array_equal(pre0, pre1)
+    assert amax.max() == np.abs(a).max() and not amax.reshape(16, 32)[:, 1:].any()
+    ref = quantize_at(a, scale)
+    assert np.array_equal(q & 0x7f, ref & 0x7f) and np.array_equal((q >> 7)[a != 0], (ref >> 7)[a != 0])
+    assert (np.abs(E4M3[q]) == 448.0).any()
+    amax2 = np.zeros(SLOT, np.float32)          # amax only (the first step: no scale yet)
+    run((None, None, amax2))
+    assert amax2.max() == np.abs(a).max()
+    # refusals: an e4m3 copy without a scale; an f32 output; the bf16 entry point
+    o = np.zeros((M, N), np.uint16)
+    assert L.clite_gemm_nt_fp8(ptr(qa), K, ptr(qb), K, M, N, K, ptr(sa), ptr(sb), C.byref(make_ep(o, N, fp8=(q, None, None))), None) == -1
+    o32 = np.zeros((M, N), np.float32)
+    assert L.clite_gemm_nt_fp8(ptr(qa), K, ptr(qb), K, M, N, K, ptr(sa), ptr(sb), C.byref(make_ep(o32, N, out_f32=True, fp8=(None, None, amax2))), None) == -1
+    L.clite_gemm_nt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    Ab, Bb = to_bf16(A), to_bf16(B)
+    assert L.clite_gemm_nt(ptr(Ab), K, ptr(Bb), K, M, N, K, BF16, C.byref(make_ep(o, N, fp8=(None, None, amax2))), None) == -1
+
+
+@pytest.mark.parametrize("M,Cc,p", [(37, 768, 0.0), (9, 264, 0.1)])
+def test_layernorm_forward_leaves_the_e4m3_copy_and_the_amax(M, Cc, p):
+    """clite_layernorm_fwd_q8 (ABI v11): the LayerNorm forward's bf16 output and statistics are clite_layernorm_fwd's bit for bit (with and without
+    the output dropout); the e4m3 codes are those of the stored output at the given scale; the slot receives max |out|."""
+    L = lib()
+    L.clite_layernorm_fwd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.clite_layernorm_fwd_q8.argtypes = L.clite_layernorm_fwd.argtypes[:-1] + [C.c_void_p] * 4
+    rng = np.random.default_rng(Cc)
+    x = to_bf16(rng.standard_normal((M, Cc)).astype(np.float32) * 3 + 1)
+    gamma = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    out0, st0 = np.zeros((M, Cc), np.uint16), np.zeros((M, 2), np.float32)
+    assert L.clite_layernorm_fwd(BF16, ptr(x), ptr(gamma), ptr(beta), 1e-12, ptr(out0), ptr(st0), M, Cc, p, 1234, 5, None) == 0
+    a = from_bf16(out0)
+    scale = np.float32(448.0 / (0.7 * np.abs(a).max()))
+    q = np.full((M, Cc), 0x55, np.uint8)
+    scales = np.array([scale, 1 / scale], np.float32)
+    amax = np.zeros(SLOT, np.float32)
+    out1, st1 = np.zeros((M, Cc), np.uint16), np.zeros((M, 2), np.float32)
+    assert L.clite_layernorm_fwd_q8(BF16, ptr(x), ptr(gamma), ptr(beta), 1e-12, ptr(out1), ptr(st1), M, Cc, p, 1234, 5, ptr(q), ptr(scales), ptr(amax), None) == 0
+    assert np.array_equal(out0, out1) and np.array_equal(st0, st1)
+    assert amax.max() == np.abs(a).max() and not amax.reshape(16, 32)[:, 1:].any()
+    ref = quantize_at(a, scale)
+    assert np.array_equal(q & 0x7f, ref & 0x7f) and np.array_equal((q >> 7)[a != 0], (ref >> 7)[a != 0])
+    amax2 = np.zeros(SLOT, np.float32)
+    assert L.clite_layernorm_fwd_q8(BF16, ptr(x), ptr(gamma), ptr(beta), 1e-12, ptr(out1), ptr(st1), M, Cc, p, 1234, 5, None, None, ptr(amax2), None) == 0
+    assert amax2.max() == np.abs(a).max()
+    assert L.clite_layernorm_fwd_q8(BF16, ptr(x), ptr(gamma), ptr(beta), 1e-12, ptr(out1), ptr(st1), M, Cc, p, 1234, 5, ptr(q), None, None, None) == -1
+    assert L.clite_layernorm_fwd_q8(F32, ptr(x), ptr(gamma), ptr(beta), 1e-12, ptr(out1), ptr(st1), M, Cc, p, 1234, 5, None, None, ptr(amax2), None) == -1
 
 
 def test_grouped_weight_quantiser_and_scale_update():

@@ -298,6 +298,31 @@ inline f32x16 mfma32_fp8(uint64_t a, uint64_t b, f32x16 c) {
   wave_barrier_();
   return c;
 }
+// v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3, unit scales): lane (r, h) holds k = 16 h + j (bytes 0..15) and k = 32 + 16 h + j - 16 (bytes 16..31)
+// - the map tools/micro/mfma_scale_probe.hip measured on the hardware
+inline f32x16 mfma32x64_fp8(u32x4 a_lo, u32x4 a_hi, u32x4 b_lo, u32x4 b_hi, f32x16 c) {
+  auto& w = wavesim::g_block->waves[wavesim::g_wave];
+  int l = wavesim::g_lane;
+  memcpy(&w.slot[l][0], &a_lo, 16);
+  memcpy(&w.slot[l][2], &a_hi, 16);
+  memcpy(&w.slot[l][4], &b_lo, 16);
+  memcpy(&w.slot[l][6], &b_hi, 16);
+  wave_barrier_();
+  int col = l & 31;
+  for (int i = 0; i < 16; ++i) {
+    int row = (i & 3) + 8 * (i >> 2) + 4 * (l >> 5);
+    float acc = c[i];
+    for (int k = 0; k < 64; ++k) {
+      const int h = (k >> 4) & 1, j = (k & 15) + 16 * (k >> 5);
+      const uint8_t av = ((const uint8_t*)&w.slot[row + 32 * h][0])[j];
+      const uint8_t bv = ((const uint8_t*)&w.slot[col + 32 * h][4])[j];
+      acc = fmaf(fp8_e4m3_to_f32(av), fp8_e4m3_to_f32(bv), acc);
+    }
+    c[i] = acc;
+  }
+  wave_barrier_();
+  return c;
+}
 // v_mfma_f32_32x32x2_f32
 inline f32x16 mfma32_f32(float a, float b, f32x16 c) {
   auto& w = wavesim::g_block->waves[wavesim::g_wave];

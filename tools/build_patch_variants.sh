@@ -18,3 +18,7 @@ for v in ${PATCH_VARIANTS:-1 2 4 3}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_PATCH_ABLATE=$v -c clip-lite_amd/csrc/conv_patch.hip -o build/var$v/conv_patch.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/var$v/libclite_hip_var.so build/var$v/conv_patch.o $(ls build/hip/*.o | grep -v conv_patch.o)
 done
+# the fp8 forward on the non-scaled v_mfma_f32_32x32x16_fp8_fp8 (round 3's form): same-box A/B of the block-scaled instruction
+mkdir -p build/varf8
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_FP8_SCALED=0 -c clip-lite_amd/csrc/fp8_ops.hip -o build/varf8/fp8_ops.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/varf8/libclite_hip_var.so build/varf8/fp8_ops.o $(ls build/hip/*.o | grep -v fp8_ops.o)
