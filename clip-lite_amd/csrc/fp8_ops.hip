@@ -157,13 +157,7 @@ DEV int fp8_frag_off(int x0, int ks, int lane) {
   return r * 64 + ((ks ^ ((r >> 2) & 3)) << 4) + 8 * (lane >> 5);
 }
 
-// The same image read for v_mfma_scale_f32_32x32x64_f8f6f4 (intrin.h): lane (r, h) takes the 16-byte chunks h and 2 + h of row r, one K tile = ONE
-// instruction per 32 x 32 block.
-DEV int fp8_frag_off64(int x0, int half, int lane) {
-  const int r = x0 + (lane & 31);
-  return r * 64 + (((2 * half + (lane >> 5)) ^ ((r >> 2) & 3)) << 4);
-}
-
+// (fp8_frag_off64, the image read of the block-scaled instruction: igemm_dma.h)
 // SCALED: the block-scaled instruction at unit scales (twice the matrix rate; default) / the non-scaled 32x32x16 form (-DCLITE_FP8_SCALED=0, A/B)
 template <class CFG, int ROWS_A, int ROWS_B, int EPI, bool SCALED>
 __global__ __launch_bounds__(256) void igemm_fp8_kernel(FKC<ROWS_A> la, FKC<ROWS_B> lb, Epilogue ep, RowMap rm, const float* sa_scales, const float* sb_scales,
@@ -387,6 +381,44 @@ extern "C" int clite_gemm_nt_fp8(const void* A, int lda, const void* B, int ldb,
   if ((size_t)M * lda >= 0xF0000000ull || (size_t)N * ldb >= 0xF0000000ull) return -1;
   const uint32_t ab = (uint32_t)((size_t)(M - 1) * lda + K), bb = (uint32_t)((size_t)(N - 1) * ldb + K);
   return launch8(A, ab, geom_dense(M, K, lda), B, bb, geom_dense(N, K, ldb), *ep, a_scales, b_scales, M, N, K, (hipStream_t)stream);
+}
+
+// Input gradient of a stride-1 convolution on fp8 operands, in the BatchNorm-backward form of the ResNet backward (igemm_dma_bn_kernel's FORM 1: packed
+// relu' bits, the BatchNorm input, bf16 output, both reductions): A = dy in e5m2 gathered with the transposed-conv geometry, B = the transposed weights
+// [C][R][S][K] in e4m3. One 128 x 128 tile per workgroup.
+ConvGeom geom_dgrad8(const clite_conv& c) {
+  ConvGeom g;
+  g.H = c.Ho; g.W = c.Wo; g.C = c.K;
+  g.sN = c.Ho * c.Wo * c.K; g.sH = c.Wo * c.K; g.sW = c.K;
+  g.RH = c.H; g.RW = c.W; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
+  g.rows = c.N * c.H * c.W;
+  g.div_hw = fastdiv_make(c.H * c.W);
+  g.div_w = fastdiv_make(c.W);
+  return g;
+}
+
+extern "C" int clite_conv_dgrad_fp8(const void* dy8, const void* wt8, const clite_conv* cv, const float* dy_scales, const float* w_scales,
+                                    const clite_epilogue* ep, void* stream) {
+  if (!dy8 || !wt8 || !cv || !dy_scales || !w_scales || !ep || !ep->out) return -1;
+  const clite_conv& c = *cv;
+  if (c.stride != 1 || c.K % 64 || c.C % 8 || ep->ldc % 8) return -1;            // a 64-element K slab stays inside one (r, s)
+  if (c.Ho != (c.H + 2 * c.pad - c.R) + 1 || c.Wo != (c.W + 2 * c.pad - c.S) + 1) return -1;
+  // exactly the epilogue the bf16 backward issues for a unit inside a block: out = relu'(bits) * acc, (sum v, sum v (bn_y - mean)) into colsum
+  if (!ep->relu_bits || !ep->bn_y || !ep->bn_stats || !ep->colsum || ep->dact_aux || ep->out_f32 || ep->alpha != 1.f || ep->residual || ep->mask_after_residual ||
+      ep->atomic || ep->bias || ep->act || ep->preact || ep->drop_p > 0.f || ep->splitk_ws || ep->residual_subsample > 1 || ep->fp8_out || ep->fp8_amax || ep->fp8_scale)
+    return -1;
+  if ((size_t)c.N * c.Ho * c.Wo * c.K >= 0xF0000000ull || (size_t)c.N * c.H * c.W * c.C * 2 >= 0xF0000000ull) return -1;
+  const int M = c.N * c.H * c.W, Ktot = c.R * c.S * c.K, ktiles = Ktot / 64;
+  const uint32_t yb = (uint32_t)((size_t)c.N * c.Ho * c.Wo * c.K), wb = (uint32_t)((size_t)c.C * Ktot);
+  typedef DmaKC<fp8, 128, 64, true> LA;
+  typedef DmaKC<fp8, 128, 64, false> LB;
+  LA la{dy8, yb, geom_dgrad8(c)};
+  LB lb{wt8, wb, geom_dense(c.C, Ktot, Ktot)};
+  RowMap rm{};
+  const int tiles = ((M + 127) / 128) * ((c.C + 127) / 128);
+  hipLaunchKernelGGL((igemm_dma_bn_kernel<bf16, F128, LA, LB, 1, false, true>), dim3(tiles), dim3(256), 0, (hipStream_t)stream, la, lb, *ep, rm, M, c.C, ktiles, 128,
+                     dy_scales, w_scales);
+  return (int)hipGetLastError();
 }
 
 extern "C" int clite_conv_fwd_fp8(const void* x8, const void* w8, const clite_conv* cv, const float* x_scales, const float* w_scales,

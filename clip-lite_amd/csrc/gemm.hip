@@ -221,20 +221,20 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
         }
         const dim3 g(slices * tiles_n);
         if constexpr (sizeof(T) == 2 && kc_b) {
-          if (form == 1) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 1>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
-          else if (form == 2) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 2>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
-          else if (form == 3) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 3>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
-          else hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+          if (form == 1) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 1>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
+          else if (form == 2) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 2>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
+          else if (form == 3) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 3>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
+          else hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
         } else {
           bool done = false;
           if constexpr (sizeof(T) == 4) {
             if (f32_split()) {
-              hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0, true>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+              hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0, true>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
               done = true;
             }
           }
           if (!done)
-            hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg);
+            hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
         }
         return (int)hipGetLastError();
       } else {

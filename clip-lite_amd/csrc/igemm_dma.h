@@ -494,8 +494,19 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(LA la, LB lb, Epilogue e
 // range read as zero / are not stored), which costs a short main loop and an epilogue proportional to its rows. With rows_per_wg =
 // ceil(M / (512 / column tiles)) all workgroups are resident at once and finish together. rows_per_wg = BM is the plain one-tile form
 // (windowed convs, whose main loop is long: a partial tile would cost a whole one).
-template <typename T, class CFG, class LA, class LB, int FORM = 0, bool SPLIT = false>
-__global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dma_bn_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int rows_per_wg) {
+// fp8 operand images (fp8_ops.hip): [rows][64 B] with 16-byte chunk c of row r in slot c ^ ((r>>2)&3) - DmaKC's image at one byte per element. For
+// v_mfma_scale_f32_32x32x64_f8f6f4 lane (r, h) takes the chunks h and 2 + h of row r (intrin.h): one K tile = ONE instruction per 32 x 32 block.
+DEV int fp8_frag_off64(int x0, int half, int lane) {
+  const int r = x0 + (lane & 31);
+  return r * 64 + (((2 * half + (lane >> 5)) ^ ((r >> 2) & 3)) << 4);
+}
+
+// F8 (clite_conv_dgrad_fp8): T stays bf16 (the epilogue's tensors), the operands are one-byte images - A = the gradient in e5m2, B = the transposed
+// weights in e4m3 - multiplied by the block-scaled instruction at unit scales; the accumulators are de-quantised (f8_a[1] * f8_b[1], the inverse
+// per-tensor scales) before the epilogue, which is the bf16 kernel's.
+template <typename T, class CFG, class LA, class LB, int FORM = 0, bool SPLIT = false, bool F8 = false>
+__global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dma_bn_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int rows_per_wg,
+                                                                                            const float* f8_a, const float* f8_b) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
   constexpr int RM = CFG::RM, RN = CFG::RN;
 #ifndef CLITE_BN_STAGES
@@ -531,7 +542,16 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
   la.g.rows = row_end;                      // rows past this workgroup's range gather as out of range (zeros)
 
   int aoff[RM][BK / 16 > 0 ? BK / 16 : 1], boff[RN][BK / 16 > 0 ? BK / 16 : 1];
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (F8) {
+    static_assert(BK == 64 && sizeof(T) == 2, "fp8 operands: 64-byte K rows, bf16 epilogue");
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i) aoff[i][q] = fp8_frag_off64(wm0 + i * 32, q, lane);
+#pragma unroll
+      for (int j = 0; j < RN; ++j) boff[j][q] = fp8_frag_off64(wn0 + j * 32, q, lane);
+    }
+  } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
@@ -585,7 +605,22 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
       if (t == 0) PHASE(2);      // wait for the first operand tile
       const char* abuf = smem + buf * STAGE;
       const char* bbuf = abuf + LA::BYTES;
-      if constexpr (sizeof(T) == 2) {
+      if constexpr (F8) {
+        u32x4 alo[RM], ahi[RM], blo[RN], bhi[RN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i) { alo[i] = *(const u32x4*)(abuf + aoff[i][0]); ahi[i] = *(const u32x4*)(abuf + aoff[i][1]); }
+#pragma unroll
+        for (int j = 0; j < RN; ++j) { blo[j] = *(const u32x4*)(bbuf + boff[j][0]); bhi[j] = *(const u32x4*)(bbuf + boff[j][1]); }
+        if (t + NSTAGE - 1 < ktiles) {
+          int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+          DmaIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+          DmaIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+        }
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j) acc[i][j] = mfma32x64_bf8_fp8(alo[i], ahi[i], blo[j], bhi[j], acc[i][j]);
+      } else if constexpr (sizeof(T) == 2) {
         bf16x8 af0[RM], bf0[RN];
 #pragma unroll
         for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
@@ -637,6 +672,15 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
     }
     barrier_raw();          // every wave is past its last fragment read before the epilogue reuses the LDS
     PHASE(3);        // main loop
+    if constexpr (F8) {
+      const float dq = f8_a[1] * f8_b[1];
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= dq;
+    }
     igemm_epilogue_bn<T, CFG, FORM, EARLY>(acc, est, rows, ep, rm, smem, row_end, N, m0, n0, tid, lane, wave, wm0, wn0);
     // (igemm_epilogue_bn ends with a barrier: every wave is past its last read of the epilogue's LDS image before the next tile's operands land)
   }

@@ -91,6 +91,15 @@ DEV f32x16 mfma32x64_fp8(u32x4 a_lo, u32x4 a_hi, u32x4 b_lo, u32x4 b_hi, f32x16 
   const i32x8 b = {(int)b_lo[0], (int)b_lo[1], (int)b_lo[2], (int)b_lo[3], (int)b_hi[0], (int)b_hi[1], (int)b_hi[2], (int)b_hi[3]};
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
+// The same instruction with an e5m2 (bf8) A operand (cbsz = 1) and an e4m3 B operand: gradients x weights in the fp8 input gradient. Same operand map
+// (the probe's "e5m2 (A, cbsz 1) x e4m3" case).
+DEV f32x16 mfma32x64_bf8_fp8(u32x4 a_lo, u32x4 a_hi, u32x4 b_lo, u32x4 b_hi, f32x16 c) {
+  const i32x8 a = {(int)a_lo[0], (int)a_lo[1], (int)a_lo[2], (int)a_lo[3], (int)a_hi[0], (int)a_hi[1], (int)a_hi[2], (int)a_hi[3]};
+  const i32x8 b = {(int)b_lo[0], (int)b_lo[1], (int)b_lo[2], (int)b_lo[3], (int)b_hi[0], (int)b_hi[1], (int)b_hi[2], (int)b_hi[3]};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+// v_cvt_pk_bf8_f32: two f32 -> two OCP e5m2 bytes (round to nearest even), low byte = a.
+DEV uint32_t cvt2_bf8(float a, float b) { return (uint32_t)__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xFFFFu; }
 // v_cvt_pk_fp8_f32: two f32 -> two OCP e4m3 bytes (round to nearest even), low byte = a. The caller clamps to +-448 first.
 DEV uint32_t cvt2_fp8(float a, float b) { return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xFFFFu; }
 

@@ -274,7 +274,9 @@ __global__ __launch_bounds__(256) void bn_centered_var_kernel(const T* __restric
 }
 
 // dy = gamma*rstd*(dz - S1/M - xhat*G/M), G = sum dz*xhat = rstd*S2 (S2 = sum dz*(y-mean) from the reduce kernel); dgamma += G, dbeta += S1
-template <typename T, bool NT>
+// Q (bf16): the producer-fused e5m2 quantiser of the fp8 input gradient that reads dy (clite_bn.fp8_out / fp8_scale / fp8_amax as in bn_apply, with the
+// e5m2 format: gradients want its range, the forward's activations e4m3's precision)
+template <typename T, bool NT, bool Q = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* __restrict__ dout, const T* __restrict__ mask, const uint8_t* __restrict__ mbits, const T* __restrict__ y, const float* dstats,
                                                            T* __restrict__ dy, T* __restrict__ dz_out, float* dgamma, float* dbeta, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
@@ -305,6 +307,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
   }
   int row_begin = blockIdx.x * rows_per_block, row_end = row_begin + rows_per_block;
   if (row_end > p.M) row_end = p.M;
+  float qmax = 0.f;
+  bool qnan = false;
+  const float qscale = (Q && p.fp8_out) ? p.fp8_scale[0] : 1.f;
 #pragma unroll 4
   for (int r = row_begin + r0; r < row_end; r += RPS) {
     size_t idx = (size_t)r * p.C + c0;
@@ -325,6 +330,38 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(clite_bn p, const T* 
 #pragma unroll
     for (int e = 0; e < 8; ++e) d[e] = ka[e] * d[e] + kb[e] + kc[e] * (yv[e] - mean[e]);
     st8<NT>(dy + idx, d);
+    if constexpr (Q) {
+      round8_bf16(d);          // quantise / measure the value as stored
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qmax = fmaxf(qmax, fabsf(d[e])); qnan = qnan || d[e] != d[e]; }
+      if (p.fp8_out) {
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // the scale maps max |dy| of an earlier step to 448, 1/128 of e5m2's largest finite value: a gradient that grew since saturates only
+          // beyond 128 x that. A NaN passes the clamp untouched and converts to e5m2's NaN.
+          const float p0 = d[2 * e] * qscale, q0 = d[2 * e + 1] * qscale;
+          const float pp = p0 != p0 ? p0 : fminf(fmaxf(p0, -57344.f), 57344.f), qq = q0 != q0 ? q0 : fminf(fmaxf(q0, -57344.f), 57344.f);
+          w[e] = cvt2_bf8(pp, qq);
+        }
+        *(u32x2*)(p.fp8_out + idx) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+      }
+    }
+  }
+  if constexpr (Q) {
+    if (p.fp8_amax) {
+      __shared__ uint32_t red[4];
+      uint32_t mb = qnan ? 0x7FC00000u : f32_bits(qmax);
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) { const uint32_t o = (uint32_t)wave_shfl_xor_i((int)mb, sh); mb = o > mb ? o : mb; }
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mb;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t b = red[0];
+        for (int w = 1; w < 4; ++w) b = red[w] > b ? red[w] : b;
+        atomic_max_u32((uint32_t*)p.fp8_amax + (blockIdx.x % CLITE_FP8_AMAX_REPLICAS) * CLITE_FP8_AMAX_STRIDE, b);
+      }
+    }
   }
 }
 
@@ -783,6 +820,12 @@ extern "C" int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout
   int grid = bn_grid(p->M, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
   const bool nt = (size_t)p->M * p->C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
+  if (p->fp8_out || p->fp8_amax) {          // producer-fused e5m2 copy / amax of dy (bf16 only)
+    if (dtype != CLITE_BF16 || (p->fp8_out && !p->fp8_scale)) return -1;
+    if (nt) hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, mask_bits, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, false, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, mask_bits, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb);
+    return (int)hipGetLastError();
+  }
   if (nt) {
     DISPATCH(dtype,
              hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)dout, (const bf16*)mask, mask_bits, (const bf16*)y, dstats, (bf16*)dy, (bf16*)dz, dgamma, dbeta, rpb),

@@ -18,6 +18,11 @@ def conv_eligible(conv):
     return conv.in_channels % (64 if conv.k > 1 else 16) == 0
 
 
+def dgrad_eligible(conv):
+    """clite_conv_dgrad_fp8: stride 1, output channels (the contraction index) a multiple of 64."""
+    return conv.stride == 1 and conv.out_channels % 64 == 0 and conv.in_channels % 8 == 0
+
+
 class Fp8Forward:
     """Per-network state of the fp8 forward: the weight group, one (amax, scales) slot per BatchNorm whose output an fp8 convolution reads."""
 
@@ -42,6 +47,18 @@ class Fp8Forward:
         self.amax = torch.zeros(n, hip.FP8_AMAX_WORDS, dtype=torch.float32, device=rt.device)          # one slot of replicated words per tensor
         self.scales = torch.ones(n, 2, dtype=torch.float32, device=rt.device)
         self.ready, self._seen = set(), set()
+        # fp8 input gradients (DeviceRuntime.fp8_dgrad): e4m3 copies of the TRANSPOSED weights (same offsets in Arena.flat_lpT) and one e5m2 slot per
+        # BatchNorm for the gradient its bn_bwd_apply writes (the dy of the unit's conv)
+        self.tindex = {}
+        tspans = []
+        for conv in convs:
+            if conv_eligible(conv) and dgrad_eligible(conv) and rt.arena.has_wt(conv.weight):
+                self.tindex[id(conv)] = (len(tspans), conv)
+                tspans.append(rt.arena.index[conv.weight._clite[1]])
+        self.tgroup = hip.Fp8WeightGroup(rt.arena.flat_lpT, tspans) if tspans else None
+        self.gamax = torch.zeros(n, hip.FP8_AMAX_WORDS, dtype=torch.float32, device=rt.device)
+        self.gscales = torch.ones(n, 2, dtype=torch.float32, device=rt.device)
+        self.gready, self._gseen = set(), set()
 
     # ---- policy
     def wants(self, conv, H):
@@ -81,6 +98,40 @@ class Fp8Forward:
             hip.fp8_scale_update(self.amax, self.scales)
             self.ready |= self._seen
             self._seen = set()
+
+    # ---- backward (fp8 input gradients)
+    def wants_dgrad(self, conv, H):
+        """Does the input gradient of `conv` (output H x H) run on fp8 operands? The windowed stride-1 convs of >= 128 channels and the 1 x 1 ones at
+        <= 14 x 14 - the forward's policy minus the 64-channel 3 x 3 at 56 x 56, whose input gradient is the HBM-bound patch-resident kernel."""
+        return id(conv) in self.tindex and ((conv.k > 1 and conv.out_channels >= 128) or (conv.k == 1 and H <= 14))
+
+    def begin_backward(self):
+        """After Arena.ensure_transposed, before the first fp8 input gradient: this step's e4m3 copies of the transposed weights."""
+        if self.tgroup is not None:
+            self.tgroup.quantize()
+
+    def weight_t(self, conv):
+        i, _ = self.tindex[id(conv)]
+        o, n = self.tgroup.spans[i]
+        return hip.Fp8View(self.tgroup.q[o:o + n], self.tgroup.scales[i])
+
+    def grad_producer(self, bn, M, Cc, want):
+        """(clite_bn.fp8_* triple for bn_bwd_apply, the Fp8View clite_conv_dgrad_fp8 reads) for the gradient bn's backward writes; (None, None) when
+        its consumer stays bf16. Delayed scaling as for the activations: the first step records the amax only."""
+        if not want:
+            return None, None
+        s = self.slot[id(bn)]
+        self._gseen.add(s)
+        if s not in self.gready:
+            return (None, None, self.gamax[s]), None
+        q = torch.empty(M, Cc, dtype=torch.uint8, device=self.rt.device)
+        return (q, self.gscales[s], self.gamax[s]), hip.Fp8View(q, self.gscales[s])
+
+    def end_backward(self):
+        if self._gseen:
+            hip.fp8_scale_update(self.gamax, self.gscales)
+            self.gready |= self._gseen
+            self._gseen = set()
 
 
 class Fp8Text:

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "clite_fp8_quantize": [_I, _V, _U64, _V, _V, _V, _V],
     "clite_gemm_nt_fp8": [_V, _I, _V, _I, _I, _I, _I, _V, _V, _V, _V],
     "clite_conv_fwd_fp8": [_V, _V, _V, _V, _V, _V, _V],
+    "clite_conv_dgrad_fp8": [_V, _V, _V, _V, _V, _V, _V],
     "clite_fp8_scale_update": [_V, _V, _I, _V],
     "clite_fp8_quantize_group": [_V, _V, _V, _I, _I, _V, _V, _V, _V, _V],
     "clite_wgrad_group_workspace": [_I, C.c_int64, _V],
@@ -552,6 +553,12 @@ def gemm_nt_fp8(A8, B8, M, N, K, ep, lda=None, ldb=None):
 
 def conv_fwd_fp8(x8, w8, cv, ep):
     check(lib().clite_conv_fwd_fp8(p(x8.q), p(w8.q), C.byref(cv), p(x8.scales), p(w8.scales), C.byref(ep), stream_ptr(x8.q)), "conv_fwd_fp8")
+
+
+def conv_dgrad_fp8(dy8, wt8, cv, ep):
+    """dy8: the e5m2 copy of dy (bn_bwd_apply's fused quantiser), wt8: the e4m3 copy of the transposed weights [C][R][S][K]; ep: the BatchNorm-backward
+    form only (relu_bits + bn + colsum). include/clite.h: clite_conv_dgrad_fp8."""
+    check(lib().clite_conv_dgrad_fp8(p(dy8.q), p(wt8.q), C.byref(cv), p(dy8.scales), p(wt8.scales), C.byref(ep), stream_ptr(dy8.q)), "conv_dgrad_fp8")
 
 
 def stem_fwd(dt, xpad, wv, N, Hp, Wp, Ho, Wo, ep):

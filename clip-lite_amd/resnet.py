@@ -265,28 +265,29 @@ def resnet_forward(rt, net, image, training, staged=None):
     return feat, ctx
 
 
-def _bn_backward(rt, u, dout, mask, N, want_dz=False, train_params=True):
-    """BN backward of unit u given dout (gradient w.r.t. the post-BN tensor) and the ReLU mask (packed bits, an activation tensor, or None)."""
+def _bn_backward(rt, u, dout, mask, N, want_dz=False, train_params=True, fp8=None):
+    """BN backward of unit u given dout (gradient w.r.t. the post-BN tensor) and the ReLU mask (packed bits, an activation tensor, or None).
+    fp8: clite_bn.fp8_* triple - bn_bwd_apply also leaves the e5m2 copy of dy / records its amax (fp8.Fp8Forward.grad_producer)."""
     M, Cc = u.y.shape
     dstats = rt.new_stats(Cc, M)
     hip.bn_bwd_reduce(rt.dt, dout, mask, u.y, u.stats, dstats, M, Cc)
     dy = _alloc(rt, M, Cc)
     dz = _alloc(rt, M, Cc) if want_dz else None
     bn = u.bn
-    desc = hip.bn_desc(M, Cc, u.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn)
+    desc = hip.bn_desc(M, Cc, u.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn, fp8=fp8)
     dg = rt.arena.g(bn.weight) if bn.weight.requires_grad else None
     db = rt.arena.g(bn.bias) if bn.bias.requires_grad else None
     hip.bn_bwd_apply(rt.dt, desc, dout, mask, u.y, dstats, dy, dz, dg, db)
     return dy, dz
 
 
-def _bn_backward_apply(rt, u, dz, dstats):
+def _bn_backward_apply(rt, u, dz, dstats, fp8=None):
     """BN backward of unit u given dz (gradient w.r.t. the BN output, ReLU mask already applied) and its two reductions `dstats`
     (sum dz, sum dz*(y - mean)), both produced by the epilogue of the GEMM that wrote dz."""
     M, Cc = u.y.shape
     bn = u.bn
     dy = _alloc(rt, M, Cc)
-    desc = hip.bn_desc(M, Cc, u.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn)
+    desc = hip.bn_desc(M, Cc, u.stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, True, False, bn.momentum, bn.eps, False, centered=rt.precise_bn, fp8=fp8)
     dg = rt.arena.g(bn.weight) if bn.weight.requires_grad else None
     db = rt.arena.g(bn.bias) if bn.bias.requires_grad else None
     hip.bn_bwd_apply(rt.dt, desc, dz, None, u.y, dstats, dy, None, dg, db)
@@ -328,6 +329,21 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
             defer.conv(dy_, u_.x, u_.cv, dw)          # hip.WgradGroup: keeps dy / x referenced until it has been launched
 
     rt.arena.ensure_transposed(capturing=rt._capturing)
+    # fp8 input gradients (DeviceRuntime.fp8_dgrad; fp8.Fp8Forward): the units' dgrads inside a block read the e5m2 copy of dy that the producing
+    # bn_bwd_apply wrote and the e4m3 copy of the transposed weights (clite_conv_dgrad_fp8); weight gradients keep reading the bf16 dy
+    from .fp8 import forward_state
+    f8 = forward_state(rt, net) if (rt.fp8_dgrad and rt.fuse_bn_backward and rt.transposed_dgrad) else None
+    if f8 is not None and f8.tgroup is None:
+        f8 = None
+    if f8 is not None and not resume:
+        f8.begin_backward()
+
+    def gq(u_, i_):
+        """(fp8 triple for the bn_bwd_apply that writes unit u_'s dy, the e5m2 view its dgrad reads)"""
+        if f8 is None or i_ == 0 or (rt.s2_classes and hip.s2_classes_ok(u_.cv)):
+            return None, None
+        return f8.grad_producer(u_.bn, u_.y.shape[0], u_.y.shape[1], f8.wants_dgrad(u_.conv, u_.cv.Ho))
+
     if resume:
         dout, pre, first = ctx.pop("bwd_state")
     else:
@@ -341,13 +357,14 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         identity = ud is None
         # block output = relu(bn_last(y_last) + shortcut): the mask is the block output itself
         dyd = None
+        q8, dy8 = gq(last, len(units) - 1)
         if pre is None:
-            dy, dz = _bn_backward(rt, last, dout, last.bits, N, want_dz=identity)
+            dy, dz = _bn_backward(rt, last, dout, last.bits, N, want_dz=identity, fp8=q8)
             if ud is not None:
                 dyd, _ = _bn_backward(rt, ud, dout, last.bits, N)
         else:
             dz = dout
-            dy = _bn_backward_apply(rt, last, dz, pre)
+            dy = _bn_backward_apply(rt, last, dz, pre, fp8=q8)
             if ud is not None:
                 dyd, _ = _bn_backward(rt, ud, dz, None, N)
         pre = None
@@ -369,9 +386,12 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 if rt.s2_classes and hip.s2_classes_ok(u.cv):
                     hip.conv_dgrad_s2(dy, wd, u.cv, mk,       # 3x3 / stride 2: four parity classes, no zero taps
                                       wsubs=(ctx.get("s2w") or {}).get(id(u.conv)), wt=wt)
+                elif dy8 is not None:
+                    hip.conv_dgrad_fp8(dy8, f8.weight_t(u.conv), u.cv, mk())
                 else:
                     hip.conv_dgrad(dy, wd, u.cv, mk(), wt=wt)
-                dy = _bn_backward_apply(rt, prev, dx, dstats)
+                q8, dy8 = gq(prev, i - 1)
+                dy = _bn_backward_apply(rt, prev, dx, dstats, fp8=q8)
             else:
                 # gradient w.r.t. the block input: main path + shortcut
                 if identity and bi > 0 and rt.fuse_bn_backward:
@@ -420,6 +440,8 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         assert own_group is None
         ctx["bwd_state"] = (dout, pre, stop_block - 1)
         return
+    if f8 is not None:
+        f8.end_backward()
     xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq = ctx["stem"]
     # max-pool backward + ReLU mask + BatchNorm backward straight from (dpool, idx, y0): neither the un-pooled gradient nor the mask is stored
     bn1 = net.bn1

@@ -214,6 +214,13 @@ int clite_gemm_nt_fp8(const void* A8, int lda, const void* B8, int ldb, int M, i
  * C % 64 == 0 for windowed convs. */
 int clite_conv_fwd_fp8(const void* x8, const void* w8, const clite_conv* cv, const float* x_scales, const float* w_scales,
                        const clite_epilogue* ep, void* stream);
+/* ABI v11. Input gradient of a stride-1 convolution on fp8 operands, in the one form the bf16 ResNet backward issues for a unit inside a block:
+ * dx [N][H][W][C] bf16 = relu'(ep->relu_bits) * (dy (*) w), with the two BatchNorm-backward reductions (ep->bn_y, ep->bn_stats, ep->colsum) - every
+ * other clite_epilogue feature is refused. dy8: [N][Ho][Wo][K] OCP e5m2 (written by clite_bn_bwd_apply's producer-fused quantiser: clite_bn.fp8_*
+ * of that call; gradients get e5m2's range), wt8: the TRANSPOSED weights [C][R][S][K] in OCP e4m3; dy_scales / w_scales: device f32 {scale, 1 / scale}.
+ * K % 64 == 0, C % 8 == 0. v_mfma_scale_f32_32x32x64_f8f6f4 (A e5m2, B e4m3) at unit block scales, f32 accumulate. */
+int clite_conv_dgrad_fp8(const void* dy8, const void* wt8, const clite_conv* cv, const float* dy_scales, const float* w_scales,
+                         const clite_epilogue* ep, void* stream);
 /* Delayed scaling, once per step over all producer-fused tensors: slot i of `amax` (clite_bn.fp8_amax; a = the maximum of its words) with
  * a != 0: scales[2i] = 448 / a, scales[2i + 1] = a / 448 (both NaN when a is not finite); the slot is zeroed. A slot that stayed 0 keeps
  * its scales. */
@@ -265,7 +272,8 @@ typedef struct clite_bn {
   float* res_running_var;
   uint8_t* relu_bits;        /* clite_bn_apply with relu = 1: optional [M][C / 8] bytes, bit e of byte (m * C + c) / 8 = (out[m][c + e] > 0): the
                               * ReLU mask the backward pass needs, at 1/16 of the bytes of re-reading `out` for its sign. NULL: not written. */
-  /* clite_bn_apply, bf16, fp8 forward (the producer-fused quantiser of DESIGN.md §6.2; any of the three may be NULL):
+  /* clite_bn_apply (e4m3) and, ABI v11, clite_bn_bwd_apply (the same three fields, OCP e5m2 codes of dy for clite_conv_dgrad_fp8: clamp at +-57344, the
+   * scale still maps the recorded amax to 448, i.e. 128 x headroom for a gradient that grew since); bf16; any of the three may be NULL:
    *   fp8_out   [M][C] e4m3 copy of `out` for the convs that read it: q = e4m3(clamp(out * fp8_scale[0], +-448)) of the value as stored,
    *             written by the same pass — half a write instead of clite_fp8_quantize's two reads and half a write;
    *   fp8_scale device f32[2] = {scale, 1 / scale}: DELAYED scaling, made from an earlier step's amax (clite_fp8_scale_update);

@@ -216,6 +216,133 @@ def test_bn_apply_fused_e4m3_copy_matches_torch_cast(M, Cc, res):
     assert not amax.any() and abs(scales[0].item() * amax_true.item() / 448.0 - 1) < 1e-6
 
 
+def _pack_bits(act):
+    M, Cc = act.shape
+    return ((act > 0).view(M, Cc // 8, 8).to(torch.int32) * (1 << torch.arange(8, device=act.device, dtype=torch.int32))).sum(-1).to(torch.uint8)
+
+
+@pytest.mark.parametrize("N,H,W,Cc,K,R,pad", [(8, 14, 14, 256, 256, 3, 1), (16, 28, 28, 128, 128, 3, 1), (8, 7, 7, 512, 2048, 1, 0), (3, 9, 11, 136, 192, 3, 1)])
+def test_conv_dgrad_fp8_matches_dequantised_fp32(N, H, W, Cc, K, R, pad):
+    """clite_conv_dgrad_fp8 (ABI v11; e5m2 gradient x e4m3 transposed weights on the block-scaled MFMA, BatchNorm-backward epilogue) against torch's
+    f32 transposed convolution of the de-quantised operands, masked by the packed relu' bits; the two reductions against sums of the stored output."""
+    hip = _hip()
+    Ho, Wo = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    cv = hip.conv_desc(BF16, N, H, W, Cc, K, R, R, 1, pad)
+    M = N * H * W
+    g = torch.Generator(device="cuda").manual_seed(H + K)
+    w = (torch.randn(K, R, R, Cc, device="cuda", generator=g) * 0.05).bfloat16()
+    wt8 = hip.Fp8Tensor(w.permute(3, 1, 2, 0).contiguous(), BF16)          # [C][R][S][K]
+    dy = (torch.randn(N * Ho * Wo, K, device="cuda", generator=g) * 1e-3).bfloat16()
+    a = dy.float().abs().max().item()
+    scales = torch.tensor([448.0 / a, a / 448.0], device="cuda")
+    q = (dy.float() * scales[0]).clamp(-57344, 57344).to(torch.float8_e5m2)
+    dy8 = hip.Fp8View(q.view(torch.uint8), scales)
+    act = torch.randn(M, Cc, device="cuda", generator=g)
+    bits = _pack_bits(act)
+    y = (torch.randn(M, Cc, device="cuda", generator=g) + 3).bfloat16()
+    fst = hip.Stats(torch.zeros(8 * 3 * Cc, device="cuda"), 8, Cc)
+    fst.t.view(8, 3, Cc)[0, 0] = y.float().sum(0)
+    mean = y.float().sum(0) / M
+    dst = hip.Stats(torch.zeros(8 * 3 * Cc, device="cuda"), 8, Cc)
+    dx = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
+    hip.conv_dgrad_fp8(dy8, wt8, cv, hip.epilogue(dx, Cc, relu_bits=bits, colsum=dst, bn=(y, fst, M)))
+    torch.cuda.synchronize()
+    wdeq = (wt8.q.view(torch.float8_e4m3fn).float() * wt8.scales[1]).permute(3, 0, 1, 2)          # [K][C][R][S]: conv_transpose2d's (in, out, kh, kw)
+    dydeq = (q.float() * scales[1]).view(N, Ho, Wo, K).permute(0, 3, 1, 2)
+    with torch.backends.cudnn.flags(enabled=False):
+        ref = F.conv_transpose2d(dydeq, wdeq, stride=1, padding=pad).permute(0, 2, 3, 1).reshape(M, Cc) * (act > 0)
+    assert _rel(dx, ref) < 6e-3
+    cs = dst.t.view(8, 3, Cc).sum(0)
+    assert _rel(cs[0], dx.float().sum(0)) < 2e-3 and _rel(cs[1], (dx.float() * (y.float() - mean)).sum(0)) < 4e-3
+
+
+def test_bn_bwd_apply_fused_e5m2_copy_matches_torch_cast():
+    """clite_bn_bwd_apply with clite_bn.fp8_* (ABI v11): the copy equals torch's float8_e5m2 cast of the STORED bf16 dy at the given scale, the
+    slot holds max |dy|, dy is bit-identical to the plain call's (a streaming-size and a cached-size tensor)."""
+    hip = _hip()
+    for M, Cc in ((100352, 512), (6272, 512)):
+        g = torch.Generator(device="cuda").manual_seed(M % 991)
+        y = (torch.randn(M, Cc, device="cuda", generator=g) * 2 + 0.5).bfloat16()
+        dz = (torch.randn(M, Cc, device="cuda", generator=g) * 1e-3).bfloat16()
+        st = hip.Stats(torch.zeros(8 * 3 * Cc, device="cuda"), 8, Cc)
+        st.t.view(8, 3, Cc)[0, 0] = y.float().sum(0)
+        st.t.view(8, 3, Cc)[0, 1] = (y.float() ** 2).sum(0)
+        dst = hip.Stats(torch.zeros(8 * 3 * Cc, device="cuda"), 8, Cc)
+        dst.t.view(8, 3, Cc)[0, 0] = dz.float().sum(0)
+        dst.t.view(8, 3, Cc)[0, 1] = (dz.float() * (y.float() - y.float().mean(0))).sum(0)
+        gamma, beta = 1 + 0.1 * torch.randn(Cc, device="cuda", generator=g), torch.zeros(Cc, device="cuda")
+
+        def run(fp8):
+            rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+            dy = torch.empty(M, Cc, device="cuda", dtype=torch.bfloat16)
+            hip.bn_bwd_apply(BF16, hip.bn_desc(M, Cc, st, gamma, beta, rm, rv, True, False, 0.1, 1e-5, False, fp8=fp8), dz, None, y, dst, dy, None, None, None)
+            torch.cuda.synchronize()
+            return dy
+
+        dy0 = run(None)
+        a = dy0.float().abs().max().item()
+        scales = torch.tensor([448.0 / (0.5 * a), 0.5 * a / 448.0], device="cuda")          # stale by 2x: inside e5m2's headroom
+        q = torch.full((M, Cc), 0x55, device="cuda", dtype=torch.uint8)
+        amax = torch.zeros(hip.FP8_AMAX_WORDS, device="cuda")
+        dy1 = run((q, scales, amax))
+        assert torch.equal(dy0, dy1)
+        assert amax.max().item() == a
+        ref = (dy0.float() * scales[0]).clamp(-57344, 57344).to(torch.float8_e5m2).view(torch.uint8)
+        same = (q == ref) | ((q & 0x7f == 0) & (ref & 0x7f == 0))
+        assert same.all(), (~same).sum().item()
+
+
+def test_fp8_input_gradients_track_the_bf16_backward(monkeypatch):
+    """DeviceRuntime.fp8_dgrad: ResNet-50 (Bottleneck: 3 x 3 convs of >= 128 channels, 1 x 1 convs at <= 14 x 14 with 128 x 128 inputs from layer2 on)
+    + 2-layer BERT + heads on the conditioned problem, fp8 forward in both runs; the second and third forward / backward of the same batch and weights
+    (the first records the amaxes) with the fp8 input gradients against the same steps with bf16 input gradients. The forward is identical, so the
+    losses agree to the run-to-run noise of the float-atomic reductions; the gradient arenas' cosine must stay >= 0.90 (e5m2 carries 2 mantissa bits -
+    2^-3 relative per element of dy, averaged down by the K-sums - on top of the same floor as the fp8-forward test), and the fp8 kernel must have run."""
+    from detfill import det_tensor
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    hip = _hip()
+    calls = []
+    orig = hip.conv_dgrad_fp8
+    monkeypatch.setattr(hip, "conv_dgrad_fp8", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    B, L = 16, 12
+    ids = torch.randint(1000, 30522, (B, L), generator=torch.Generator().manual_seed(9))
+    batch = {"image": det_tensor("f8dg", (B, 3, 128, 128), "normal").cuda(), "input_ids": ids.cuda(), "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()}
+    u = (det_tensor("f8u1c", (B, 2048), "uniform").cuda(), det_tensor("f8u2c", (B, 768), "uniform").cuda())
+    res = []
+    for dg in (False, True, False):
+        torch.manual_seed(4)
+        te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
+        te.strans.hidden_dropout_prob = te.strans.attention_probs_dropout_prob = 0.0
+        M = VLInfoModel(te, ImageEncoder("resnet50"), JSDInfoMaxLoss(2048, 768, "dot", 0.1, True, True), "train_sbert", is_amp=True)
+        with torch.no_grad():
+            for n, p in M.named_parameters():
+                if n.endswith("bn3.weight"):
+                    p.mul_(0.1)
+        M = M.to("cuda").train()
+        M.runtime.fp8 = True
+        M.runtime.fp8_dgrad = dg
+        M.loss.set_prior_noise(*u)
+        n0 = len(calls)
+        for it in range(3):
+            M.runtime.arena.flat_g.zero_()
+            out = M(batch)
+            out["loss"].backward()
+        torch.cuda.synchronize()
+        if dg:
+            # two fused steps x (the 10 stride-1 3 x 3 convs of layer2-4 + the 9 last 1 x 1 convs of layer3 / layer4's blocks, 8 x 8 and 4 x 4 here)
+            assert len(calls) - n0 == 2 * 19
+            (st,) = M.runtime.fp8_nets.values()
+            assert st.gready and not st._gseen and not st.gamax.any() and torch.isfinite(st.gscales).all()
+        res.append((out["loss"].item(), M.runtime.arena.flat_g.clone()))
+    (l0, g0), (l1, g1), (l2, g2) = res
+    cos = (g0 @ g1 / (g0.norm() * g1.norm())).item()
+    cos_self = (g0 @ g2 / (g0.norm() * g2.norm())).item()
+    print(f"loss bf16-dgrad {l0:.5f} fp8-dgrad {l1:.5f}; gradient cosine fp8~bf16 dgrad {cos:.4f} (bf16~bf16 {cos_self:.4f})")
+    assert abs(l0 - l1) < 2e-2 and cos >= 0.90
+
+
 def test_bert_producers_leave_the_e4m3_copies_at_full_size():
     """The text encoder's fused quantisers at the benchmark's size (M = 3840 tokens; ABI v11): clite_layernorm_fwd_q8 and the fp8 FFN1 launch
     (bias + pre-activation store + GELU) leave torch's float8_e4m3fn cast of their STORED bf16 outputs at the given scale, record max |out|, and

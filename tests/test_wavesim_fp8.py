@@ -294,6 +294,143 @@ def test_layernorm_forward_leaves_the_e4m3_copy_and_the_amax(M, Cc, p):
     assert L.clite_layernorm_fwd_q8(F32, ptr(x), ptr(gamma), ptr(beta), 1e-12, ptr(out1), ptr(st1), M, Cc, p, 1234, 5, None, None, ptr(amax2), None) == -1
 
 
+def e5m2_values():
+    v = np.zeros(256, np.float32)
+    for b in range(256):
+        s_, e, m = b >> 7, (b >> 2) & 31, b & 3
+        if e == 31:
+            r = np.nan if m else np.inf
+        elif e == 0:
+            r = m * 2.0 ** -16
+        else:
+            r = (1 + m / 4) * 2.0 ** (e - 15)
+        v[b] = -r if s_ else r
+    return v
+
+
+E5M2 = e5m2_values()
+
+
+def quantize_e5m2_at(x, scale):
+    """e5m2 codes of clamp(x * scale, +-57344), round to nearest even (numpy restatement of the producer-fused gradient quantiser)."""
+    y = np.clip(x.astype(np.float32) * np.float32(scale), -57344, 57344).astype(np.float32)
+    pos = E5M2[:124]                                          # 0 .. 57344 ascending (0x00..0x7b)
+    idx = np.searchsorted(pos, np.abs(y), side="left").clip(1, 123)
+    lo, hi = pos[idx - 1], pos[idx]
+    dl, dh = np.abs(y) - lo, hi - np.abs(y)
+    pick_hi = (dh < dl) | ((dh == dl) & (idx % 2 == 0))
+    code = np.where(pick_hi, idx, idx - 1).astype(np.uint8)
+    code = np.where(np.abs(y) == 0, 0, code).astype(np.uint8)
+    return code | np.where(np.signbit(y), 0x80, 0).astype(np.uint8)
+
+
+@pytest.mark.parametrize("M,Cc", [(70, 64), (33, 256)])
+def test_bn_bwd_apply_writes_the_e5m2_copy_and_the_amax(M, Cc):
+    """clite_bn_bwd_apply with clite_bn.fp8_* (ABI v11): the e5m2 codes of the STORED bf16 dy at the given scale, max |dy| in the slot, dy itself
+    bit-identical to the plain call's."""
+    from simlib import pack_relu_bits
+    L = lib()
+    rng = np.random.default_rng(M * 3 + Cc)
+    y = bf16_round(rng.standard_normal((M, Cc)).astype(np.float32) * 2 + 0.5)
+    dout = bf16_round(rng.standard_normal((M, Cc)).astype(np.float32) * 1e-3)
+    act = rng.standard_normal((M, Cc)).astype(np.float32)
+    bits = pack_relu_bits(act)
+    yb, db = to_bf16(y), to_bf16(dout)
+    gamma = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    beta = np.zeros(Cc, np.float32)
+    stats = np.zeros((1, 3, Cc), np.float32)
+    stats[0, 0], stats[0, 1] = y.sum(0), (y * y).sum(0)
+    dz = dout * (act > 0)
+    dstats = np.zeros((1, 3, Cc), np.float32)
+    dstats[0, 0], dstats[0, 1] = dz.sum(0), (dz * (y - y.mean(0))).sum(0)
+    L.clite_bn_bwd_apply.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 10
+
+    def run(fp8):
+        rm, rv = np.zeros(Cc, np.float32), np.ones(Cc, np.float32)
+        p = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 0, 0.1, 1e-5, 0, 1, 3 * Cc, 0)
+        if fp8 is not None:
+            p.fp8_out, p.fp8_scale, p.fp8_amax = ptr(fp8[0]), ptr(fp8[1]), ptr(fp8[2])
+        dy = np.zeros((M, Cc), np.uint16)
+        assert L.clite_bn_bwd_apply(C.byref(p), BF16, ptr(db), None, ptr(bits), ptr(yb), ptr(dstats), ptr(dy), None, None, None, None) == 0
+        return dy
+
+    dy0 = run(None)
+    a = from_bf16(dy0)
+    scale = np.float32(448.0 / (0.5 * np.abs(a).max()))          # stale by 2x: e5m2's headroom (57344 / 448) absorbs it, nothing saturates
+    q = np.full((M, Cc), 0x55, np.uint8)
+    scales = np.array([scale, 1 / scale], np.float32)
+    amax = np.zeros(SLOT, np.float32)
+    dy1 = run((q, scales, amax))
+    assert np.array_equal(dy0, dy1)
+    assert amax.max() == np.abs(a).max() and not amax.reshape(16, 32)[:, 1:].any()
+    ref = quantize_e5m2_at(a, scale)
+    assert np.array_equal(q & 0x7f, ref & 0x7f) and np.array_equal((q >> 7)[a != 0], (ref >> 7)[a != 0])
+    assert np.abs(E5M2[q]).max() <= 2 * 448.0 * 1.25 and np.isfinite(E5M2[q]).all()
+    amax2 = np.zeros(SLOT, np.float32)
+    run((None, None, amax2))
+    assert amax2.max() == np.abs(a).max()
+
+
+@pytest.mark.parametrize("N,H,W,Cc,K,R,pad", [(2, 8, 8, 64, 64, 3, 1), (3, 6, 6, 136, 128, 1, 0), (2, 9, 7, 128, 64, 3, 1)])
+def test_conv_dgrad_fp8_bn_backward_form(N, H, W, Cc, K, R, pad):
+    """clite_conv_dgrad_fp8 (ABI v11): dx = relu'(bits) * (dy8 (*) wt8) * dy_scales[1] * w_scales[1] with dy in e5m2 and the transposed weights
+    [C][R][S][K] in e4m3 on v_mfma_scale_f32_32x32x64_f8f6f4 (A e5m2 / B e4m3: the operand map the hardware probe measured), stored as bf16, plus
+    the two BatchNorm-backward reductions - against numpy on the de-quantised operands (products of an e5m2 and an e4m3 value are exact in f32).
+    Ragged tiles (M, C not multiples of 128) included; the refusals (anything but that epilogue form; stride 2; K % 64)."""
+    from simlib import pack_relu_bits
+    from test_wavesim_igemm import conv_dgrad_ref
+    L = lib()
+    L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.clite_conv_dgrad_fp8.argtypes = [C.c_void_p] * 7
+    rng = np.random.default_rng(H * 5 + K)
+    Ho, Wo = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    cv = Conv(BF16, N, H, W, Cc, K, R, R, 1, pad, Ho, Wo)
+    M = N * H * W
+    w = (rng.standard_normal((K, R, R, Cc)) * 0.1).astype(np.float32)
+    wt = np.ascontiguousarray(w.transpose(3, 1, 2, 0))          # [C][R][S][K]
+    qwt, sw, _ = _quant(L, wt, F32)
+    dy = (rng.standard_normal((N, Ho, Wo, K)) * 1e-3).astype(np.float32)
+    sdy = np.float32(448.0 / np.abs(dy).max())
+    qdy = quantize_e5m2_at(dy, sdy)
+    sy = np.array([sdy, 1 / sdy], np.float32)
+    act = rng.standard_normal((M, Cc)).astype(np.float32)
+    bits = pack_relu_bits(act)
+    y = bf16_round(rng.standard_normal((M, Cc)).astype(np.float32) + 3.0)
+    yb = to_bf16(y)
+    Rr = 4
+    fstats = np.zeros((Rr, 3, Cc), np.float32)
+    fstats[:, 0] = y.sum(0) / Rr
+    mean = fstats[:, 0].sum(0) / M
+    out = np.zeros((M, Cc), np.uint16)
+    dst = np.zeros((Rr, 3, Cc), np.float32)
+
+    def mk(**kw):
+        ep = make_ep(out, Cc, colsum=dst, relu_bits=bits, **kw)
+        ep.colsum_replicas, ep.colsum_stride = Rr, 3 * Cc
+        ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = ptr(yb), ptr(fstats), Rr, 3 * Cc, 1.0 / M
+        return ep
+
+    assert L.clite_conv_dgrad_fp8(ptr(qdy), ptr(qwt), C.byref(cv), ptr(sy), ptr(sw), C.byref(mk()), None) == 0
+    wdeq = np.ascontiguousarray(E4M3[qwt].transpose(3, 1, 2, 0))          # back to [K][R][S][C]
+    g = conv_dgrad_ref(E5M2[qdy], wdeq, (N, H, W, Cc), 1, pad).reshape(M, Cc) * (sy[1] * sw[1])
+    v = g * (act > 0)
+    got = from_bf16(out)
+    assert np.abs(got - v).max() <= 6e-3 * np.abs(v).max()
+    d = dst.sum(0)
+    assert np.abs(d[0] - got.sum(0)).max() <= 1e-3 * max(np.abs(got.sum(0)).max(), 1e-9)
+    assert np.abs(d[1] - (got * (y - mean)).sum(0)).max() <= 2e-3 * np.abs((got * (y - mean)).sum(0)).max()
+    # and the format costs what e5m2 x e4m3 costs: ~10 % of the gradient's scale on N(0, 1e-3) x N(0, 0.1) operands
+    exact = conv_dgrad_ref(dy, w, (N, H, W, Cc), 1, pad).reshape(M, Cc) * (act > 0)
+    assert np.abs(got - exact).max() <= 0.2 * np.abs(exact).max()
+    res = np.zeros((M, Cc), np.uint16)
+    assert L.clite_conv_dgrad_fp8(ptr(qdy), ptr(qwt), C.byref(cv), ptr(sy), ptr(sw), C.byref(mk(residual=res)), None) == -1
+    assert L.clite_conv_dgrad_fp8(ptr(qdy), ptr(qwt), C.byref(cv), ptr(sy), ptr(sw), C.byref(make_ep(out, Cc)), None) == -1
+    cv2 = Conv(BF16, N, H, W, Cc, K, R, R, 2, pad, (H + 2 * pad - R) // 2 + 1, (W + 2 * pad - R) // 2 + 1)
+    assert L.clite_conv_dgrad_fp8(ptr(qdy), ptr(qwt), C.byref(cv2), ptr(sy), ptr(sw), C.byref(mk()), None) == -1
+    cv3 = Conv(BF16, N, H, W, Cc, 48, R, R, 1, pad, Ho, Wo)
+    assert L.clite_conv_dgrad_fp8(ptr(qdy), ptr(qwt), C.byref(cv3), ptr(sy), ptr(sw), C.byref(mk()), None) == -1
+
+
 def test_grouped_weight_quantiser_and_scale_update():
     """clite_fp8_quantize_group: three tensors of one bf16 arena (one longer than a workgroup's 8192-element chunk, one all zero) get the
     stand-alone quantiser's codes and scales, untouched bytes between them stay untouched; clite_fp8_scale_update turns recorded amaxes into

@@ -298,9 +298,38 @@ inline f32x16 mfma32_fp8(uint64_t a, uint64_t b, f32x16 c) {
   wave_barrier_();
   return c;
 }
+// OCP e5m2: 1 sign, 5 exponent (bias 15), 2 mantissa bits; infinities and NaNs as IEEE half's top byte
+inline float fp8_e5m2_to_f32(uint8_t v) {
+  int s = v >> 7, e = (v >> 2) & 31, m = v & 3;
+  float r;
+  if (e == 31) r = m ? NAN : INFINITY;
+  else if (e == 0) r = ldexpf((float)m, -16);              // subnormal: m/4 * 2^-14
+  else r = ldexpf(1.0f + m / 4.0f, e - 15);
+  return s ? -r : r;
+}
+inline uint8_t f32_to_fp8_e5m2(float f) {                  // round to nearest even; overflow saturates at +-57344 (v_cvt_pk_bf8_f32 with clamping semantics of the callers' range)
+  if (f != f) return 0x7f;
+  uint8_t s = std::signbit(f) ? 0x80 : 0;
+  float a = fabsf(f);
+  if (a >= 61440.f) return s | 0x7b;                       // beyond the midpoint above the largest finite value (57344): saturate
+  if (a < ldexpf(1.f, -17)) return s;
+  int e;
+  float m = frexpf(a, &e);
+  int E = e - 1 + 15;
+  float q;
+  if (E >= 1) q = rintf((m * 2.f - 1.f) * 4.f);
+  else { q = rintf(ldexpf(a, 16)); E = 0; }
+  int mi = (int)q;
+  if (E >= 1 && mi == 4) { mi = 0; ++E; }
+  if (E == 0 && mi == 4) { mi = 0; E = 1; }
+  if (E >= 31) return s | 0x7b;
+  return s | (uint8_t)(E << 2) | (uint8_t)mi;
+}
+inline uint32_t cvt2_bf8(float a, float b) { return (uint32_t)f32_to_fp8_e5m2(a) | ((uint32_t)f32_to_fp8_e5m2(b) << 8); }
 // v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3, unit scales): lane (r, h) holds k = 16 h + j (bytes 0..15) and k = 32 + 16 h + j - 16 (bytes 16..31)
 // - the map tools/micro/mfma_scale_probe.hip measured on the hardware
-inline f32x16 mfma32x64_fp8(u32x4 a_lo, u32x4 a_hi, u32x4 b_lo, u32x4 b_hi, f32x16 c) {
+template <bool A_E5M2>
+inline f32x16 mfma32x64_f8_(u32x4 a_lo, u32x4 a_hi, u32x4 b_lo, u32x4 b_hi, f32x16 c) {
   auto& w = wavesim::g_block->waves[wavesim::g_wave];
   int l = wavesim::g_lane;
   memcpy(&w.slot[l][0], &a_lo, 16);
@@ -316,13 +345,15 @@ inline f32x16 mfma32x64_fp8(u32x4 a_lo, u32x4 a_hi, u32x4 b_lo, u32x4 b_hi, f32x
       const int h = (k >> 4) & 1, j = (k & 15) + 16 * (k >> 5);
       const uint8_t av = ((const uint8_t*)&w.slot[row + 32 * h][0])[j];
       const uint8_t bv = ((const uint8_t*)&w.slot[col + 32 * h][4])[j];
-      acc = fmaf(fp8_e4m3_to_f32(av), fp8_e4m3_to_f32(bv), acc);
+      acc = fmaf(A_E5M2 ? fp8_e5m2_to_f32(av) : fp8_e4m3_to_f32(av), fp8_e4m3_to_f32(bv), acc);
     }
     c[i] = acc;
   }
   wave_barrier_();
   return c;
 }
+inline f32x16 mfma32x64_fp8(u32x4 a_lo, u32x4 a_hi, u32x4 b_lo, u32x4 b_hi, f32x16 c) { return mfma32x64_f8_<false>(a_lo, a_hi, b_lo, b_hi, c); }
+inline f32x16 mfma32x64_bf8_fp8(u32x4 a_lo, u32x4 a_hi, u32x4 b_lo, u32x4 b_hi, f32x16 c) { return mfma32x64_f8_<true>(a_lo, a_hi, b_lo, b_hi, c); }
 // v_mfma_f32_32x32x2_f32
 inline f32x16 mfma32_f32(float a, float b, f32x16 c) {
   auto& w = wavesim::g_block->waves[wavesim::g_wave];

@@ -12,13 +12,15 @@ V=build/varf8/libclite_hip_var.so
 python bench.py $B --visual resnet101 --batch 256 > $O/r4_bench_rn101_b256.json 2> $O/err.log
 python bench.py $B --visual resnet101 --batch 256 --fp8 > $O/r4_bench_rn101_b256_fp8.json 2>> $O/err.log
 [ -f $V ] && CLITE_HIP_LIB=$V python bench.py $B --visual resnet101 --batch 256 --fp8 > $O/r4_bench_rn101_b256_fp8_nonscaled.json 2>> $O/err.log
-python bench.py $B --visual resnet101 --batch 256 --fp8 --no-fp8-text > $O/r4_bench_rn101_b256_fp8_image_only.json 2>> $O/err.log
+python bench.py $B --visual resnet101 --batch 256 --fp8 --no-fp8-text --no-fp8-dgrad > $O/r4_bench_rn101_b256_fp8_image_only.json 2>> $O/err.log
+python bench.py $B --visual resnet101 --batch 256 --fp8 --no-fp8-dgrad > $O/r4_bench_rn101_b256_fp8_forward_only.json 2>> $O/err.log
 python bench.py $B --visual resnet101 --batch 256 > $O/r4_bench_rn101_b256_again.json 2>> $O/err.log
 python bench.py $B --visual resnet101 --batch 256 --fp8 > $O/r4_bench_rn101_b256_fp8_again.json 2>> $O/err.log
 python bench.py $B > $O/r4_bench_rn50_b128.json 2>> $O/err.log
 python bench.py $B --fp8 > $O/r4_bench_fp8.json 2>> $O/err.log
 [ -f $V ] && CLITE_HIP_LIB=$V python bench.py $B --fp8 > $O/r4_bench_fp8_nonscaled.json 2>> $O/err.log
-python bench.py $B --fp8 --no-fp8-text > $O/r4_bench_fp8_image_only.json 2>> $O/err.log
+python bench.py $B --fp8 --no-fp8-text --no-fp8-dgrad > $O/r4_bench_fp8_image_only.json 2>> $O/err.log
+python bench.py $B --fp8 --no-fp8-dgrad > $O/r4_bench_fp8_forward_only.json 2>> $O/err.log
 python bench.py $B --loss infonce > $O/r4_bench_infonce.json 2>> $O/err.log
 python bench.py $B --batch 256 > $O/r4_bench_rn50_b256.json 2>> $O/err.log
 for f in $O/r4_bench_*.json; do python -c "import sys,json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', round(d['ms_per_step'],2), round(d['value']), d['dtype'][:12])"; done
