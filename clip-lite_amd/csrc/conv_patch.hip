@@ -530,7 +530,209 @@ __global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __
 
 }  // namespace
 
-size_t clite::conv3x3_wgrad_patch_workspace() { return (size_t)CLITE_PATCH_WGS * WG_OUT * sizeof(float); }
+// =====================================================================================================================================
+// Patch-resident weight gradient of the STEM (7 x 7 / stride 2 on the pre-padded NHWC4 image, gemm.hip: clite_stem_fwd): dw[c][r][s][ch] (f32) +=
+// sum over output pixels of dy[p][c] * xpad[2 oy + r][2 ox + s][ch]. As an implicit GEMM it has 64 x 224 outputs and 1.6 M pixels to contract; the
+// grouped form streams dy (205 MB at batch 128) and gathers every input pixel ~12 times out of L2 (189 us for an HBM ideal of 47). Here, as in
+// conv3x3_wgrad_patch_kernel, ONE workgroup owns the whole output in registers and walks a contiguous range of strips of two output rows:
+//   dy strip    2 Wo pixels x 128 B, contiguous in memory, LDS-DMA into the swizzled [pixel][64 ch] image (A fragments: wg_frag_base / wg_frag_at)
+//   x  patch    input rows 2 oy0 .. 2 oy0 + 8: ONE contiguous block of 9 Wp x 8 B, copied as it lies. For a fixed tap row r the 32 columns (s, ch) of
+//               pixel ox are the 64 contiguous bytes at ((2 oyl + r) Wp + 2 ox) x 8: a [pixel][32] image whose rows start 16 B apart and overlap,
+//               which a transposed read does not mind (every lane supplies its own row address).
+// 8 waves: wave = (kh, rp); it multiplies the k-steps (16 pixels) of parity kh for tap rows 2 rp, 2 rp + 1 (rp = 3: row 6 only) and both channel
+// halves: 4 (2) accumulator blocks. The two parities meet in LDS at the end; the workgroup's [64][224] partial sums go to its slab of the workspace
+// and stem_wgrad_reduce_kernel adds the slabs straight into the [64][7][7][3] gradient (dropping the s = 7 / ch = 3 padding columns).
+namespace {
+
+constexpr int SW_MAXPIX = 256;                      // dy pixels per strip (2 Wo <= 256)
+constexpr int SW_DYB = SW_MAXPIX * PIXB;            // 32 KB
+constexpr int SW_XB = 20 * 1024;                    // 10 Wp x 8 B + 128 <= 20 KB: Wp <= 254
+constexpr int SW_STAGE = SW_DYB + SW_XB;
+constexpr int SW_OUT = 64 * 224;
+static_assert(2 * SW_STAGE <= 160 * 1024 && SW_OUT * 4 <= 2 * SW_STAGE && 3 * SW_STAGE <= 160 * 1024, "LDS budget");
+
+struct StemWgradArgs {
+  const void* dy;
+  const void* x;
+  uint32_t dybytes, xbytes;
+  int N, Hp, Wp, Ho, Wo;
+  int strips_per_img, nstrips;          // strips of 2 output rows
+  float* ws;                            // [gridDim.x][64][224] f32 slabs
+};
+
+// NW = 8: one workgroup per CU, two LDS stages (the next strip's images land under this one's K loop), the k-steps split between two wave sets.
+// NW = 4 (default): THREE single-stage workgroups per CU - a persistent workgroup with one strip of loads in flight runs in lockstep with the other
+// 255 and sees the DMA round trip per strip (133 us at batch 128: 2.4 TB/s); three independent workgroups per CU cover each other's waits.
+#ifndef CLITE_STEM_WGRAD_NW
+#define CLITE_STEM_WGRAD_NW 4
+#endif
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void stem_wgrad_patch_kernel(StemWgradArgs a, int strips_per_wg) {
+  constexpr int NSTG = NW == 8 ? 2 : 1;
+  constexpr int KSTEP = NW == 8 ? 2 : 1;
+  __shared__ __attribute__((aligned(1024))) char smem[NSTG * SW_STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int kh = NW == 8 ? wave >> 2 : 0, rp = wave & 3;
+  const int npix = 2 * a.Wo;                          // pixels of a full strip
+  const int nks = npix >> 4;                          // k-steps per strip (Wo % 16 == 0: a k-step never straddles the two rows)
+  const int ks_row = a.Wo >> 4;
+  const int ndy = npix >> 3;                          // DMA instructions of the dy strip (8 pixels each)
+  const int xbytes_strip = 9 * a.Wp * 8;
+  const int nx = (xbytes_strip + 1023) >> 10;
+
+  int s_begin = blockIdx.x * strips_per_wg, s_end = s_begin + strips_per_wg;
+  if (s_end > a.nstrips) s_end = a.nstrips;
+  const rsrc_t rdy = make_rsrc(a.dy, a.dybytes), rx = make_rsrc(a.x, a.xbytes);
+
+  auto issue = [&](int strip, char* dst) {
+    const int n = strip / a.strips_per_img;
+    const int oy0 = (strip - n * a.strips_per_img) * 2;
+    const int rows = a.Ho - oy0 < 2 ? a.Ho - oy0 : 2;          // (an odd Ho leaves a one-row strip: its second row gathers as zeros)
+    const uint32_t dbase = (uint32_t)((n * a.Ho + oy0) * a.Wo) * PIXB;
+    for (int i = wave; i < ndy; i += NW) {
+      const int pix = i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
+      const bool v = pix < rows * a.Wo;
+      PATCH_LOAD(rdy, v ? dbase + (uint32_t)(pix * PIXB + chunk * 16) : OOB_OFF, dst + i * 1024);
+    }
+    // the patch: 9 input rows from row 2 oy0, as they lie (rows past the image's padded height read as zeros: the buffer's bound, and for an image
+    // that is not the last the one-row strip's second output row is masked by its zero dy)
+    const uint32_t xbase = (uint32_t)((n * a.Hp + 2 * oy0) * a.Wp) * 8u;
+    const uint32_t xend = (uint32_t)((n + 1) * a.Hp * a.Wp) * 8u;
+    for (int i = wave; i < nx; i += NW) {
+      const uint32_t off = xbase + (uint32_t)(i * 1024 + lane * 16);
+      PATCH_LOAD(rx, (i * 1024 + lane * 16 < xbytes_strip && off < xend) ? off : OOB_OFF, dst + SW_DYB + i * 1024);
+    }
+  };
+
+  // per-lane constants: A fragments (both channel halves) and the B fragment's offset inside a tap row's [pixel][32] image
+  const int oa0 = wg_frag_base(0, 0, lane), oa1 = wg_frag_base(0, 32, lane);
+  const int bl = 16 * (8 * (lane >> 5) + ((lane >> 2) & 3)) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  const int r0 = 2 * rp;
+  const bool two = rp < 3;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f; }
+
+  if (NSTG == 2 && s_begin < s_end) issue(s_begin, smem);
+  for (int strip = s_begin; strip < s_end; ++strip) {
+    const int cur = NSTG == 2 ? (strip - s_begin) & 1 : 0;
+    if (NSTG == 1) {
+      if (strip > s_begin) lds_barrier();          // every wave is past the K loop that read the stage
+      issue(strip, smem);
+    }
+    wait_vmcnt<0>();
+    lds_barrier();          // the strip's images landed (every wave's part); (two stages:) every wave is past the K loop that read the other stage
+    if (NSTG == 2 && strip + 1 < s_end) issue(strip + 1, smem + (cur ^ 1) * SW_STAGE);
+    const char* dyi = smem + cur * SW_STAGE;
+    const char* xi = dyi + SW_DYB;
+    // every wave multiplies TWO tap rows: for rp = 3 the second one is the non-existent row 7 - its reads stay inside the x region of the stage (patch
+    // row 2 oyl + 7 <= 9: the launch bounds 10 Wp x 8 B by SW_XB) and its sums are never stored; a wave-uniform branch around it doubled the kernel's
+    // accumulator registers (one set per instantiation: 266 registers, one wave per SIMD, 133 us instead of 60)
+#pragma unroll 2
+    for (int ks = kh; ks < nks; ks += KSTEP) {
+      const int oyl = ks >= ks_row ? 1 : 0;
+      const int ox0 = (ks - oyl * ks_row) << 4;
+      const char* pa = dyi + ks * 16 * PIXB;
+      const bf16x8 fa0 = wg_frag_at(pa + oa0), fa1 = wg_frag_at(pa + oa1);
+      const char* pb = xi + ((2 * oyl + r0) * a.Wp + 2 * ox0) * 8 + bl;
+      union { s16x4 v[2]; bf16x8 h; } b0, b1;
+      b0.v[0] = lds_read_tr16(pb); b0.v[1] = lds_read_tr16(pb + 64);          // + 4 pixels
+      b1.v[0] = lds_read_tr16(pb + a.Wp * 8); b1.v[1] = lds_read_tr16(pb + a.Wp * 8 + 64);
+      acc[0][0] = mfma32_bf16(fa0, b0.h, acc[0][0]);
+      acc[1][0] = mfma32_bf16(fa1, b0.h, acc[1][0]);
+      acc[0][1] = mfma32_bf16(fa0, b1.h, acc[0][1]);
+      acc[1][1] = mfma32_bf16(fa1, b1.h, acc[1][1]);
+    }
+  }
+
+  // (8 waves) the odd-k-step waves hand their partial sums to the even ones through LDS ([c][224] f32), which add their own and write the slab
+  auto at = [&](int cb, int ri, int r) { return (cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 224 + (r0 + ri) * 32 + (lane & 31); };
+  if constexpr (NW == 4) {
+    float* slab = a.ws + (size_t)blockIdx.x * SW_OUT;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+        if (ri == 0 || two)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slab[at(cb, ri, r)] = acc[cb][ri][r];
+    return;
+  }
+  lds_barrier();
+  float* fold = (float*)smem;
+  if (kh == 1) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+        if (ri == 0 || two)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) fold[at(cb, ri, r)] = acc[cb][ri][r];
+  }
+  lds_barrier();
+  if (kh == 0) {
+    float* slab = a.ws + (size_t)blockIdx.x * SW_OUT;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ri = 0; ri < 2; ++ri)
+        if (ri == 0 || two)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slab[at(cb, ri, r)] = acc[cb][ri][r] + fold[at(cb, ri, r)];
+  }
+}
+
+// dw[c][r][s][ch] (f32 [64][7][7][3]) += sum over slabs of ws[b][c][r * 32 + s * 4 + ch]; grid (37, 8): a slice of the slabs per workgroup, one float
+// atomic per output and slice
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nslabs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * 147) return;
+  const int ch = i % 3, sx = (i / 3) % 7, r = (i / 21) % 7, c = i / 147;
+  const int src = c * 224 + r * 32 + sx * 4 + ch;
+  const int per = (nslabs + gridDim.y - 1) / gridDim.y;
+  int b0 = blockIdx.y * per, b1 = b0 + per;
+  if (b1 > nslabs) b1 = nslabs;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
+    s0 += ws[(size_t)b * SW_OUT + src]; s1 += ws[(size_t)(b + 1) * SW_OUT + src]; s2 += ws[(size_t)(b + 2) * SW_OUT + src]; s3 += ws[(size_t)(b + 3) * SW_OUT + src];
+  }
+  for (; b < b1; ++b) s0 += ws[(size_t)b * SW_OUT + src];
+  if (b0 < b1) atomic_add_f32(dw + i, (s0 + s1) + (s2 + s3));
+}
+
+}  // namespace
+
+int clite::launch_stem_wgrad_patch(const void* dy, const void* xpad, int N, int Hp, int Wp, int Ho, int Wo, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+#ifdef CLITE_NO_PATCH
+  return WIDE_NOT_TAKEN;
+#endif
+  if (Wo % 16 || 2 * Wo > SW_MAXPIX || 10 * Wp * 8 + 128 > SW_XB || Hp < 2 * (Ho - 1) + 7 || Wp < 2 * (Wo - 1) + 8) return WIDE_NOT_TAKEN;
+  constexpr int WGS = (CLITE_STEM_WGRAD_NW == 8 ? 1 : 3) * CLITE_PATCH_WGS;
+  if (!ws || ws_bytes < (size_t)WGS * SW_OUT * sizeof(float)) return WIDE_NOT_TAKEN;
+  if ((size_t)N * Ho * Wo * PIXB >= 0xF0000000ull || (size_t)N * Hp * Wp * 8 >= 0xF0000000ull) return WIDE_NOT_TAKEN;
+  StemWgradArgs a;
+  a.dy = dy; a.x = xpad;
+  a.dybytes = (uint32_t)((size_t)N * Ho * Wo * PIXB); a.xbytes = (uint32_t)((size_t)N * Hp * Wp * 8);
+  a.N = N; a.Hp = Hp; a.Wp = Wp; a.Ho = Ho; a.Wo = Wo;
+  a.strips_per_img = (Ho + 1) / 2;
+  a.nstrips = N * a.strips_per_img;
+  a.ws = (float*)ws;
+  const int grid = a.nstrips < WGS ? a.nstrips : WGS;
+  const int per = (a.nstrips + grid - 1) / grid;
+  const int g2 = (a.nstrips + per - 1) / per;
+  hipLaunchKernelGGL(stem_wgrad_patch_kernel<CLITE_STEM_WGRAD_NW>, dim3(g2), dim3(CLITE_STEM_WGRAD_NW * 64), 0, st, a, per);
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 147 + 255) / 256, 8), dim3(256), 0, st, (const float*)ws, dw, g2);
+  return (int)hipGetLastError();
+}
+
+size_t clite::conv3x3_wgrad_patch_workspace() {          // the larger of its two users' needs (the stem's weight gradient runs three workgroups per CU)
+  const size_t a = (size_t)CLITE_PATCH_WGS * WG_OUT * sizeof(float), b = (size_t)3 * CLITE_PATCH_WGS * 64 * 224 * sizeof(float);
+  return a > b ? a : b;
+}
 
 int clite::launch_conv3x3_wgrad_patch(const void* dy, const void* x, const clite_conv& c, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
 #ifdef CLITE_NO_PATCH

@@ -780,6 +780,16 @@ extern "C" int clite_conv_wgrad_patch(const void* dy, const void* x, const clite
   return rc == WIDE_NOT_TAKEN ? 1 : rc;
 }
 
+// The stem's weight gradient on the patch-resident kernel (conv_patch.hip), straight into the [64][7][7][3] f32 gradient (+=). Returns 1 when it does
+// not cover the problem (f32, shape, workspace, deterministic mode, a forced tile policy): the caller then takes clite_stem_wgrad + clite_stem_unpack_grad.
+extern "C" int clite_stem_wgrad_patch(const void* dy, const void* xpad, int dtype, int N, int Hp, int Wp, int Ho, int Wo, float* dw, void* ws, uint64_t ws_bytes,
+                                      void* stream) {
+  if (check_stem(dtype, N, Hp, Wp, Ho, Wo) || !dy || !xpad || !dw) return -1;
+  if (dtype != CLITE_BF16 || deterministic() || tile_policy_value() != 0) return 1;
+  const int rc = launch_stem_wgrad_patch(dy, xpad, N, Hp, Wp, Ho, Wo, dw, ws, (size_t)ws_bytes, (hipStream_t)stream);
+  return rc == WIDE_NOT_TAKEN ? 1 : rc;
+}
+
 extern "C" int clite_stem_fwd(const void* xpad, const void* wv, int dtype, int N, int Hp, int Wp, int Ho, int Wo, const clite_epilogue* ep, void* stream) {
   if (check_stem(dtype, N, Hp, Wp, Ho, Wo) || check_ep(ep, 64)) return -1;
   return dtype == CLITE_BF16 ? stem_fwd<bf16>(xpad, wv, N, Hp, Wp, Ho, Wo, ep, (hipStream_t)stream)

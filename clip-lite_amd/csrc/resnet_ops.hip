@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* dout, T* dx, 
 template <typename T> DEV void round_store_type(float (&v)[8]) { if constexpr (sizeof(T) == 2) round8_bf16(v); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void stem_bn_pool_fwd_kernel(clite_bn p, const T* __restrict__ y, T* __restrict__ out, uint8_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void stem_bn_pool_fwd_kernel(clite_bn p, const T* __restrict__ y, T* __restrict__ out, uint8_t* __restrict__ idx, T* __restrict__ ymax,
                                                                int N, int H, int W, int Ho, int Wo, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
@@ -547,10 +547,10 @@ __global__ __launch_bounds__(256) void stem_bn_pool_fwd_kernel(clite_bn p, const
         const int hc = hi < 0 ? 0 : (hi >= H ? H - 1 : hi), wc = wi < 0 ? 0 : (wi >= W ? W - 1 : wi);
         load8(y + (((size_t)n * H + hc) * W + wc) * p.C + c0, tap[r * 3 + s]);
       }
-    float best[8];
+    float best[8], ybest[8];
     int bi[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; }
+    for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = -1; ybest[e] = 0.f; }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       float v[8];
@@ -559,9 +559,19 @@ __global__ __launch_bounds__(256) void stem_bn_pool_fwd_kernel(clite_bn p, const
       round_store_type<T>(v);                      // a0 as bn_apply would have stored it
 #pragma unroll
       for (int e = 0; e < 8; ++e)
-        if (ok[t] && (v[e] > best[e] || bi[e] < 0 || v[e] != v[e])) { best[e] = v[e]; bi[e] = t; }   // first maximum in scan order wins; a NaN wins (torch max_pool2d propagates it)
+        if (ok[t] && (v[e] > best[e] || bi[e] < 0 || v[e] != v[e])) { best[e] = v[e]; bi[e] = t; ybest[e] = tap[t][e]; }   // first maximum in scan order wins; a NaN wins (torch max_pool2d propagates it)
     }
     store8(out + (size_t)pix * p.C + c0, best);
+    // clite_stem_bn_pool_fwd_ex: the BatchNorm INPUT at the argmax (an exact copy of that y element) and the packed relu' bits of the pooled output -
+    // what lets the kernel that writes the pooled gradient accumulate this BatchNorm's two backward reductions in its epilogue (clite_epilogue.bn_y
+    // := ymax, relu_bits), instead of a pass over the 4 x larger un-pooled tensors
+    if (ymax) store8(ymax + (size_t)pix * p.C + c0, ybest);
+    if (p.relu_bits) {
+      uint32_t b = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b |= (best[e] > 0.f ? 1u : 0u) << e;
+      p.relu_bits[((size_t)pix * p.C + c0) >> 3] = (uint8_t)b;
+    }
     uint32_t lo = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     uint32_t hi4 = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
     *(u32x2*)(idx + (size_t)pix * p.C + c0) = u32x2{lo, hi4};
@@ -690,27 +700,47 @@ __global__ __launch_bounds__(256) void stem_bn_pool_bwd_apply_kernel(clite_bn p,
   }
 }
 
-// image f32 NCHW [N][3][H][W] -> T [N][H+2*pad][Wp][4], zero padded (channel 3 = 0)
+// image f32 NCHW [N][3][H][W] -> T [N][H+2*pad][Wp][4], zero padded (channel 3 = 0). One wave per output row (n, hp), a lane per group of 4 INPUT
+// columns: three 16-byte loads (one per channel plane) and four 8-byte stores, 32-bit index arithmetic and one division per wave (round 3's form
+// spent its 125 us on three 64-bit divisions per pixel; this one streams at the HBM rate).
 template <typename T>
-__global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* img, T* out, int N, int H, int W, int pad, int Hp, int Wp) {
-  size_t total = (size_t)N * Hp * Wp;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    int wp = (int)(i % Wp);
-    int hp = (int)((i / Wp) % Hp);
-    int n = (int)(i / ((size_t)Wp * Hp));
-    int h = hp - pad, w = wp - pad;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+__global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* __restrict__ img, T* __restrict__ out, int N, int H, int W, int pad, int Hp, int Wp) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);          // (n, hp)
+  if (row >= N * Hp) return;
+  const int lane = threadIdx.x & 63;
+  const int n = row / Hp, hp = row - n * Hp, h = hp - pad;
+  const bool hv = (unsigned)h < (unsigned)H;
+  const size_t plane = (size_t)H * W;
+  const float* src = img + (size_t)n * 3 * plane + (size_t)(hv ? h : 0) * W;
+  T* dst = out + (size_t)row * Wp * 4;
+  const int g0 = -((pad + 3) >> 2);                             // first group of 4 input columns that reaches output column 0
+  const bool vec = (W & 3) == 0 && (((uintptr_t)img) & 15) == 0;
+  for (int g = g0 + lane; g * 4 + pad < Wp; g += 64) {
+    const int w0 = g * 4;
+    float v[3][4];
+    if (hv && vec && w0 >= 0 && w0 + 3 < W) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = img[(((size_t)n * 3 + c) * H + h) * W + w];
-    }
-    if constexpr (sizeof(T) == 2) {
-      union { bf16 e[4]; u32x2 u; } pk;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) pk.e[c] = f2bf(v[c]);
-      *(u32x2*)(out + i * 4) = pk.u;
+      for (int c = 0; c < 3; ++c) {
+        const f32x4 q = *(const f32x4*)(src + c * plane + w0);
+        v[c][0] = q[0]; v[c][1] = q[1]; v[c][2] = q[2]; v[c][3] = q[3];
+      }
     } else {
-      *(f32x4*)(out + i * 4) = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] = (hv && (unsigned)(w0 + e) < (unsigned)W) ? src[c * plane + w0 + e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int wp = w0 + e + pad;
+      if ((unsigned)wp >= (unsigned)Wp) continue;
+      if constexpr (sizeof(T) == 2) {
+        union { bf16 x[4]; u32x2 u; } pk;
+        pk.x[0] = f2bf(v[0][e]); pk.x[1] = f2bf(v[1][e]); pk.x[2] = f2bf(v[2][e]); pk.x[3] = f2bf(0.f);
+        *(u32x2*)(dst + (size_t)wp * 4) = pk.u;
+      } else {
+        *(f32x4*)(dst + (size_t)wp * 4) = f32x4{v[0][e], v[1][e], v[2][e], 0.f};
+      }
     }
   }
 }
@@ -860,16 +890,20 @@ extern "C" int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t
   return (int)hipGetLastError();
 }
 
-extern "C" int clite_stem_bn_pool_fwd(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, int N, int H, int W, void* stream) {
+extern "C" int clite_stem_bn_pool_fwd_ex(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, void* ymax, int N, int H, int W, void* stream) {
   if (!p || !y || !pooled || !idx || N <= 0 || p->M != N * H * W || !bn_ok(p->M, p->C) || p->replicas < 1) return -1;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   int rpb;
   int grid = bn_grid(N * Ho * Wo, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(stem_bn_pool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (bf16*)pooled, idx, N, H, W, Ho, Wo, rpb),
-           hipLaunchKernelGGL(stem_bn_pool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, *p, (const float*)y, (float*)pooled, idx, N, H, W, Ho, Wo, rpb));
+           hipLaunchKernelGGL(stem_bn_pool_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (bf16*)pooled, idx, (bf16*)ymax, N, H, W, Ho, Wo, rpb),
+           hipLaunchKernelGGL(stem_bn_pool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, *p, (const float*)y, (float*)pooled, idx, (float*)ymax, N, H, W, Ho, Wo, rpb));
   return (int)hipGetLastError();
+}
+extern "C" int clite_stem_bn_pool_fwd(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, int N, int H, int W, void* stream) {
+  if (p && p->relu_bits) return -1;          // (the _ex entry point writes them)
+  return clite_stem_bn_pool_fwd_ex(p, dtype, y, pooled, idx, nullptr, N, H, W, stream);
 }
 
 extern "C" int clite_stem_bn_pool_bwd(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, float* dstats, void* dy,
@@ -886,6 +920,19 @@ extern "C" int clite_stem_bn_pool_bwd(const clite_bn* p, int dtype, const void* 
   DISPATCH(dtype,
            hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<bf16>, dim3(grid_a), dim3(256), 0, st, *p, (const bf16*)dpool, idx, (const bf16*)y, (const float*)dstats, (bf16*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a),
            hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<float>, dim3(grid_a), dim3(256), 0, st, *p, (const float*)dpool, idx, (const float*)y, (const float*)dstats, (float*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a));
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_stem_bn_pool_bwd_apply(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, void* dy,
+                                            float* dgamma, float* dbeta, int N, int H, int W, void* stream) {
+  if (!p || !dpool || !idx || !y || !dstats || !dy || N <= 0 || p->M != N * H * W || !bn_ok(p->M, p->C) || p->replicas < 1) return -1;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  int rpb_a;
+  const int grid_a = bn_grid(p->M, p->C, &rpb_a);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<bf16>, dim3(grid_a), dim3(256), 0, st, *p, (const bf16*)dpool, idx, (const bf16*)y, dstats, (bf16*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a),
+           hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<float>, dim3(grid_a), dim3(256), 0, st, *p, (const float*)dpool, idx, (const float*)y, dstats, (float*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a));
   return (int)hipGetLastError();
 }
 
@@ -911,7 +958,8 @@ extern "C" int clite_avgpool_bwd(int dtype, const void* dout, void* dx, int N, i
 
 extern "C" int clite_image_to_nhwc4(int dtype, const float* img, void* out, int N, int H, int W, int pad, int Hp, int Wp, void* stream) {
   if (N <= 0 || Hp < H + 2 * pad || Wp < W + 2 * pad) return -1;
-  int grid = ew_grid((size_t)N * Hp * Wp);
+  if ((size_t)N * Hp >= ((size_t)1 << 31)) return -1;
+  int grid = (N * Hp + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
            hipLaunchKernelGGL(image_to_nhwc4_kernel<bf16>, dim3(grid), dim3(256), 0, st, img, (bf16*)out, N, H, W, pad, Hp, Wp),

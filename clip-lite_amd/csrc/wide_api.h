@@ -23,6 +23,8 @@ int launch_conv3x3_patch(const void* x, const void* w, const clite_conv& c, cons
 // ... and its weight gradient (dw f32 [K][3][3][C] += ...) through a workspace of conv3x3_wgrad_patch_workspace() bytes (per-workgroup partial sums)
 size_t conv3x3_wgrad_patch_workspace();
 int launch_conv3x3_wgrad_patch(const void* dy, const void* x, const clite_conv& c, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+// the stem's weight gradient on the same scheme (dw f32 [64][7][7][3] +=; the same workspace serves)
+int launch_stem_wgrad_patch(const void* dy, const void* xpad, int N, int Hp, int Wp, int Ho, int Wo, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // the tile policy set by clite_set_tile_policy (gemm_wide.hip): 0 = automatic; the forced forms keep every launch on the kernel family they name
 int tile_policy_value();
 

@@ -96,6 +96,7 @@ _SIGNATURES = {
     "clite_wgrad_group_workspace": [_I, C.c_int64, _V],
     "clite_stem_fwd": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
     "clite_stem_wgrad": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
+    "clite_stem_wgrad_patch": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V, _U64, _V],
     "clite_stem_pack": [_V, _V, _I, _V],
     "clite_stem_unpack_grad": [_V, _V, _V],
     "clite_bn_apply": [_V, _I, _V, _V, _V, _V],
@@ -106,6 +107,8 @@ _SIGNATURES = {
     "clite_maxpool3x3s2_bwd": [_I, _V, _V, _V, _I, _I, _I, _I, _V],
     "clite_stem_bn_pool_fwd": [_V, _I, _V, _V, _V, _I, _I, _I, _V],
     "clite_stem_bn_pool_bwd": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V],
+    "clite_stem_bn_pool_fwd_ex": [_V, _I, _V, _V, _V, _V, _I, _I, _I, _V],
+    "clite_stem_bn_pool_bwd_apply": [_V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _I, _V],
     "clite_avgpool_fwd": [_I, _V, _V, _I, _I, _I, _V],
     "clite_avgpool_bwd": [_I, _V, _V, _I, _I, _I, _V],
     "clite_image_to_nhwc4": [_I, _V, _V, _I, _I, _I, _I, _I, _I, _V],
@@ -569,6 +572,19 @@ def stem_wgrad(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dwv):
     check(lib().clite_stem_wgrad(p(dy), p(xpad), dt, N, Hp, Wp, Ho, Wo, p(dwv), stream_ptr(dy)), "stem_wgrad")
 
 
+def stem_wgrad_patch(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dw):
+    """The stem's weight gradient on the patch-resident kernel, += into the f32 [64][7][7][3] gradient. False: not covered (the caller takes
+    stem_wgrad + stem_unpack_grad). The device's patch workspace must exist (patch_workspace: DeviceRuntime creates it)."""
+    ws = _patch_ws.get(dy.device)
+    if ws is None:
+        return False
+    rc = lib().clite_stem_wgrad_patch(p(dy), p(xpad), dt, N, Hp, Wp, Ho, Wo, p(dw), p(ws), ws.numel(), stream_ptr(dy))
+    if rc == 1:
+        return False
+    check(rc, "stem_wgrad_patch")
+    return True
+
+
 def stem_pack(dt, w, wv):
     check(lib().clite_stem_pack(p(w), p(wv), dt, stream_ptr(w)), "stem_pack")
 
@@ -633,8 +649,14 @@ def maxpool_bwd(dt, dout, idx, dx, N, H, W, Cc):
     check(lib().clite_maxpool3x3s2_bwd(dt, p(dout), p(idx), p(dx), N, H, W, Cc, stream_ptr(dout)), "maxpool_bwd")
 
 
-def stem_bn_pool_fwd(dt, bn, y, pooled, idx, N, H, W):
-    check(lib().clite_stem_bn_pool_fwd(C.byref(bn), dt, p(y), p(pooled), p(idx), N, H, W, stream_ptr(y)), "stem_bn_pool_fwd")
+def stem_bn_pool_fwd(dt, bn, y, pooled, idx, N, H, W, ymax=None):
+    """ymax (and bn.relu_bits): the pooled-size operands of the backward reductions (include/clite.h: clite_stem_bn_pool_fwd_ex)."""
+    check(lib().clite_stem_bn_pool_fwd_ex(C.byref(bn), dt, p(y), p(pooled), p(idx), p(ymax), N, H, W, stream_ptr(y)), "stem_bn_pool_fwd")
+
+
+def stem_bn_pool_bwd_apply(dt, bn, dpool, idx, y, dstats, dy, dgamma, dbeta, N, H, W):
+    check(lib().clite_stem_bn_pool_bwd_apply(C.byref(bn), dt, p(dpool), p(idx), p(y), p(dstats.t), p(dy), p(dgamma), p(dbeta), N, H, W, stream_ptr(y)),
+          "stem_bn_pool_bwd_apply")
 
 
 def stem_bn_pool_bwd(dt, bn, dpool, idx, y, dstats, dy, dgamma, dbeta, N, H, W):

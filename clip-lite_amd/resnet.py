@@ -210,8 +210,13 @@ def resnet_forward(rt, net, image, training, staged=None):
     Hq, Wq = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
     p0 = _alloc(rt, N * Hq * Wq, 64)
     idx = torch.empty(N * Hq * Wq, 64, device=rt.device, dtype=torch.uint8)
-    hip.stem_bn_pool_fwd(dt, _bn_desc(rt, net.bn1, N * Ho * Wo, st0, True, training), y0, p0, idx, N, Ho, Wo)
-    ctx["stem"] = (xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq)
+    # pooled-size operands of bn1's backward reductions (hip.stem_bn_pool_fwd / DeviceRuntime.stem_pooled_stats): y0 at each window's argmax and the
+    # relu' bits of the pooled output, so that layer1's first block accumulates the two sums in the epilogue that writes the pooled gradient
+    pooled_stats = training and rt.stem_pooled_stats and rt.lowp and rt.fuse_bn_backward and rt.transposed_dgrad
+    ymax = _alloc(rt, N * Hq * Wq, 64) if pooled_stats else None
+    sbits = _relu_bits(rt, N * Hq * Wq, 64, True) if pooled_stats else None
+    hip.stem_bn_pool_fwd(dt, _bn_desc(rt, net.bn1, N * Ho * Wo, st0, True, training, bits=sbits), y0, p0, idx, N, Ho, Wo, ymax=ymax)
+    ctx["stem"] = (xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq, ymax, sbits)
 
     # fp8 forward (BASELINE configs[4]; fp8.py): the eligible convs read e4m3 copies that the producing bn_apply wrote beside its bf16 output
     from .fp8 import forward_state
@@ -420,13 +425,27 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                                    hip.epilogue(dx, Cin, residual=dsc, residual_subsample=2, relu_bits=pl.bits, mask_after_residual=True, colsum=pre,
                                                 bn=(pl.y, pl.stats, pl.y.shape[0])), wt=wt)
                 else:
-                    hip.conv_dgrad(dy, wd, u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None), wt=wt)
+                    # the network's first block: its input gradient is the pooled gradient of the stem. With the stem's pooled-size operands
+                    # (resnet_forward: ymax, sbits) the LAST launch that writes it also masks it by relu'(pooled output) and accumulates bn1's two
+                    # backward reductions (the BatchNorm-backward epilogue with bn_y := ymax): stem_pre replaces stem_bn_pool_bwd's reduction pass
+                    # over the 4 x larger un-pooled tensors
+                    ymax, sbits = ctx["stem"][10:12]
+                    stem_ep = None
+                    if bi == 0 and ymax is not None and wt and (ud is None or (ud.cv.stride == 1 and _wd(rt, ud.conv)[1])):
+                        ctx["stem_pre"] = rt.new_stats(Cin, ctx["stem"][5].shape[0])
+                        rows0 = ctx["stem"][5].shape[0]          # N * Ho * Wo of the un-pooled tensor: the count behind bn1's mean
+                        stem_ep = lambda res: hip.epilogue(dx, Cin, residual=res, relu_bits=sbits, mask_after_residual=True, colsum=ctx["stem_pre"],
+                                                           bn=(ymax, ctx["stem"][6], rows0))
+                    if stem_ep is not None and ud is None:
+                        hip.conv_dgrad(dy, wd, u.cv, stem_ep(dz), wt=wt)
+                    else:
+                        hip.conv_dgrad(dy, wd, u.cv, hip.epilogue(dx, Cin, residual=dz if identity else None), wt=wt)
                     if ud is not None:
                         if ud.conv.weight.requires_grad:
                             wgrad(dyd, ud)
                         # shortcut branch accumulated in place (dx += dgrad); a strided 1x1 shortcut takes the scatter-add path of clite_conv_dgrad
                         wdd, wtd = _wd(rt, ud.conv)
-                        hip.conv_dgrad(dyd, wdd, ud.cv, hip.epilogue(dx, Cin, residual=dx), wt=wtd)
+                        hip.conv_dgrad(dyd, wdd, ud.cv, stem_ep(dx) if stem_ep is not None else hip.epilogue(dx, Cin, residual=dx), wt=wtd)
                 dout = dx
         if defer is None:
             rt.grads_ready(blocks[bi])
@@ -442,17 +461,24 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         return
     if f8 is not None:
         f8.end_backward()
-    xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq = ctx["stem"]
+    xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq = ctx["stem"][:10]
     # max-pool backward + ReLU mask + BatchNorm backward straight from (dpool, idx, y0): neither the un-pooled gradient nor the mask is stored
     bn1 = net.bn1
     dst0 = rt.new_stats(64, N * Ho * Wo)
     dy0 = _alloc(rt, N * Ho * Wo, 64)
     desc0 = hip.bn_desc(N * Ho * Wo, 64, st0, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, True, False, bn1.momentum, bn1.eps, False,
                         centered=rt.precise_bn)
-    hip.stem_bn_pool_bwd(dt, desc0, dout, idx, y0, dst0, dy0, rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None,
-                         rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None, N, Ho, Wo)
+    stem_pre = ctx.pop("stem_pre", None)
+    if stem_pre is not None:          # the reductions came out of the epilogue that wrote `dout` (already masked by relu'(pooled output))
+        hip.stem_bn_pool_bwd_apply(dt, desc0, dout, idx, y0, stem_pre, dy0, rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None,
+                                   rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None, N, Ho, Wo)
+    else:
+        hip.stem_bn_pool_bwd(dt, desc0, dout, idx, y0, dst0, dy0, rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None,
+                             rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None, N, Ho, Wo)
     if net.conv1.weight.requires_grad:
         def stem_wgrad(dy0=dy0):
+            if rt.stem_wgrad_patch and rt.lowp and hip.stem_wgrad_patch(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, rt.arena.g(net.conv1.weight)):
+                return
             dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)
             hip.stem_wgrad(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, dwv)
             hip.stem_unpack_grad(dwv, rt.arena.g(net.conv1.weight))

@@ -243,6 +243,11 @@ int clite_fp8_quantize_group(const void* base, const clite_fp8_item* items_dev, 
  * as [64][7][8][4] (clite_stem_pack from f32 [64][7][7][3]); clite_stem_unpack_grad folds the packed gradient back (+=). */
 int clite_stem_fwd(const void* xpad, const void* wv, int dtype, int N, int Hp, int Wp, int Ho, int Wo, const clite_epilogue* ep, void* stream);
 int clite_stem_wgrad(const void* dy, const void* xpad, int dtype, int N, int Hp, int Wp, int Ho, int Wo, float* dwv, void* stream);
+/* ABI v11. The same weight gradient on a patch-resident kernel (bf16, Wo % 16 == 0, Wo <= 128, Wp <= 254): dw f32 [64][7][7][3] += directly (no
+ * packed intermediate), through clite_conv_wgrad_patch_workspace() bytes of scratch. Returns 1 (nothing launched) when the problem is not covered -
+ * the caller then takes clite_stem_wgrad + clite_stem_unpack_grad - or in the deterministic mode / under a forced tile policy. */
+int clite_stem_wgrad_patch(const void* dy, const void* xpad, int dtype, int N, int Hp, int Wp, int Ho, int Wo, float* dw, void* ws, uint64_t ws_bytes,
+                           void* stream);
 int clite_stem_pack(const float* w, void* wv, int dtype, void* stream);
 int clite_stem_unpack_grad(const float* dwv, float* dw, void* stream);
 
@@ -312,6 +317,16 @@ int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t* idx, void
 int clite_stem_bn_pool_fwd(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, int N, int H, int W, void* stream);
 int clite_stem_bn_pool_bwd(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, float* dstats, void* dy,
                            float* dgamma, float* dbeta, int N, int H, int W, void* stream);
+/* ABI v11. The forward pass that also leaves what the backward reductions of this BatchNorm need in POOLED size: ymax [N][Ho][Wo][C] (optional) = the
+ * BatchNorm input y at each window's argmax (an exact copy), and p->relu_bits (optional) = the packed relu' bits of the pooled output. Every other
+ * position of a window receives no gradient, so sum dz and sum dz (y - mean) over the un-pooled tensor equal the same sums over (pooled gradient *
+ * relu', ymax): the kernel that writes the pooled gradient accumulates them in its epilogue (clite_epilogue.bn_y = ymax, relu_bits,
+ * mask_after_residual, colsum; bn_inv_count = 1 / (N H W) of the UN-pooled tensor) and clite_stem_bn_pool_bwd_apply takes them as `dstats` -
+ * clite_stem_bn_pool_bwd's second half alone, without the pass over y (205 MB at batch 128) that produced them. (The sums skip one rounding of the
+ * unfused sequence - the un-pooled gradient of a pixel that is the argmax of several windows was rounded to the storage type before it was summed.) */
+int clite_stem_bn_pool_fwd_ex(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, void* ymax, int N, int H, int W, void* stream);
+int clite_stem_bn_pool_bwd_apply(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, void* dy,
+                                 float* dgamma, float* dbeta, int N, int H, int W, void* stream);
 /* nn.AdaptiveAvgPool2d((1,1)) + view (reference encoder.py:63-65): [N][HW][C] -> [N][C] */
 int clite_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream);
 int clite_avgpool_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, void* stream);

@@ -162,6 +162,34 @@ def test_stem_7x7(dt):
     assert _rel(dw, wr.grad.permute(0, 2, 3, 1)) < 2e-3
 
 
+@pytest.mark.policy_independent
+@pytest.mark.parametrize("N,H,W", [(16, 224, 224), (3, 70, 96)])
+def test_stem_weight_gradient_patch_resident(N, H, W):
+    """clite_stem_wgrad_patch (ABI v11) at the benchmark's image size and on an image with an odd number of output rows, against torch's f32 weight
+    gradient and clite_stem_wgrad; it accumulates into a non-zero gradient."""
+    hip = _hip()
+    hip.set_tile_policy(0)          # (a forced tile policy makes the entry point decline)
+    g = torch.Generator(device="cuda").manual_seed(H + W)
+    img = torch.randn(N, 3, H, W, device="cuda", generator=g)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = H + 6, W + 8
+    xpad = torch.empty(N, Hp, Wp, 4, device="cuda", dtype=torch.bfloat16)
+    hip.image_to_nhwc4(BF16, img, xpad, N, H, W, 3, Hp, Wp)
+    dy = (torch.randn(N, Ho, Wo, 64, device="cuda", generator=g) * 0.1).bfloat16()
+    hip.patch_workspace(torch.device("cuda", 0))
+    dw = torch.full((64, 7, 7, 3), 0.25, device="cuda")
+    assert hip.stem_wgrad_patch(BF16, dy, xpad, N, Hp, Wp, Ho, Wo, dw)
+    wr = torch.zeros(64, 3, 7, 7, device="cuda", requires_grad=True)
+    with torch.backends.cudnn.flags(enabled=False):
+        F.conv2d(img.bfloat16().float(), wr, stride=2, padding=3).backward(dy.float().permute(0, 3, 1, 2))
+    assert _rel(dw - 0.25, wr.grad.permute(0, 2, 3, 1)) < 2e-3
+    dwv = torch.zeros(64, 7, 8, 4, device="cuda")
+    hip.stem_wgrad(BF16, dy, xpad, N, Hp, Wp, Ho, Wo, dwv)
+    dw2 = torch.zeros(64, 7, 7, 3, device="cuda")
+    hip.stem_unpack_grad(dwv, dw2)
+    assert _rel(dw - 0.25, dw2) < 2e-3
+
+
 @pytest.mark.parametrize("M,N,K", [(200, 136, 104), (3840, 2304, 768), (1000, 64, 72)])
 def test_plain_epilogue_bf16_store_bias_and_column_statistics(M, N, K):
     """The branch-free plain epilogue instantiation (bf16 store of alpha*acc + bias, column sums of what was stored): every conv forward

@@ -240,6 +240,40 @@ def test_bf16_mode_tracks_bf16_emulated_oracle_resnet18():
     assert c_he >= 0.93 and c_he >= c_e32 - 0.02
 
 
+@pytest.mark.parametrize("visual,idim", [("resnet18", 512), ("resnet50", 2048)])
+@pytest.mark.usefixtures("deterministic_reductions")
+def test_stem_reductions_from_pooled_operands_match_the_unpooled_pass(visual, idim):
+    """DeviceRuntime.stem_pooled_stats (round 4, bf16): bn1's two backward reductions come out of the epilogue of layer1's first input gradient
+    (bn_y := the BatchNorm input at each pooling window's argmax, packed relu' bits of the pooled output) instead of stem_bn_pool_bwd's pass over the
+    un-pooled tensors - with an identity first block (ResNet-18: one launch, residual = the block's masked output gradient) and with a projection
+    shortcut (ResNet-50: the in-place second launch carries the epilogue). Same weights and batch, deterministic reductions: every gradient outside
+    the stem is BIT-identical (nothing else reads the now-masked pooled gradient), the stem's three (conv1.weight, bn1.weight, bn1.bias) agree to
+    the one bf16 rounding the pooled form skips (5e-2 of the largest element: the sums cancel heavily)."""
+    B, S = 8, 64
+    state = default_init_state(visual, "sbert", 0)
+    batch = {"image": det_tensor("stemimg", (B, 3, S, S), "normal").cuda(), "caption_encodings": det_tensor("stemcap", (B, 768), "normal").cuda()}
+    u1, u2 = det_tensor("u1s", (B, idim), "uniform").cuda(), det_tensor("u2s", (B, 768), "uniform").cuda()
+    grads = []
+    for pooled in (False, True):
+        M = build(visual, "sbert", 0, True, idim, state)
+        M.runtime.stem_pooled_stats = pooled
+        M.loss.set_prior_noise(u1, u2)
+        out = M(batch)
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        grads.append(({k: p.grad.detach().float().clone() for k, p in M.named_parameters()}, out["loss"].item()))
+    (g0, l0), (g1, l1) = grads
+    assert l0 == l1
+    stem = ("image_encoder.img_encoder.conv1.weight", "image_encoder.img_encoder.bn1.weight", "image_encoder.img_encoder.bn1.bias")
+    assert all(k in g0 for k in stem), [k for k in g0 if "conv1" in k or "bn1" in k][:6]
+    for k in g0:
+        if k in stem:
+            assert (g0[k] - g1[k]).abs().max().item() <= 5e-2 * g0[k].abs().max().item(), k          # (observed: 2.1e-2 on bn1.bias of the ResNet-50 case - a sum of 8192 signed terms per channel that largely cancel)
+            assert not torch.equal(g0[k], g1[k]) or k.endswith("bias")          # the other path really ran
+        else:
+            assert torch.equal(g0[k], g1[k]), k
+
+
 def test_bf16_mode_resnet50_bert_forward():
     """ResNet-50 + BERT in bf16 at a test-sized batch: backward is chaotic under bf16 at random init (the emulated oracle's
     gradients have cosine ~0.1 with fp32 here), so only the forward is compared. The yardstick is what bf16 storage alone does to

@@ -295,6 +295,43 @@ def test_stem_conv7x7(dtype):
 
 
 @pytest.mark.policy_independent
+@pytest.mark.parametrize("N,H,W,extra_rows", [(2, 10, 32, 0), (3, 7, 64, 2)])
+def test_stem_weight_gradient_patch_resident(N, H, W, extra_rows):
+    """clite_stem_wgrad_patch (ABI v11, conv_patch.hip): dw [64][7][7][3] f32 += over strips of two output rows, both operands read from per-strip LDS
+    images by transposed reads (the x patch as the 9 input rows lie in memory), per-workgroup slabs + the reduction that drops the packed layout's
+    padding columns. Against the numpy reference and clite_stem_wgrad + clite_stem_unpack_grad on the same operands; an odd number of output rows
+    (a one-row last strip per image), a padded image taller than the minimum, several strips per workgroup (the simulator build runs 2 workgroups);
+    accumulation into a non-zero dw; the refusals (Wo % 16, f32, workspace too small: return 1, nothing launched)."""
+    assert lib().clite_set_tile_policy(0) == 0
+    rng = np.random.default_rng(H + W)
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    Hp, Wp = H + 6 + extra_rows, W + 6 + 2
+    img = rng.standard_normal((N, 3, H, W), dtype=np.float32)
+    xpad = np.full((N, Hp, Wp, 4), 0x7FC0, np.uint16)          # the padding arrives as NaNs where image_to_nhwc4 does not write: it writes everything
+    assert lib().clite_image_to_nhwc4(BF16, ptr(img), ptr(xpad), N, H, W, 3, Hp, Wp, None) == 0
+    imgr = bf16_round(img)
+    dy, dyb = _prep(rng.standard_normal((N, Ho, Wo, 64), dtype=np.float32), BF16)
+    nb = C.c_uint64(0)
+    assert lib().clite_conv_wgrad_patch_workspace(C.byref(nb)) == 0
+    ws = np.full(nb.value // 4, np.nan, np.float32)          # scratch arrives dirty
+    dw = np.full((64, 7, 7, 3), 0.5, np.float32)
+    L = lib()
+    L.clite_stem_wgrad_patch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    assert L.clite_stem_wgrad_patch(ptr(dyb), ptr(xpad), BF16, N, Hp, Wp, Ho, Wo, ptr(dw), ptr(ws), nb.value, None) == 0
+    ref = conv_wgrad_ref(dy, imgr.transpose(0, 2, 3, 1), (64, 7, 7, 3), 2, 3)
+    _close(dw - 0.5, ref, 2e-3)
+    dwv = np.zeros((64, 7, 8, 4), np.float32)
+    assert L.clite_stem_wgrad(ptr(dyb), ptr(xpad), BF16, N, Hp, Wp, Ho, Wo, ptr(dwv), None) == 0
+    dw2 = np.zeros((64, 7, 7, 3), np.float32)
+    assert L.clite_stem_unpack_grad(ptr(dwv), ptr(dw2), None) == 0
+    _close(dw - 0.5, dw2, 2e-3)
+    assert L.clite_stem_wgrad_patch(ptr(dyb), ptr(xpad), BF16, N, Hp, Wp, Ho, Wo, ptr(dw), ptr(ws), 1024, None) == 1
+    assert L.clite_stem_wgrad_patch(ptr(dyb), ptr(xpad), F32, N, Hp, Wp, Ho, Wo, ptr(dw), ptr(ws), nb.value, None) == 1
+    Wo2 = Wo - 4          # a width that is not a multiple of 16
+    assert L.clite_stem_wgrad_patch(ptr(dyb), ptr(xpad), BF16, N, Hp, Wp, Ho, Wo2, ptr(dw), ptr(ws), nb.value, None) == 1
+
+
+@pytest.mark.policy_independent
 def test_grouped_weight_gradients():
     """clite_wgrad_group: conv weight gradients of all three tile families (<= 64 output channels, <= 64 (r, s, ci) columns, general) and a
     linear weight gradient with a strided operand, as ONE grouped launch set, accumulate (+=) the same values as the per-member entry points
@@ -604,7 +641,7 @@ def test_patch_resident_wgrad3x3_64ch(N, H, W):
     x, xb = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), BF16)
     dy, dyb = _prep(rng.standard_normal((N, H, W, K), dtype=np.float32), BF16)
     nb = C.c_uint64(0)
-    assert lib().clite_conv_wgrad_patch_workspace(C.byref(nb)) == 0 and nb.value == 2 * 9 * 64 * 64 * 4          # the simulator build runs 2 workgroups
+    assert lib().clite_conv_wgrad_patch_workspace(C.byref(nb)) == 0 and nb.value == max(2 * 9 * 64 * 64 * 4, 6 * 64 * 224 * 4)          # the simulator build runs 2 (the stem's kernel 6) workgroups
     ws = np.full(nb.value // 4, np.nan, np.float32)          # scratch arrives dirty
     dw = np.full((K, 3, 3, Cc), 0.5, np.float32)
     lib().clite_conv_wgrad_patch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]

@@ -185,6 +185,66 @@ def test_fused_stem_bn_pool_equals_unfused_sequence(dtype, N, H, W):
     assert L.clite_stem_bn_pool_fwd(C.byref(d), dtype, ptr(yb), ptr(p_f), ptr(i_f), N, H + 1, W, None) == -1     # p->M must be N*H*W
 
 
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_stem_pooled_size_operands_give_the_same_backward_reductions(dtype):
+    """clite_stem_bn_pool_fwd_ex (ABI v11): ymax is an exact copy of the BatchNorm input at each window's argmax and relu_bits the packed sign of the
+    pooled output, with pooled / idx unchanged; the two backward reductions formed over the POOLED positions - sum of dpool * relu' and of
+    dpool * relu' * (ymax - mean), what a BatchNorm-backward epilogue with bn_y := ymax accumulates - equal clite_stem_bn_pool_bwd's over the un-pooled
+    tensor up to the rounding the pooled form skips; clite_stem_bn_pool_bwd_apply on those sums and the MASKED pooled gradient gives the same dy."""
+    from simlib import pack_relu_bits
+    rng = np.random.default_rng(11)
+    N, H, W, Cc, R = 2, 9, 8, 64, 2
+    M = N * H * W
+    y, yb = prep(np.round(rng.standard_normal((M, Cc), dtype=np.float32) * 2) / 2, dtype)
+    gamma = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    stats = np.zeros((R, 3, Cc), np.float32)
+    stats[0, 0], stats[0, 1] = y.sum(0), (y * y).sum(0)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    P = N * Ho * Wo
+    rm, rv = np.zeros(Cc, np.float32), np.ones(Cc, np.float32)
+    L = lib()
+    L.clite_stem_bn_pool_fwd_ex.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.clite_stem_bn_pool_bwd_apply.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_void_p]
+
+    def desc(bits=None):
+        d = Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 0, 0.1, 1e-5, 1, R, 3 * Cc, 0, None, None, None, None, None)
+        d.relu_bits = ptr(bits)
+        return d
+    p0, i0 = outbuf((P, Cc), dtype), np.zeros((P, Cc), np.uint8)
+    assert L.clite_stem_bn_pool_fwd(C.byref(desc()), dtype, ptr(yb), ptr(p0), ptr(i0), N, H, W, None) == 0
+    p1, i1, ymax, bits = outbuf((P, Cc), dtype), np.zeros((P, Cc), np.uint8), outbuf((P, Cc), dtype), np.zeros((P, Cc // 8), np.uint8)
+    assert L.clite_stem_bn_pool_fwd_ex(C.byref(desc(bits)), dtype, ptr(yb), ptr(p1), ptr(i1), ptr(ymax), N, H, W, None) == 0
+    assert np.array_equal(np.asarray(p0), np.asarray(p1)) and np.array_equal(i0, i1)
+    assert np.array_equal(bits, pack_relu_bits(val(p1, dtype)))
+    # ymax against a gather of y at (window origin + tap)
+    y4 = y.reshape(N, H, W, Cc)
+    ref = np.zeros((N, Ho, Wo, Cc), np.float32)
+    t = i1.reshape(N, Ho, Wo, Cc).astype(np.int64)
+    for n in range(N):
+        for ho in range(Ho):
+            for wo in range(Wo):
+                hi, wi = ho * 2 - 1 + t[n, ho, wo] // 3, wo * 2 - 1 + t[n, ho, wo] % 3
+                ref[n, ho, wo] = y4[n, hi, wi, np.arange(Cc)]
+    assert np.array_equal(val(ymax, dtype).reshape(N, Ho, Wo, Cc), ref)
+    assert L.clite_stem_bn_pool_fwd(C.byref(desc(bits)), dtype, ptr(yb), ptr(p1), ptr(i1), N, H, W, None) == -1          # bits: the _ex entry point only
+    # backward: the reference reductions and dy from the fused entry point
+    dpool, dpoolb = prep(rng.standard_normal((P, Cc), dtype=np.float32), dtype)
+    ds_ref = np.zeros((R, 3, Cc), np.float32)
+    dy_ref = outbuf((M, Cc), dtype)
+    assert L.clite_stem_bn_pool_bwd(C.byref(desc()), dtype, ptr(dpoolb), ptr(i1), ptr(yb), ptr(ds_ref), ptr(dy_ref), None, None, N, H, W, None) == 0
+    mask = val(p1, dtype) > 0
+    dzp = dpool * mask
+    mean = y.sum(0) / M
+    ds = np.zeros((R, 3, Cc), np.float32)
+    ds[0, 0], ds[0, 1] = dzp.sum(0), (dzp * (val(ymax, dtype) - mean)).sum(0)
+    _close(ds[0, :2], ds_ref.sum(0)[:2], 2e-2 if dtype == BF16 else 1e-5)          # bf16: the unfused form rounds a pixel's summed gradient before the reductions
+    _, dzpb = prep(dzp, dtype)
+    dy = outbuf((M, Cc), dtype)
+    assert L.clite_stem_bn_pool_bwd_apply(C.byref(desc()), dtype, ptr(dzpb), ptr(i1), ptr(yb), ptr(ds), ptr(dy), None, None, N, H, W, None) == 0
+    _close(val(dy, dtype), val(dy_ref, dtype), 2e-2 if dtype == BF16 else 1e-5)
+
+
 def _ln_ref(x, g, b, eps):
     mean = x.mean(1, keepdims=True); var = x.var(1, keepdims=True)
     xh = (x - mean) / np.sqrt(var + eps)

@@ -1,5 +1,6 @@
 """A/B timing of executor switches on the captured train step: python tools/ab_runtime.py [attr=value ...] [--steps 50]
-Each `attr=value` sets an attribute of the model's DeviceRuntime (fuse_bn_backward, s2_classes, group_wgrad, overlap_wgrad ...) before the
+`text.attr=value` sets an attribute of the BERT module (dropout probabilities), `hip.path=value` one of clip_lite_amd.hip, `step.attr=value` one of the
+TrainStep. Each other `attr=value` sets an attribute of the model's DeviceRuntime (fuse_bn_backward, s2_classes, group_wgrad, overlap_wgrad ...) before the
 step is captured; prints ms/step (HIP events around `steps` replays). The baseline is the same command without arguments."""
 import argparse
 import contextlib
@@ -37,7 +38,10 @@ def main():
         for name in parents:
             obj = getattr(obj, name)
         setattr(obj, leaf, type(getattr(obj, leaf))(int(v)))
-    for s in [x for x in args.sets if not x.startswith("step.") and not x.startswith("hip.")]:
+    for s in [x for x in args.sets if x.startswith("text.")]:        # e.g. text.hidden_dropout_prob=0 (a sensitivity probe: what the dropout machinery costs)
+        k, v = s[5:].split("=")
+        setattr(model.text_encoder.strans, k, float(v))
+    for s in [x for x in args.sets if not x.startswith("step.") and not x.startswith("hip.") and not x.startswith("text.")]:
         k, v = s.split("=")
         old = getattr(rt, k)
         setattr(rt, k, type(old)(int(v)) if isinstance(old, (bool, int)) else type(old)(v))

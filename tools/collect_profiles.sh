@@ -15,7 +15,7 @@ cp $O/r4_hbm_traffic.json profiles/r4_hbm_traffic.json
 python bench.py > $O/r4_bench.json 2> $O/bench.err
 python tools/diag_launch.py > $O/r4_timeline.txt 2>&1
 python tools/layer_profile.py > $O/r4_layers.txt 2> $O/layers.err
-rocprofv3 --kernel-trace -d $O/kt -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/kt.log 2>&1
+rocprofv3 --kernel-trace -d $O/kt -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-records > $O/kt.log 2>&1
 python tools/rocpd_stats.py $O/kt/kt_results.db $O/r4_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/pmc_m -o m -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_m.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d $O/pmc_g -o g -- python3 bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $O/pmc_g.log 2>&1
