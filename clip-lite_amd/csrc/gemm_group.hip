@@ -23,7 +23,10 @@ using namespace clite;
 namespace {
 
 constexpr int GBK = 32;                 // K tile (bf16)
-constexpr int KCHUNK = 256;             // K tiles per workgroup at most (8192 pixels / tokens)
+#ifndef CLITE_GROUP_KCHUNK
+#define CLITE_GROUP_KCHUNK 256          // (the wave-simulator build of the tests sets 24, so that a member of 32 K tiles already runs in two chunks)
+#endif
+constexpr int KCHUNK = CLITE_GROUP_KCHUNK;             // K tiles per workgroup at most (8192 pixels / tokens)
 
 template <class LA, class LB>
 struct GroupItem {

@@ -335,7 +335,7 @@ def test_stem_weight_gradient_patch_resident(N, H, W, extra_rows):
 def test_grouped_weight_gradients():
     """clite_wgrad_group: conv weight gradients of all three tile families (<= 64 output channels, <= 64 (r, s, ci) columns, general) and a
     linear weight gradient with a strided operand, as ONE grouped launch set, accumulate (+=) the same values as the per-member entry points
-    compute — including a member whose K range is cut into several k-chunks (> 256 K tiles)."""
+    compute — including a member whose K range is cut into several k-chunks."""
     from simlib import Conv
 
     class Item(C.Structure):
@@ -347,9 +347,10 @@ def test_grouped_weight_gradients():
     L.clite_wgrad_group.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.clite_wgrad_group_workspace.argtypes = [C.c_int, C.c_int64, C.c_void_p]
     items, refs, outs, hold = [], [], [], []
-    # 4th: 9216 pixels = 288 K tiles -> two k-chunks. Then the 8-wave wide bucket: 288 x 288 outputs (256 x 256 tiles, ragged both ways, a
-    # ragged last K tile of 64), and two 128-wide outputs that stay on the 4-wave tiles
-    for (N, H, W, Cc, K, R, st, pad) in [(2, 8, 8, 32, 64, 3, 1, 1), (3, 6, 6, 64, 136, 1, 1, 0), (2, 9, 7, 128, 160, 1, 2, 0), (9, 32, 32, 32, 64, 1, 1, 0),
+    # 4th: 1024 pixels = 32 K tiles -> two k-chunks (the simulator build's chunk is 24 K tiles, Makefile: CLITE_GROUP_KCHUNK; the product's 256). Then the
+    # 8-wave wide bucket: 288 x 288 outputs (256 x 256 tiles, ragged both ways, a ragged last K tile of 64), and two 128-wide outputs that stay on
+    # the 4-wave tiles
+    for (N, H, W, Cc, K, R, st, pad) in [(2, 8, 8, 32, 64, 3, 1, 1), (3, 6, 6, 64, 136, 1, 1, 0), (2, 9, 7, 128, 160, 1, 2, 0), (1, 32, 32, 32, 64, 1, 1, 0),
                                          (2, 7, 7, 32, 288, 3, 1, 1), (1, 10, 10, 128, 256, 1, 1, 0), (1, 9, 9, 256, 128, 1, 1, 0)]:
         Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
         cv = Conv(BF16, N, H, W, Cc, K, R, R, st, pad, Ho, Wo)
