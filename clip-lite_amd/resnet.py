@@ -337,7 +337,8 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
     # fp8 input gradients (DeviceRuntime.fp8_dgrad; fp8.Fp8Forward): the units' dgrads inside a block read the e5m2 copy of dy that the producing
     # bn_bwd_apply wrote and the e4m3 copy of the transposed weights (clite_conv_dgrad_fp8); weight gradients keep reading the bf16 dy
     from .fp8 import forward_state
-    f8 = forward_state(rt, net) if (rt.fp8_dgrad and rt.fuse_bn_backward and rt.transposed_dgrad) else None
+    # (not in the deterministic-reduction mode: clite_conv_dgrad_fp8 accumulates its column sums with float atomics only)
+    f8 = forward_state(rt, net) if (rt.fp8_dgrad and rt.fuse_bn_backward and rt.transposed_dgrad and not hip.is_deterministic()) else None
     if f8 is not None and f8.tgroup is None:
         f8 = None
     if f8 is not None and not resume:
