@@ -465,28 +465,34 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
     xpad, Hp, Wp, Ho, Wo, y0, st0, idx, Hq, Wq = ctx["stem"][:10]
     # max-pool backward + ReLU mask + BatchNorm backward straight from (dpool, idx, y0): neither the un-pooled gradient nor the mask is stored
     bn1 = net.bn1
-    dst0 = rt.new_stats(64, N * Ho * Wo)
-    dy0 = _alloc(rt, N * Ho * Wo, 64)
-    desc0 = hip.bn_desc(N * Ho * Wo, 64, st0, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, True, False, bn1.momentum, bn1.eps, False,
-                        centered=rt.precise_bn)
     stem_pre = ctx.pop("stem_pre", None)
-    if stem_pre is not None:          # the reductions came out of the epilogue that wrote `dout` (already masked by relu'(pooled output))
-        hip.stem_bn_pool_bwd_apply(dt, desc0, dout, idx, y0, stem_pre, dy0, rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None,
-                                   rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None, N, Ho, Wo)
-    else:
-        hip.stem_bn_pool_bwd(dt, desc0, dout, idx, y0, dst0, dy0, rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None,
-                             rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None, N, Ho, Wo)
-    if net.conv1.weight.requires_grad:
-        def stem_wgrad(dy0=dy0):
-            if rt.stem_wgrad_patch and rt.lowp and hip.stem_wgrad_patch(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, rt.arena.g(net.conv1.weight)):
-                return
-            dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)
-            hip.stem_wgrad(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, dwv)
-            hip.stem_unpack_grad(dwv, rt.arena.g(net.conv1.weight))
-        if defer is None:
-            stem_wgrad()
+
+    def stem_tail(dout=dout, stem_pre=stem_pre):
+        """bn1's backward (the un-pooled gradient dy0) and conv1's weight gradient, its only reader. Nothing on the dependent chain needs either: with
+        a deferring caller (the captured step) the whole tail joins the collected stand-alone launches, which replay on the side stream beside the
+        last weight-gradient group (DeviceRuntime.stem_tail_deferred; 165 us of bn_bwd_apply off the chain)."""
+        dst0 = rt.new_stats(64, N * Ho * Wo)
+        dy0 = _alloc(rt, N * Ho * Wo, 64)
+        desc0 = hip.bn_desc(N * Ho * Wo, 64, st0, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, True, False, bn1.momentum, bn1.eps, False,
+                            centered=rt.precise_bn)
+        dg = rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None
+        db = rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None
+        if stem_pre is not None:          # the reductions came out of the epilogue that wrote `dout` (already masked by relu'(pooled output))
+            hip.stem_bn_pool_bwd_apply(dt, desc0, dout, idx, y0, stem_pre, dy0, dg, db, N, Ho, Wo)
         else:
-            defer.call(stem_wgrad)
+            hip.stem_bn_pool_bwd(dt, desc0, dout, idx, y0, dst0, dy0, dg, db, N, Ho, Wo)
+        if not net.conv1.weight.requires_grad:
+            return
+        if rt.stem_wgrad_patch and rt.lowp and hip.stem_wgrad_patch(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, rt.arena.g(net.conv1.weight)):
+            return
+        dwv = torch.zeros(64, 7, 8, 4, device=rt.device, dtype=torch.float32)
+        hip.stem_wgrad(dt, dy0, xpad, N, Hp, Wp, Ho, Wo, dwv)
+        hip.stem_unpack_grad(dwv, rt.arena.g(net.conv1.weight))
+
+    if defer is None or not rt.stem_tail_deferred:
+        stem_tail()
+    else:
+        defer.call(stem_tail)
     if own_group is not None:
         own_group.launch()
         if staged:                    # the four stages were handed over as their groups were launched: only the stem is left

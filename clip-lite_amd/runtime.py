@@ -310,6 +310,7 @@ class DeviceRuntime:
         self.stat_replicas_fixed = False   # True: 8 statistics replicas everywhere (new_stats; tools/ab_runtime.py stat_replicas_fixed=1 for the A/B)
         self.fp8 = False                   # image-encoder forward convs on OCP e4m3 operands, quantised by their producers (BASELINE configs[4]; fp8.py); bf16 mode only
         self.fp8_text = False              # ... and BERT's QKV / FFN1 / FFN2 forward linears, quantised by the LayerNorm forward and FFN1's epilogue (fp8.Fp8Text)
+        self.stem_tail_deferred = True     # bn1's backward + conv1's weight gradient with the collected weight gradients (off the dependent chain) when the caller defers them
         self.stem_wgrad_patch = True       # conv1's weight gradient on the patch-resident kernel (hip.stem_wgrad_patch; bf16 mode)
         self.stem_pooled_stats = True      # bn1's backward reductions from pooled-size operands in the epilogue of layer1's first input gradient (resnet.py; bf16 mode)
         self.fp8_dgrad = False             # ... and the input gradients of the image encoder's 3 x 3 (>= 128 channels) / late 1 x 1 convs inside a block: e5m2 gradient x e4m3
