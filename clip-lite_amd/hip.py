@@ -347,10 +347,18 @@ def conv_wgrad_patch_applies(cv):
     return cv.dtype == BF16 and cv.C == 64 and cv.K == 64 and cv.R == 3 and cv.S == 3 and cv.stride == 1 and cv.pad == 1 and cv.W <= 58
 
 
+def _indexed(device):
+    """torch.device("cuda") and torch.device("cuda", 0) are different dictionary keys: always the indexed form (a tensor's .device carries the index)."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 def patch_workspace(device):
     """The device's scratch for clite_conv_wgrad_patch (37.7 MB). DeviceRuntime creates it when the model moves to the GPU, i.e. before any
     stream capture; a first use INSIDE a capture would put it into the graph's private pool."""
-    device = torch.device(device)
+    device = _indexed(device)
     ws = _patch_ws.get(device)
     if ws is None:
         if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
@@ -575,7 +583,7 @@ def stem_wgrad(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dwv):
 def stem_wgrad_patch(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dw):
     """The stem's weight gradient on the patch-resident kernel, += into the f32 [64][7][7][3] gradient. False: not covered (the caller takes
     stem_wgrad + stem_unpack_grad). The device's patch workspace must exist (patch_workspace: DeviceRuntime creates it)."""
-    ws = _patch_ws.get(dy.device)
+    ws = _patch_ws.get(_indexed(dy.device))
     if ws is None:
         return False
     rc = lib().clite_stem_wgrad_patch(p(dy), p(xpad), dt, N, Hp, Wp, Ho, Wo, p(dw), p(ws), ws.numel(), stream_ptr(dy))
