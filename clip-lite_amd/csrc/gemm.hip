@@ -241,6 +241,27 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
         return -1;
       }
     }
+    // The HBM-bound 1 x 1 FORWARD convolutions of the 56 x 56 / 28 x 28 stages (K <= 512, thousands of tiles, plain bf16 store + column statistics:
+    // 3.4 - 3.8 TB/s as one tile per workgroup) in the row-range persistent structure of the BatchNorm-backward dgrads, which
+    // sustains 5.2 TB/s on the same tensors (igemm_epilogue_bn FORM 4: no operands, sums of v and v^2): every workgroup is resident at once, walks
+    // its own row range of one column tile and adds its column sums once.
+#ifndef CLITE_NO_PERSIST_FWD
+    if constexpr (sizeof(T) == 2 && !LA::XC && !LB::XC && !IsDgrad<LA>::value) {
+      const bool plain_fwd = !ep.atomic && !ep.out_f32 && !ep.preact && ep.act == CLITE_ACT_NONE && !ep.dact_aux && ep.drop_p <= 0.f && !ep.residual && !ep.bias &&
+                             ep.alpha == 1.f && !ep.relu_bits && !ep.splitk_ws && splits == 1 && rm.on == 0;
+      const int tiles_n = (N + CFG::BN - 1) / CFG::BN, tiles_m = (M + CFG::BM - 1) / CFG::BM;
+      if (plain_fwd && la.g.R * la.g.S == 1 && ktiles <= 16 && (long)tiles_m * tiles_n > 2 * CLITE_BN_SLOTS && tiles_n <= CLITE_BN_SLOTS && !deterministic() &&
+          tile_policy_value() == 0) {
+        int slices = CLITE_BN_SLOTS / tiles_n;
+        int rows_per_wg = ((M + slices - 1) / slices + 7) & ~7;
+        if (rows_per_wg < CFG::BM) rows_per_wg = CFG::BM;
+        slices = (M + rows_per_wg - 1) / rows_per_wg;
+        hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 4>), dim3(slices * tiles_n), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles,
+                           rows_per_wg, nullptr, nullptr);
+        return (int)hipGetLastError();
+      }
+    }
+#endif
     // at most one workgroup per CU: two K-groups per workgroup (8 waves, in-workgroup split-K) instead of one wave per SIMD. bf16 only:
     // the exact-f32 parity mode keeps one k-ordered fmaf chain per output, which is what tracks the CPU reference most closely
     if (g2_pref() != 0 && 6 * STAGE <= 160 * 1024 && (((long)tiles * splits <= 256 && per >= 8 && sizeof(T) == 2) || g2_pref() == 2)) {

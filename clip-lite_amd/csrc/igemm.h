@@ -721,13 +721,14 @@ struct BnRows {
   // 1024 <- 256 dgrad at 14 x 14).
   DEV void request(int q, const Epilogue& ep, const RowMap& rm, int M, int N, int m0, int n0, int tid) {
     const int gcol = n0 + (tid % CPRE) * 8;
-    const bool has_bits = FORM ? true : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? true : ep.bn_y != nullptr,
-               has_res = FORM ? FORM >= 2 : ep.residual != nullptr;
+    const bool has_bits = FORM ? FORM != 4 : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? FORM != 4 : ep.bn_y != nullptr,
+               has_res = FORM ? (FORM == 2 || FORM == 3) : ep.residual != nullptr;
     const rsrc_t r_bits = make_rsrc(ep.relu_bits, RSRC_WHOLE), r_aux = make_rsrc(ep.dact_aux, RSRC_WHOLE), r_y = make_rsrc(ep.bn_y, RSRC_WHOLE),
                  r_res = make_rsrc(ep.residual, RSRC_WHOLE);
     const int grow = m0 + tid / CPRE + q * RPSE;
     okr[q] = gcol < N && grow < M;
     gix[q] = okr[q] ? (uint32_t)(map_row(rm, grow) * ep.ldc + gcol) : 0u;
+    if constexpr (FORM == 4) return;          // the plain forward form has no epilogue operands: only the row's offset
 #ifndef CLITE_EPI_ABLATE
 #define CLITE_EPI_ABLATE 0       // diagnostic builds only: 1 = epilogue without its operand loads, 2 = without its stores
 #endif
@@ -810,8 +811,8 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, BnRo
 
   constexpr int AHEAD = (FORM && CLITE_BN_HALF) ? 2 : (FORM ? CLITE_BN_AHEAD_FORM : CLITE_BN_AHEAD);
   static_assert(NREQ == 0 || NP == 1, "early requests assume the whole-tile staging order");
-  const bool has_bits = FORM ? true : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? true : ep.bn_y != nullptr;
-  const bool mask_after = FORM ? FORM >= 2 : ep.mask_after_residual != 0;
+  const bool has_bits = FORM ? FORM != 4 : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? FORM != 4 : ep.bn_y != nullptr;
+  const bool mask_after = FORM ? (FORM == 2 || FORM == 3) : ep.mask_after_residual != 0;
   const bool to_f32 = FORM ? false : (ep.out_f32 || sizeof(T) == 4);
   const rsrc_t r_out = make_rsrc(ep.out, RSRC_WHOLE);
   Raw8<T> (&pa)[ROWS_PT] = rows.pa, (&py)[ROWS_PT] = rows.py, (&pr)[ROWS_PT] = rows.pr;
@@ -837,8 +838,13 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, BnRo
     f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     float msk[8], av[8], rv[8], yv[8];
-    py[q].get(yv);
-    if constexpr (FORM == 0) {
+    if constexpr (FORM != 4) py[q].get(yv);
+    if constexpr (FORM == 4) {
+      // FORM 4 (round 4): the plain FORWARD epilogue of the HBM-bound 1 x 1 convolutions in this kernel's row-range persistent structure - bf16 store
+      // of the accumulators, column sums (sum v, sum v^2) of the stored values; no operands, no mask (out-of-range rows have zero accumulators)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) yv[e] = 0.f;
+    } else if constexpr (FORM == 0) {
       pa[q].get(av);
       pr[q].get(rv);          // zeros when there is no residual (or the row is out of range)
 #pragma unroll
@@ -852,7 +858,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, BnRo
     } else {
       // out-of-range rows / columns need no select: their accumulators are zero (operand rows / columns past the range gather as zeros) and
       // every operand load returned zeros, so v = 0 and nothing is added to the statistics; the store offset is OOB_OFF
-      if constexpr (FORM >= 2) {
+      if constexpr (FORM == 2 || FORM == 3) {
         pr[q].get(rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (pb[q] >> e) & 1u ? v[e] + rv[e] : 0.f;

@@ -248,6 +248,33 @@ def test_conv_fwd_dgrad_wgrad(dtype, N, H, W, Cc, K, R, S, st, pad):
     _close(from_bf16(buf) if dtype == BF16 else buf, want, 8e-3 if dtype == BF16 else 2e-3)
 
 
+@pytest.mark.policy_independent
+@pytest.mark.parametrize("N,H,W,Cc,K,st", [(5, 16, 16, 32, 136, 1), (10, 32, 32, 32, 64, 2), (3, 21, 20, 96, 128, 1)])
+def test_conv_fwd_1x1_row_range_persistent_form(N, H, W, Cc, K, st):
+    """The plain FORWARD epilogue in the row-range persistent kernel (igemm_dma_bn_kernel / igemm_epilogue_bn FORM 4, round 4): 1 x 1 convolutions with
+    a bf16 output, column statistics and more than twice as many tiles as resident slots (the simulator build has 4) leave one-tile-per-workgroup
+    launches for it - several tiles per workgroup, the last one partial, ragged column tiles, the 256 x 64 tile (K <= 64 outputs) and a stride-2
+    gather. Output = bf16(conv), statistics = sums of the STORED values and their squares, over replicated accumulators."""
+    assert lib().clite_set_tile_policy(0) == 0
+    rng = np.random.default_rng(H + K)
+    Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+    cv = Conv(BF16, N, H, W, Cc, K, 1, 1, st, 0, Ho, Wo)
+    x, xb = _prep(rng.standard_normal((N, H, W, Cc), dtype=np.float32), BF16)
+    w, wb = _prep(rng.standard_normal((K, 1, 1, Cc), dtype=np.float32) * 0.2, BF16)
+    y = np.zeros((N, Ho, Wo, K), np.uint16)
+    csr = np.zeros((4, 3, K), np.float32)
+    ep = make_ep(y, K, colsum=csr)
+    ep.colsum_replicas, ep.colsum_stride = 4, 3 * K
+    assert lib().clite_conv_fwd(ptr(xb), ptr(wb), C.byref(cv), C.byref(ep), None) == 0
+    ref = conv_ref(x, w, st, 0)
+    got = from_bf16(y)
+    assert np.abs(got - ref).max() <= 6e-3 * np.abs(ref).max()
+    cs = csr.sum(0)
+    assert not csr[:, 2].any()
+    _close(cs[0], got.reshape(-1, K).sum(0), 1e-4)
+    _close(cs[1], (got.reshape(-1, K) ** 2).sum(0), 1e-4)
+
+
 @pytest.mark.parametrize("dtype,N,H,W,Cc,K", [(BF16, 2, 8, 8, 64, 64), (BF16, 1, 6, 10, 128, 64), (F32, 2, 4, 6, 64, 128)])
 def test_conv_dgrad_stride2_parity_classes(dtype, N, H, W, Cc, K):
     """The four input-parity classes of a 3x3 / stride-2 / pad-1 dgrad (clite_conv_dgrad_s2class, each a stride-1 dgrad over the

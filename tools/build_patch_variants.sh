@@ -22,3 +22,11 @@ done
 mkdir -p build/varf8
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_FP8_SCALED=0 -c clip-lite_amd/csrc/fp8_ops.hip -o build/varf8/fp8_ops.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/varf8/libclite_hip_var.so build/varf8/fp8_ops.o $(ls build/hip/*.o | grep -v fp8_ops.o)
+# the HBM-bound 1 x 1 forward convolutions as one tile per workgroup (before the row-range persistent FORM 4): same-box A/B, tools/probe_fwd1x1.py
+mkdir -p build/varnpf
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_NO_PERSIST_FWD -c clip-lite_amd/csrc/gemm.hip -o build/varnpf/gemm.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/varnpf/libclite_hip_var.so build/varnpf/gemm.o $(ls build/hip/*.o | grep -v "/gemm.o")
+# the stem's patch-resident weight gradient in its 8-wave double-buffered form (tools/probe_stem.py)
+mkdir -p build/varsw8
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Iclip-lite_amd/csrc -Wno-unused-value -DCLITE_STEM_WGRAD_NW=8 -c clip-lite_amd/csrc/conv_patch.hip -o build/varsw8/conv_patch.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/varsw8/libclite_hip_var.so build/varsw8/conv_patch.o $(ls build/hip/*.o | grep -v conv_patch.o)
