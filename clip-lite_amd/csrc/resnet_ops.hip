@@ -7,11 +7,12 @@
 #include "det.h"
 #include "clite.h"
 
+#include "stem_bn.h"
+
 using namespace clite;
 
 namespace {
 
-struct BnCoef { float a[8], b[8]; };
 
 // Fold NV per-thread partial sums over all threads of the workgroup that own the same 8-channel chunk (threads tid with equal
 // tid % CPR), leaving the total in the threads with tid < CPR (CPR <= 64) or, for CPR > 64, in the threads of wave 0..(CPR/64-1)
@@ -41,44 +42,6 @@ DEV bool chunk_fold(float (&v)[NV], int CPR, float* red /* [4][64][NV] */) {
     return true;
   }
   return true;
-}
-
-// sum of the R partial accumulators of 8 consecutive channels of one statistic (32-byte vector loads)
-DEV void rsum8(const float* p, int replicas, int rstride, float (&s)[8]) {
-  load8(p, s);
-  for (int r = 1; r < replicas; ++r) {
-    float t[8];
-    load8(p + (size_t)r * rstride, t);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] += t[e];
-  }
-}
-
-// scale/shift of 8 channels from batch statistics (training) or running statistics (eval)
-DEV void bn_coef(const float* stats, int R, int RS, const float* gamma, const float* beta, const float* rmean, const float* rvar,
-                 int training, int centered, float inv_count, float eps, int C, int c0, BnCoef& k, float (&mean)[8], float (&var)[8]) {
-  if (training) {
-    // single-pass E[x^2]-E[x]^2 (sums from the conv epilogue), or the two-pass sum of squared deviations when a
-    // centered pass (clite_bn_centered_var) filled stats[2][C]
-    float s1[8], s2[8];
-    rsum8(stats + c0, R, RS, s1);
-    rsum8(stats + (centered ? 2 : 1) * C + c0, R, RS, s2);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      mean[e] = s1[e] * inv_count;
-      var[e] = centered ? s2[e] * inv_count : fmaxf(s2[e] * inv_count - mean[e] * mean[e], 0.f);
-    }
-  } else {
-    load8(rmean + c0, mean);
-    load8(rvar + c0, var);
-  }
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    int c = c0 + e;
-    float rstd = rsqrtf(var[e] + eps);
-    k.a[e] = gamma[c] * rstd;
-    k.b[e] = beta[c];           // applied as (y - mean)*a + b: folding mean into the shift cancels badly when |mean| >> std
-  }
 }
 
 // out = relu?( y*a + b  [+ res | + res*a' + b'] ).  Workgroup = 256 threads = (256/CPR) rows x CPR 8-channel chunks.
@@ -512,7 +475,6 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const T* dout, T* dx, 
 //             reductions and once for dy0                                          (282 + 487 MB instead of 282 + 615 + 820 MB)
 // Values are rounded to the storage type exactly where the unfused kernels stored them (a0 before the max, da0 before the mask), so the
 // results are bit-identical to bn_apply -> maxpool / maxpool_bwd -> bn_bwd_reduce -> bn_bwd_apply.
-template <typename T> DEV void round_store_type(float (&v)[8]) { if constexpr (sizeof(T) == 2) round8_bf16(v); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void stem_bn_pool_fwd_kernel(clite_bn p, const T* __restrict__ y, T* __restrict__ out, uint8_t* __restrict__ idx, T* __restrict__ ymax,
@@ -576,55 +538,6 @@ __global__ __launch_bounds__(256) void stem_bn_pool_fwd_kernel(clite_bn p, const
     uint32_t hi4 = (uint32_t)bi[4] | ((uint32_t)bi[5] << 8) | ((uint32_t)bi[6] << 16) | ((uint32_t)bi[7] << 24);
     *(u32x2*)(idx + (size_t)pix * p.C + c0) = u32x2{lo, hi4};
   }
-}
-
-// dz0 of one input pixel (8 channels): the pooled gradients of the <= 4 windows whose argmax is this pixel, rounded to the storage type,
-// masked by relu'(bn(y0)); also returns y0 - mean
-template <typename T>
-DEV void stem_dz(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ y, int n, int hi, int wi, int H, int W, int Ho, int Wo,
-                 int C, int c0, const float (&mean)[8], const BnCoef& k, float (&dz)[8], float (&yc)[8]) {
-  // an input pixel lies in at most 2 x 2 pooling windows: odd coordinate -> taps 0 and 2 of windows (c+1)/2 and (c-1)/2, even -> tap 1 of
-  // window c/2. All candidates are requested before any is used (clamped address + validity flag); accumulation order r-major, s-minor as in
-  // maxpool_bwd.
-  int hoc[2], woc[2], rr[2], ss[2];
-  bool hv[2], wv[2];
-  if (hi & 1) { hoc[0] = (hi + 1) >> 1; rr[0] = 0; hv[0] = hoc[0] < Ho; hoc[1] = (hi - 1) >> 1; rr[1] = 2; hv[1] = true; }
-  else        { hoc[0] = hi >> 1;       rr[0] = 1; hv[0] = hoc[0] < Ho; hoc[1] = 0;             rr[1] = 0; hv[1] = false; }
-  if (wi & 1) { woc[0] = (wi + 1) >> 1; ss[0] = 0; wv[0] = woc[0] < Wo; woc[1] = (wi - 1) >> 1; ss[1] = 2; wv[1] = true; }
-  else        { woc[0] = wi >> 1;       ss[0] = 1; wv[0] = woc[0] < Wo; woc[1] = 0;             ss[1] = 0; wv[1] = false; }
-  float d[4][8];
-  u32x2 ib[4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int ho = hv[a] ? hoc[a] : 0, wo = wv[b] ? woc[b] : 0;
-      const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c0;
-      ib[a * 2 + b] = *(const u32x2*)(idx + o);
-      load8(dpool + o, d[a * 2 + b]);
-    }
-  float acc[8];
-  zero8(acc);
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const uint32_t code = (uint32_t)(rr[a] * 3 + ss[b]);
-      const bool valid = hv[a] && wv[b];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const uint32_t t = ((e < 4 ? ib[a * 2 + b][0] : ib[a * 2 + b][1]) >> (8 * (e & 3))) & 0xFFu;
-        if (valid && t == code) acc[e] += d[a * 2 + b][e];
-      }
-    }
-  round_store_type<T>(acc);                          // da0 as maxpool_bwd would have stored it
-  float yv[8], a[8];
-  load8(y + (((size_t)n * H + hi) * W + wi) * C + c0, yv);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { yc[e] = yv[e] - mean[e]; a[e] = relu_f(yc[e] * k.a[e] + k.b[e]); }
-  round_store_type<T>(a);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) dz[e] = a[e] > 0.f ? acc[e] : 0.f;
 }
 
 template <typename T>

@@ -471,12 +471,15 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         """bn1's backward (the un-pooled gradient dy0) and conv1's weight gradient, its only reader. Nothing on the dependent chain needs either: with
         a deferring caller (the captured step) the whole tail joins the collected stand-alone launches, which replay on the side stream beside the
         last weight-gradient group (DeviceRuntime.stem_tail_deferred; 165 us of bn_bwd_apply off the chain)."""
-        dst0 = rt.new_stats(64, N * Ho * Wo)
-        dy0 = _alloc(rt, N * Ho * Wo, 64)
         desc0 = hip.bn_desc(N * Ho * Wo, 64, st0, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var, True, False, bn1.momentum, bn1.eps, False,
                             centered=rt.precise_bn)
         dg = rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None
         db = rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None
+        if (stem_pre is not None and rt.stem_bwd_fused and rt.lowp and net.conv1.weight.requires_grad
+                and hip.stem_bwd_fused(dt, desc0, dout, idx, y0, stem_pre, xpad, N, Hp, Wp, Ho, Wo, rt.arena.g(net.conv1.weight), dg, db)):
+            return          # one kernel: the un-pooled gradient existed in LDS only
+        dst0 = rt.new_stats(64, N * Ho * Wo)
+        dy0 = _alloc(rt, N * Ho * Wo, 64)
         if stem_pre is not None:          # the reductions came out of the epilogue that wrote `dout` (already masked by relu'(pooled output))
             hip.stem_bn_pool_bwd_apply(dt, desc0, dout, idx, y0, stem_pre, dy0, dg, db, N, Ho, Wo)
         else:

@@ -311,6 +311,8 @@ class DeviceRuntime:
         self.fp8 = False                   # image-encoder forward convs on OCP e4m3 operands, quantised by their producers (BASELINE configs[4]; fp8.py); bf16 mode only
         self.fp8_text = False              # ... and BERT's QKV / FFN1 / FFN2 forward linears, quantised by the LayerNorm forward and FFN1's epilogue (fp8.Fp8Text)
         self.stem_tail_deferred = True     # bn1's backward + conv1's weight gradient with the collected weight gradients (off the dependent chain) when the caller defers them
+        self.stem_bwd_fused = False        # ... both in ONE kernel when the reductions are there (hip.stem_bwd_fused: the un-pooled gradient formed in LDS only). Built, tested,
+                                           # OFF: 253 us against 176 + 80 for the two kernels - the pooled-gradient gather (241 registers, two waves per SIMD), not the 410 MB it saves, is what costs
         self.stem_wgrad_patch = True       # conv1's weight gradient on the patch-resident kernel (hip.stem_wgrad_patch; bf16 mode)
         self.stem_pooled_stats = True      # bn1's backward reductions from pooled-size operands in the epilogue of layer1's first input gradient (resnet.py; bf16 mode)
         self.fp8_dgrad = False             # ... and the input gradients of the image encoder's 3 x 3 (>= 128 channels) / late 1 x 1 convs inside a block: e5m2 gradient x e4m3

@@ -33,3 +33,22 @@ dw = torch.zeros(64, 7, 7, 3, device="cuda")
 print(f"stem_wgrad + unpack       {timed(lambda: (dwv.zero_(), hip.stem_wgrad(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dwv), hip.stem_unpack_grad(dwv, dw))):8.1f} us   (243 MB)")
 hip.patch_workspace(torch.device('cuda', 0))
 print(f"stem_wgrad_patch          {timed(lambda: hip.stem_wgrad_patch(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dw)):8.1f} us")
+
+# bn1's backward + conv1's weight gradient: two kernels (the un-pooled gradient through memory) against the fused one
+Hq = Wq = 56
+y = (torch.randn(N * Ho * Wo, 64, device="cuda") * 2).bfloat16()
+st = hip.Stats(torch.zeros(8 * 3 * 64, device="cuda"), 8, 64)
+st.t.view(8, 3, 64)[0, 0] = y.float().sum(0)
+st.t.view(8, 3, 64)[0, 1] = (y.float() ** 2).sum(0)
+gamma, beta, rm, rv = torch.ones(64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda"), torch.ones(64, device="cuda")
+desc = lambda: hip.bn_desc(N * Ho * Wo, 64, st, gamma, beta, rm, rv, True, False, 0.1, 1e-5, False)
+p0 = torch.empty(N * Hq * Wq, 64, device="cuda", dtype=torch.bfloat16)
+idx = torch.empty(N * Hq * Wq, 64, device="cuda", dtype=torch.uint8)
+print(f"stem_bn_pool_fwd          {timed(lambda: hip.stem_bn_pool_fwd(dt, desc(), y, p0, idx, N, Ho, Wo)):8.1f} us")
+dpool = (torch.randn(N * Hq * Wq, 64, device="cuda") * 0.1).bfloat16()
+ds = hip.Stats(torch.zeros(8 * 3 * 64, device="cuda"), 8, 64)
+ds.t.view(8, 3, 64)[0, 0] = 1.0
+dy0 = torch.empty(N * Ho * Wo, 64, device="cuda", dtype=torch.bfloat16)
+dg, db = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+print(f"stem_bn_pool_bwd_apply    {timed(lambda: hip.stem_bn_pool_bwd_apply(dt, desc(), dpool, idx, y, ds, dy0, dg, db, N, Ho, Wo)):8.1f} us")
+print(f"stem_bwd_fused            {timed(lambda: hip.stem_bwd_fused(dt, desc(), dpool, idx, y, ds, xpad, N, Hp, Wp, Ho, Wo, dw, dg, db)):8.1f} us   (apply + weight gradient in one kernel)")
