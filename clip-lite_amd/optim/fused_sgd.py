@@ -94,8 +94,32 @@ class FusedSGD(torch.optim.Optimizer):
         self._build_items()
         self.zero_frozen()           # stale / unconditional gradients of frozen tensors must not enter the norm
         self.sumsq.zero_()
-        hip.sumsq(self.arena.flat_g, self.arena.total, self.sumsq, self.sumsq_partials)
+        self.sumsq_spans()
         return self.sumsq.sqrt() * self.grad_prescale
+
+    def norm_spans(self):
+        """The spans the squared gradient norm is summed over, in the FIXED order every path - eager, one graph, per-phase graphs - adds them into
+        `sumsq` (so that all of them derive bit-identical clip factors): what is final before the image encoder's last weight-gradient groups (the text
+        encoder, then layer3 .. the loss heads), then the late span (stem, layer1, layer2). The captured per-phase step sums the early spans on the main
+        stream while the side stream finishes the late span's gradients (train_loop.TrainStep: norm_early); one span when the model has no such layout."""
+        if getattr(self, "_norm_spans", None) is None:
+            A = self.arena
+            spans = [(0, A.total)]
+            try:
+                img, l3 = A.region("image_encoder."), A.region("image_encoder.img_encoder.layer3.")
+                if img[0] < l3[0] < img[1]:
+                    spans = [sp for sp in ((0, img[0]), (l3[0], A.total), (img[0], l3[0])) if sp[1] > sp[0]]
+            except AssertionError:
+                pass
+            self._norm_spans = spans
+        return self._norm_spans
+
+    def sumsq_spans(self, part=None):
+        """sumsq += the squared norm of the spans of `part`: None all, "early" all but the last, "late" the last (a single-span layout is all "late")."""
+        spans = self.norm_spans()
+        sel = spans if part is None else (spans[:-1] if part == "early" else spans[-1:])
+        for lo, hi in sel:
+            hip.sumsq(self.arena.flat_g[lo:hi], hi - lo, self.sumsq, self.sumsq_partials)
 
     def zero_grad(self, set_to_none: bool = False):
         """Gradients are zeroed by the update kernel itself; this only clears a backward that was not followed by step()."""
