@@ -613,6 +613,53 @@ __global__ __launch_bounds__(256) void stem_bn_pool_bwd_apply_kernel(clite_bn p,
   }
 }
 
+// The apply pass over 2 x 2 pixel groups (stem_bn.h: stem_dz4): a thread owns the four pixels of a group and 8 channels; four window loads serve them.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_bn_pool_bwd_apply4_kernel(clite_bn p, const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ y,
+                                                                      const float* dstats, T* __restrict__ dy, float* dgamma, float* dbeta,
+                                                                      int N, int H, int W, int Ho, int Wo, int groups_per_block) {
+  const int C = p.C, CPR = C / 8, RPS = 256 / CPR;
+  const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
+  const float inv_count = 1.0f / (float)p.M;
+  BnCoef k;
+  float mean[8], var[8], ka[8], kb[8], kc[8], S1[8], S2[8];
+  bn_coef(p.stats, p.replicas, p.rstride, p.gamma, p.beta, p.running_mean, p.running_var, 1, p.centered, inv_count, p.eps, C, c0, k, mean, var);
+  rsum8(dstats + c0, p.replicas, p.rstride, S1);
+  rsum8(dstats + C + c0, p.replicas, p.rstride, S2);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = c0 + e;
+    const float rstd = rsqrtf(var[e] + p.eps);
+    const float G = rstd * S2[e];
+    const float a = p.gamma[c] * rstd;
+    ka[e] = a;
+    kc[e] = -a * rstd * G * inv_count;
+    kb[e] = -a * S1[e] * inv_count;
+    if (blockIdx.x == 0 && r0 == 0) {
+      if (dgamma) dgamma[c] += G;
+      if (dbeta) dbeta[c] += S1[e];
+    }
+  }
+  const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+  const int Q = N * H2 * W2;
+  int g_begin = blockIdx.x * groups_per_block, g_end = g_begin + groups_per_block;
+  if (g_end > Q) g_end = Q;
+  for (int g = g_begin + r0; g < g_end; g += RPS) {
+    const int j = g % W2, i = (g / W2) % H2, n = g / (W2 * H2);
+    float dz[4][8], yc[4][8];
+    stem_dz4(dpool, idx, y, n, i, j, H, W, Ho, Wo, C, c0, mean, k, dz, yc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int hi = 2 * i + (q >> 1), wi = 2 * j + (q & 1);
+      if (hi >= H || wi >= W) continue;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = ka[e] * dz[q][e] + kb[e] + kc[e] * yc[q][e];
+      store8(dy + (((size_t)n * H + hi) * W + wi) * C + c0, o);
+    }
+  }
+}
+
 // image f32 NCHW [N][3][H][W] -> T [N][H+2*pad][Wp][4], zero padded (channel 3 = 0). One wave per output row (n, hp), a lane per group of 4 INPUT
 // columns: three 16-byte loads (one per channel plane) and four 8-byte stores, 32-bit index arithmetic and one division per wave (round 3's form
 // spent its 125 us on three 64-bit divisions per pixel; this one streams at the HBM rate).
@@ -803,6 +850,22 @@ extern "C" int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t
   return (int)hipGetLastError();
 }
 
+// the stem's apply pass over 2 x 2 pixel groups (both entry points that run it)
+static int stem_apply4(const clite_bn& p, int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, void* dy, float* dgamma, float* dbeta,
+                       int N, int H, int W, int Ho, int Wo, hipStream_t st) {
+  const int CPR = p.C / 8, RPS = 256 / CPR;
+  const int Q = N * ((H + 1) / 2) * ((W + 1) / 2);
+  int sweeps = (Q + RPS - 1) / RPS;
+  int spw = sweeps / 2048;
+  spw = spw < 2 ? 2 : (spw > 8 ? 8 : spw);
+  const int gpb = spw * RPS;
+  const int grid = (Q + gpb - 1) / gpb;
+  DISPATCH(dtype,
+           hipLaunchKernelGGL(stem_bn_pool_bwd_apply4_kernel<bf16>, dim3(grid), dim3(256), 0, st, p, (const bf16*)dpool, idx, (const bf16*)y, dstats, (bf16*)dy, dgamma, dbeta, N, H, W, Ho, Wo, gpb),
+           hipLaunchKernelGGL(stem_bn_pool_bwd_apply4_kernel<float>, dim3(grid), dim3(256), 0, st, p, (const float*)dpool, idx, (const float*)y, dstats, (float*)dy, dgamma, dbeta, N, H, W, Ho, Wo, gpb));
+  return (int)hipGetLastError();
+}
+
 extern "C" int clite_stem_bn_pool_fwd_ex(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, void* ymax, int N, int H, int W, void* stream) {
   if (!p || !y || !pooled || !idx || N <= 0 || p->M != N * H * W || !bn_ok(p->M, p->C) || p->replicas < 1) return -1;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
@@ -830,23 +893,16 @@ extern "C" int clite_stem_bn_pool_bwd(const clite_bn* p, int dtype, const void* 
   DISPATCH(dtype,
            hipLaunchKernelGGL(stem_bn_pool_bwd_reduce_kernel<bf16>, dim3(grid_r), dim3(256), 0, st, *p, (const bf16*)dpool, idx, (const bf16*)y, dstats, N, H, W, Ho, Wo, rpb_r),
            hipLaunchKernelGGL(stem_bn_pool_bwd_reduce_kernel<float>, dim3(grid_r), dim3(256), 0, st, *p, (const float*)dpool, idx, (const float*)y, dstats, N, H, W, Ho, Wo, rpb_r));
-  DISPATCH(dtype,
-           hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<bf16>, dim3(grid_a), dim3(256), 0, st, *p, (const bf16*)dpool, idx, (const bf16*)y, (const float*)dstats, (bf16*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a),
-           hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<float>, dim3(grid_a), dim3(256), 0, st, *p, (const float*)dpool, idx, (const float*)y, (const float*)dstats, (float*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a));
-  return (int)hipGetLastError();
+  (void)grid_a; (void)rpb_a;
+  return stem_apply4(*p, dtype, dpool, idx, y, (const float*)dstats, dy, dgamma, dbeta, N, H, W, Ho, Wo, st);
 }
 
 extern "C" int clite_stem_bn_pool_bwd_apply(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, void* dy,
                                             float* dgamma, float* dbeta, int N, int H, int W, void* stream) {
   if (!p || !dpool || !idx || !y || !dstats || !dy || N <= 0 || p->M != N * H * W || !bn_ok(p->M, p->C) || p->replicas < 1) return -1;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  int rpb_a;
-  const int grid_a = bn_grid(p->M, p->C, &rpb_a);
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH(dtype,
-           hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<bf16>, dim3(grid_a), dim3(256), 0, st, *p, (const bf16*)dpool, idx, (const bf16*)y, dstats, (bf16*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a),
-           hipLaunchKernelGGL(stem_bn_pool_bwd_apply_kernel<float>, dim3(grid_a), dim3(256), 0, st, *p, (const float*)dpool, idx, (const float*)y, dstats, (float*)dy, dgamma, dbeta, N, H, W, Ho, Wo, rpb_a));
-  return (int)hipGetLastError();
+  return stem_apply4(*p, dtype, dpool, idx, y, dstats, dy, dgamma, dbeta, N, H, W, Ho, Wo, st);
 }
 
 extern "C" int clite_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream) {

@@ -101,6 +101,61 @@ DEV void stem_dz(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, c
   for (int e = 0; e < 8; ++e) dz[e] = a[e] > 0.f ? acc[e] : 0.f;
 }
 
+// The same for the 2 x 2 group of input pixels (2 i + dy, 2 j + dx): it lies in exactly the four windows (i + a, j + b), a, b in {0, 1}, which are loaded
+// ONCE for the four pixels - nine (pixel, window) pairs instead of the sixteen candidate loads four calls of stem_dz issue (the stand-alone apply
+// pass was gather-bound at 55 % of its HBM time). Pixel (dy, dx) takes window (a, b) at tap (dy - 2 a + 1, dx - 2 b + 1) when that tap exists; the
+// order of the additions is stem_dz's (the window of the smaller tap row first, then of the smaller tap column), so the sums are bit-identical.
+// dz / yc: [dy * 2 + dx][8]; pixels past H / W are computed from clamped addresses and must be dropped by the caller.
+template <typename T>
+DEV void stem_dz4(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ y, int n, int i, int j, int H, int W, int Ho, int Wo,
+                  int C, int c0, const float (&mean)[8], const BnCoef& k, float (&dz)[4][8], float (&yc)[4][8]) {
+  float d[4][8];          // window a * 2 + b
+  u32x2 ib[4];
+  bool wok[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ho = i + a, wo = j + b;
+      wok[a * 2 + b] = ho < Ho && wo < Wo;
+      const size_t o = (((size_t)n * Ho + (ho < Ho ? ho : Ho - 1)) * Wo + (wo < Wo ? wo : Wo - 1)) * C + c0;
+      ib[a * 2 + b] = *(const u32x2*)(idx + o);
+      load8(dpool + o, d[a * 2 + b]);
+    }
+  float yv[4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int hi = 2 * i + (q >> 1), wi = 2 * j + (q & 1);
+    load8(y + (((size_t)n * H + (hi < H ? hi : H - 1)) * W + (wi < W ? wi : W - 1)) * C + c0, yv[q]);
+  }
+  auto add = [&](float (&acc)[8], int win, uint32_t code) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t t = ((e < 4 ? ib[win][0] : ib[win][1]) >> (8 * (e & 3))) & 0xFFu;
+      if (wok[win] && t == code) acc[e] += d[win][e];
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) zero8(dz[q]);
+  // (dy, dx) = (0, 0): window (0, 0) tap (1, 1)
+  add(dz[0], 0, 4);
+  // (0, 1): window (0, 1) tap (1, 0), then (0, 0) tap (1, 2)
+  add(dz[1], 1, 3); add(dz[1], 0, 5);
+  // (1, 0): window (1, 0) tap (0, 1), then (0, 0) tap (2, 1)
+  add(dz[2], 2, 1); add(dz[2], 0, 7);
+  // (1, 1): windows (1, 1) tap (0, 0), (1, 0) tap (0, 2), (0, 1) tap (2, 0), (0, 0) tap (2, 2)
+  add(dz[3], 3, 0); add(dz[3], 2, 2); add(dz[3], 1, 6); add(dz[3], 0, 8);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    round_store_type<T>(dz[q]);                      // da0 as maxpool_bwd would have stored it
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { yc[q][e] = yv[q][e] - mean[e]; a[e] = relu_f(yc[q][e] * k.a[e] + k.b[e]); }
+    round_store_type<T>(a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dz[q][e] = a[e] > 0.f ? dz[q][e] : 0.f;
+  }
+}
 
 }  // namespace clite
 #endif
