@@ -310,6 +310,8 @@ class DeviceRuntime:
         self.stat_replicas_fixed = False   # True: 8 statistics replicas everywhere (new_stats; tools/ab_runtime.py stat_replicas_fixed=1 for the A/B)
         self.fp8 = False                   # image-encoder forward convs on OCP e4m3 operands, quantised by their producers (BASELINE configs[4]; fp8.py); bf16 mode only
         self.fp8_text = False              # ... and BERT's QKV / FFN1 / FFN2 forward linears, quantised by the LayerNorm forward and FFN1's epilogue (fp8.Fp8Text)
+        self.zero_chunk = 512 * 1024       # floats per chunk of the zero pool (ZeroPool): every captured phase starts a fresh pool, and most need a few KB of statistics -
+                                           # a 16 MB chunk per phase cost ~14 fills of 10 - 20 us per step
         self.stem_tail_deferred = True     # bn1's backward + conv1's weight gradient with the collected weight gradients (off the dependent chain) when the caller defers them
         self.stem_bwd_fused = False        # ... both in ONE kernel when the reductions are there (hip.stem_bwd_fused: the un-pooled gradient formed in LDS only). Built, tested,
                                            # OFF: 253 us against 176 + 80 for the two kernels - the pooled-gradient gather (241 registers, two waves per SIMD), not the 410 MB it saves, is what costs
@@ -344,7 +346,7 @@ class DeviceRuntime:
         key = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
         pool = self._zpools.get(key)
         if pool is None:
-            pool = self._zpools[key] = ZeroPool(self.device)
+            pool = self._zpools[key] = ZeroPool(self.device, self.zero_chunk)
         return pool
 
     def gemm_ws(self, M, N):
