@@ -329,7 +329,8 @@ class TrainStep:
                         capture("wgrad_heads", pool_side, wgrad_heads)          # (capture order = replay order on a stream: shared pool)
                     capture("wgrad_" + sg, pool_side if i < len(segs) - 1 else pool_main, wgrad(i))
                 capture("wgrad_last_extras", pool_side, wgrad_last_extras)
-                capture("norm_early", pool_main, norm_early)
+                if self.clip and self.clip > 0:          # (without clipping there is no norm: an empty capture is not worth finding out about)
+                    capture("norm_early", pool_main, norm_early)
                 capture("norm", pool_main, norm)
                 capture("update_rest", pool_side, update_rest)
                 capture("update_img", pool_main, update_img)
@@ -393,7 +394,7 @@ class TrainStep:
         with torch.cuda.stream(side):
             G["wgrad_last_extras"].replay()        # three 3 x 3 weight gradients + the stem's, beside ...
         G["wgrad_" + self._segs[-1]].replay()      # ... the grouped launch of the segment's 1 x 1 members
-        early_done = ex is None and getattr(self, "norm_overlap", True)
+        early_done = ex is None and getattr(self, "norm_overlap", True) and "norm_early" in G
         if early_done:
             main.wait_event(ev_early)
             G["norm_early"].replay()               # beside the side stream's last groups
@@ -410,7 +411,7 @@ class TrainStep:
                 ex.reduce_span(pos, rt.arena.total, after=main)
             ex.wait()
         main.wait_stream(side)
-        if not early_done:
+        if not early_done and "norm_early" in G:
             G["norm_early"].replay()               # (data parallel: only the exchanged gradients enter the norm; or norm_overlap = 0, the A/B)
         G["norm"].replay()
         G["update_img"].replay()
