@@ -83,6 +83,51 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, fl
   }
 }
 
+// torch.optim.AdamW (reference factories.py:439: OPTIMIZER_NAME "adamw", torch defaults) in the same one-pass form: decoupled weight decay, bias-corrected
+// moments, then the Lookahead synchronisation, the gradient zeroing and the bf16 copy as sgd_step_kernel. hp as there, plus [1] beta1, [6] beta2, [7] eps,
+// [8] 1 - beta1^t, [9] 1 - beta2^t, [10] 1 - beta1, [11] 1 - beta2 (the host uploads the step's bias corrections with the rest of hp).
+template <typename T, bool CAST>
+__global__ __launch_bounds__(256) void adamw_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v2, float* __restrict__ slow,
+                                                         T* __restrict__ cast, const clite_optim_item* __restrict__ items,
+                                                         const float* __restrict__ hp, const float* __restrict__ sumsq) {
+  const clite_optim_item it = items[blockIdx.x];
+  const float lr = it.lr * hp[0], wd = it.wd, max_norm = hp[2], alpha = hp[4], gs = hp[5], b2 = hp[6], eps = hp[7], bc1 = hp[8], bc2 = hp[9], omb1 = hp[10], omb2 = hp[11];
+  const bool sync = hp[3] != 0.f;
+  float clip = 1.f;
+  if (max_norm > 0.f) {
+    float total = sqrtf(sumsq[0]) * gs;
+    clip = fminf(max_norm / (total + 1e-6f), 1.f);
+  }
+  const float gmul = gs * clip, decay = 1.f - lr * wd, step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+#pragma unroll 4
+  for (uint32_t i = threadIdx.x * 4; i < it.count; i += 1024) {
+    size_t o = (size_t)it.start + i;
+    f32x4 pv = *(const f32x4*)(p + o), gv = *(const f32x4*)(g + o), mv = *(const f32x4*)(m + o), vv = *(const f32x4*)(v2 + o);
+    f32x4 sv = {0.f, 0.f, 0.f, 0.f};
+    if (sync) sv = *(const f32x4*)(slow + o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gv[e] * gmul;
+      pv[e] *= decay;
+      mv[e] = mv[e] + omb1 * (ge - mv[e]);          // exp_avg.lerp_(grad, 1 - beta1)
+      vv[e] = b2 * vv[e] + omb2 * ge * ge;          // (1 - beta formed in double on the host, as torch does: 1.f - 0.999f is off by 1.3e-5)
+      pv[e] -= step_size * (mv[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps));
+      if (sync) { pv[e] = alpha * pv[e] + (1.f - alpha) * sv[e]; sv[e] = pv[e]; }
+    }
+    *(f32x4*)(p + o) = pv;
+    *(f32x4*)(m + o) = mv;
+    *(f32x4*)(v2 + o) = vv;
+    *(f32x4*)(g + o) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (sync) *(f32x4*)(slow + o) = sv;
+    if (CAST) {
+      union { bf16 e[4]; u32x2 u; } pk;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pk.e[e] = f2bf(pv[e]);
+      *(u32x2*)((bf16*)cast + o) = pk.u;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, bf16* dst, size_t n) {
   size_t n8 = n / 8;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
@@ -188,6 +233,17 @@ extern "C" int clite_sgd_step(float* p, float* g, float* v, float* slow, void* c
     hipLaunchKernelGGL((sgd_step_kernel<bf16, true>), dim3(n_items), dim3(256), 0, st, p, g, v, slow, (bf16*)cast_bf16, items, hp, sumsq);
   else
     hipLaunchKernelGGL((sgd_step_kernel<bf16, false>), dim3(n_items), dim3(256), 0, st, p, g, v, slow, (bf16*)nullptr, items, hp, sumsq);
+  return (int)hipGetLastError();
+}
+
+extern "C" int clite_adamw_step(float* p, float* g, float* m, float* v2, float* slow, void* cast_bf16, const clite_optim_item* items, int n_items,
+                                const float* hp, const float* sumsq, void* stream) {
+  if (!p || !g || !m || !v2 || !slow || !items || n_items <= 0 || !hp || !sumsq) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  if (cast_bf16)
+    hipLaunchKernelGGL((adamw_step_kernel<bf16, true>), dim3(n_items), dim3(256), 0, st, p, g, m, v2, slow, (bf16*)cast_bf16, items, hp, sumsq);
+  else
+    hipLaunchKernelGGL((adamw_step_kernel<bf16, false>), dim3(n_items), dim3(256), 0, st, p, g, m, v2, slow, (bf16*)nullptr, items, hp, sumsq);
   return (int)hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ from .config import Config
 from .encoder import ImageEncoder, TextEncoder
 from .loss import InfoNCELoss, JSDInfoMaxLoss
 from .model import VLInfoModel
-from .optim import FusedSGD, Lookahead, lr_scheduler
+from .optim import FusedAdamW, FusedSGD, Lookahead, lr_scheduler
 
 
 class Factory(object):
@@ -105,13 +105,11 @@ class PretrainingModelFactory(Factory):
 
 
 class OptimizerFactory(Factory):
-    PRODUCTS: Dict[str, Callable] = {"sgd": FusedSGD}
+    PRODUCTS: Dict[str, Callable] = {"sgd": FusedSGD, "adamw": FusedAdamW}
 
     @classmethod
     def from_config(cls, config: Config, named_parameters: Iterable[Any]):
         _C = config
-        if _C.OPTIM.OPTIMIZER_NAME != "sgd":
-            raise KeyError("only OPTIMIZER_NAME=sgd (every shipped YAML) has a fused update kernel")
         param_groups: List[Dict[str, Any]] = []
         for name, param in named_parameters:
             wd = 0.0 if re.match(_C.OPTIM.NO_DECAY, name) else _C.OPTIM.WEIGHT_DECAY
@@ -122,7 +120,8 @@ class OptimizerFactory(Factory):
             else:
                 lr = _C.OPTIM.LR
             param_groups.append({"params": [param], "lr": lr, "weight_decay": wd})
-        optimizer = cls.create(_C.OPTIM.OPTIMIZER_NAME, param_groups, momentum=_C.OPTIM.SGD_MOMENTUM)
+        kwargs = {"momentum": _C.OPTIM.SGD_MOMENTUM} if _C.OPTIM.OPTIMIZER_NAME == "sgd" else {}          # (reference factories.py:478-483)
+        optimizer = cls.create(_C.OPTIM.OPTIMIZER_NAME, param_groups, **kwargs)
         if _C.OPTIM.LOOKAHEAD.USE:
             optimizer = Lookahead(optimizer, k=_C.OPTIM.LOOKAHEAD.STEPS, alpha=_C.OPTIM.LOOKAHEAD.ALPHA)
         return optimizer

@@ -136,6 +136,7 @@ _SIGNATURES = {
     "clite_sumsq": [_V, _U64, _V, _V, _I, _V],
     "clite_sum_slices": [_V, _I, _U64, _U64, _V, _V],
     "clite_sgd_step": [_V, _V, _V, _V, _V, _V, _I, _V, _V, _V],
+    "clite_adamw_step": [_V, _V, _V, _V, _V, _V, _V, _I, _V, _V, _V],
     "clite_cast_bf16": [_V, _V, _U64, _V],
 }
 
@@ -797,6 +798,10 @@ def sum_slices(src, slices, stride, n, dst):
 
 def sgd_step(pf, gf, vf, slow, cast, items_ptr, n_items, hp, ss):
     check(lib().clite_sgd_step(p(pf), p(gf), p(vf), p(slow), p(cast), items_ptr, n_items, p(hp), p(ss), stream_ptr(pf)), "sgd_step")
+
+
+def adamw_step(pf, gf, mf, v2f, slow, cast, items_ptr, n_items, hp, ss):
+    check(lib().clite_adamw_step(p(pf), p(gf), p(mf), p(v2f), p(slow), p(cast), items_ptr, n_items, p(hp), p(ss), stream_ptr(pf)), "adamw_step")
 
 
 def cast_bf16(src, dst, n):

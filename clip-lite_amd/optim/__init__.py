@@ -1,2 +1,2 @@
-from .fused_sgd import FusedSGD, Lookahead  # noqa: F401
+from .fused_sgd import FusedAdamW, FusedSGD, Lookahead  # noqa: F401
 from . import lr_scheduler  # noqa: F401

@@ -210,6 +210,105 @@ class FusedSGD(torch.optim.Optimizer):
         self._items_key = None
 
 
+class FusedAdamW(FusedSGD):
+    """torch.optim.AdamW (reference factories.py:439, `OPTIM.OPTIMIZER_NAME: adamw`, torch's default betas / eps) on the same arena, work items, clipping,
+    Lookahead hook and captured-step protocol as FusedSGD (clite_adamw_step). `state_dict()` keeps torch.optim.AdamW's layout (step, exp_avg, exp_avg_sq
+    per parameter). The step count - the bias corrections' exponent - advances once per upload_hp(), i.e. once per optimizer step however many span
+    launches the captured step splits it into."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        torch.optim.Optimizer.__init__(self, params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        plist = [p for g in self.param_groups for p in g["params"]]
+        arenas = {id(p._clite[0]) for p in plist if hasattr(p, "_clite")}
+        if len(arenas) != 1 or any(not hasattr(p, "_clite") for p in plist):
+            raise RuntimeError("FusedAdamW: parameters must live in one device arena - move the model to the GPU (model.to(device)) before building the "
+                               "optimizer, as reference train.py:136-138 does")
+        self.arena = plist[0]._clite[0]
+        dev = self.arena.device
+        self.flat_v = torch.zeros(self.arena.total, device=dev, dtype=torch.float32)           # exp_avg
+        self.flat_v2 = torch.zeros(self.arena.total, device=dev, dtype=torch.float32)          # exp_avg_sq
+        self.flat_slow = self.arena.flat_p.clone()
+        self.hp = torch.zeros(12, device=dev, dtype=torch.float32)
+        self.sumsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.sumsq_partials = torch.zeros(1024, device=dev, dtype=torch.float32)
+        self.max_norm = 0.0
+        self.grad_prescale = 1.0
+        self._items = None
+        self._hp_ring = None
+        self._items_key = None
+        self.before_step = None
+        self.steps = 0
+
+    def upload_hp(self, lookahead_sync=False, alpha=1.0, max_norm=None):
+        self.steps += 1
+        b1, b2 = self.param_groups[0]["betas"]
+        mn = self.max_norm if max_norm is None else float(max_norm)
+        vals = [self._lr_mult(), b1, mn, 1.0 if lookahead_sync else 0.0, alpha, self.grad_prescale, b2, self.param_groups[0]["eps"],
+                1.0 - b1 ** self.steps, 1.0 - b2 ** self.steps, 1.0 - b1, 1.0 - b2]
+        if not self.hp.is_cuda:
+            self.hp.copy_(torch.tensor(vals))
+            return
+        if self._hp_ring is None:
+            self._hp_ring = [(torch.empty(12, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+            self._hp_used = [False] * 8
+            self._hp_next = 0
+        i = self._hp_next
+        self._hp_next = (i + 1) % len(self._hp_ring)
+        host, ev = self._hp_ring[i]
+        if self._hp_used[i]:
+            ev.synchronize()
+        host.copy_(torch.tensor(vals))
+        self.hp.copy_(host, non_blocking=True)
+        ev.record()
+        self._hp_used[i] = True
+
+    @torch.no_grad()
+    def launch(self, span=None):
+        self.arena.join()
+        self._build_items()
+        self.zero_frozen()
+        first, n = 0, self._n_items
+        if span is not None:
+            import bisect
+            first = bisect.bisect_left(self._item_starts, span[0])
+            n = bisect.bisect_left(self._item_starts, span[1]) - first
+        if n > 0:
+            hip.adamw_step(self.arena.flat_p, self.arena.flat_g, self.flat_v, self.flat_v2, self.flat_slow, self.arena.flat_lp,
+                           C.c_void_p(self._items.data_ptr() + first * C.sizeof(hip.OptimItem)), n, self.hp, self.sumsq)
+        self.arena._tr_stale = True
+        self._dirty = False
+
+    def state_dict(self):
+        self.arena.flush_pending()
+        state, groups = {}, []
+        for i, g in enumerate(self.param_groups):
+            p = g["params"][0]
+            o, n = self.arena.index[p._clite[1]]
+            state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.arena._torch_view(self.flat_v, o, n, p).clone(),
+                        "exp_avg_sq": self.arena._torch_view(self.flat_v2, o, n, p).clone()}
+            groups.append({k: v for k, v in g.items() if k != "params"} | {"params": [i]})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        self.arena.flush_pending()
+        for i, g in enumerate(self.param_groups):
+            saved = sd["param_groups"][i]
+            for k, v in saved.items():
+                if k != "params":
+                    g[k] = tuple(v) if k == "betas" else v
+            p = g["params"][0]
+            o, n = self.arena.index[p._clite[1]]
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is not None:
+                if st.get("exp_avg") is not None:
+                    self.arena._torch_view(self.flat_v, o, n, p).copy_(st["exp_avg"])
+                if st.get("exp_avg_sq") is not None:
+                    self.arena._torch_view(self.flat_v2, o, n, p).copy_(st["exp_avg_sq"])
+                if st.get("step") is not None:
+                    self.steps = int(float(st["step"]))
+        self._items_key = None
+
+
 class Lookahead(object):
     r"""Reference optim/lookahead.py:8-127 on top of FusedSGD: every ``k``-th step ``p = alpha*p + (1-alpha)*slow; slow = p`` —
     executed inside the same update kernel."""

@@ -438,6 +438,12 @@ int clite_sum_slices(const float* src, int slices, uint64_t stride, uint64_t n, 
  * g is zeroed; cast_bf16 (optional) receives the bf16 copy of p at the same offsets. */
 int clite_sgd_step(float* p, float* g, float* v, float* slow, void* cast_bf16, const clite_optim_item* items, int n_items,
                    const float* hp, const float* sumsq, void* stream);
+/* ABI v11. torch.optim.AdamW (reference factories.py:439: OPTIMIZER_NAME "adamw", torch's defaults) in the same one-pass form, with the same clipping,
+ * Lookahead synchronisation, gradient zeroing and bf16 copy. hp (device f32[12]): as clite_sgd_step, with [1] = beta1, [6] = beta2, [7] = eps,
+ * [8] = 1 - beta1^t, [9] = 1 - beta2^t of this step, [10] = 1 - beta1, [11] = 1 - beta2 (formed in double by the host). p *= 1 - lr wd; m += (1 - beta1)(g' - m); v2 = beta2 v2 + (1 - beta2) g'^2;
+ * p -= lr / hp[8] * m / (sqrt(v2) / sqrt(hp[9]) + eps), g' = g * prescale * clip. */
+int clite_adamw_step(float* p, float* g, float* m, float* v2, float* slow, void* cast_bf16, const clite_optim_item* items, int n_items,
+                     const float* hp, const float* sumsq, void* stream);
 int clite_cast_bf16(const float* src, void* dst, uint64_t n, void* stream);
 
 #ifdef __cplusplus
