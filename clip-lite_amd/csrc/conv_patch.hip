@@ -652,23 +652,19 @@ __global__ __launch_bounds__(NW * 64, FUSED ? 2 : 1) void stem_wgrad_patch_kerne
   auto form_dy = [&](int strip, char* dst) {
     const int n = strip / a.strips_per_img;
     const int oy0 = (strip - n * a.strips_per_img) * 2;
-    for (int pix = tid >> 3; pix < npix; pix += NW * 8) {
-      const int oyl = pix >= a.Wo ? 1 : 0;
-      const int hi = oy0 + oyl, wi = pix - oyl * a.Wo;
-      float d[8];
-      if (hi < a.Ho) {
-        float dz[8], yc[8];
-        stem_dz((const bf16*)f.dpool, f.idx, (const bf16*)f.y, n, hi, wi, a.Ho, a.Wo, f.Hq, f.Wq, 64, fc0, fmean, fk, dz, yc);
+    // the strip's two rows are one row of 2 x 2 pixel groups (strips start on even rows): stem_dz4 - four window loads serve a group's four pixels
+    for (int gj = tid >> 3; gj < (a.Wo >> 1); gj += NW * 8) {
+      float dz[4][8], yc[4][8];
+      stem_dz4((const bf16*)f.dpool, f.idx, (const bf16*)f.y, n, oy0 >> 1, gj, a.Ho, a.Wo, f.Hq, f.Wq, 64, fc0, fmean, fk, dz, yc);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] = fka[e] * dz[e] + fkb[e] + fkc[e] * yc[e];
-      } else {
+      for (int q = 0; q < 4; ++q) {
+        const int oyl = q >> 1, pix = oyl * a.Wo + 2 * gj + (q & 1);
+        const bool live = oy0 + oyl < a.Ho;          // (an odd Ho: the last strip's second row does not exist - zeros)
+        Chunk16 ch;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] = 0.f;
+        for (int e = 0; e < 8; ++e) ch.e[e] = f2bf(live ? fka[e] * dz[q][e] + fkb[e] + fkc[e] * yc[q][e] : 0.f);
+        *(u32x4*)(dst + pix * PIXB + (((tid & 7) ^ (((pix >> 1) & 1) << 2)) << 4)) = ch.u;
       }
-      Chunk16 ch;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ch.e[e] = f2bf(d[e]);
-      *(u32x4*)(dst + pix * PIXB + (((tid & 7) ^ (((pix >> 1) & 1) << 2)) << 4)) = ch.u;
     }
   };
 
