@@ -418,3 +418,34 @@ def test_checkpoint_manager_layout(tmp_path):
     model2 = torch.nn.Linear(4, 2)
     assert CheckpointManager(model=model2, scheduler=None and 0).load(str(tmp_path / "checkpoint_30.pth")) == 30
     assert torch.equal(model2.weight, model.weight)
+
+
+def test_gradient_norm_spans_cover_the_arena_once_in_a_fixed_order():
+    """FusedSGD.norm_spans (round 4): the squared gradient norm is summed over [text encoder | layer3 .. loss heads | stem + layer1 + layer2] - in that order
+    on every path (eager, one graph, per-phase graphs with the first two summed early), so that every path derives the same clip factor. On the real
+    ResNet-50 + BERT layout (meta tensors: shapes only): the spans are disjoint, ALIGN-aligned, cover the whole arena, the late span is the image
+    encoder's head (conv1 .. layer2) and holds under 2 % of the elements; a model without that layout falls back to one span."""
+    import types
+    import torch
+    from clip_lite_amd.encoder import ImageEncoder, TextEncoder
+    from clip_lite_amd.loss import JSDInfoMaxLoss
+    from clip_lite_amd.model import VLInfoModel
+    from clip_lite_amd.optim import FusedSGD
+    from clip_lite_amd.runtime import ALIGN, Arena
+    with torch.device("meta"):
+        M = VLInfoModel(TextEncoder(mode="train_sbert", num_hidden_layers=12), ImageEncoder("resnet50"), JSDInfoMaxLoss(2048, 768, "dot", 0.1, True, True),
+                        "train_sbert", is_amp=True)
+    A = Arena.__new__(Arena)
+    A.names, A.index, A.total = Arena.layout(M.named_parameters(), M.text_encoder.strans.contiguous_groups("text_encoder.strans."))
+    opt = types.SimpleNamespace(arena=A, _norm_spans=None)
+    spans = FusedSGD.norm_spans(opt)
+    assert len(spans) == 3 and spans[0][0] == 0 and spans[1][1] == A.total
+    assert spans[0][1] == spans[2][0] and spans[2][1] == spans[1][0]          # text | late | layer3 .. : adjacent in the arena, summed in the order text, layer3 .., late
+    assert all(lo % ALIGN == 0 and hi % ALIGN == 0 for lo, hi in spans)
+    assert sum(hi - lo for lo, hi in spans) == A.total
+    late = [n for n in A.names if spans[2][0] <= A.index[n][0] < spans[2][1]]
+    assert late[0].endswith("conv1.weight") and all(".layer3." not in n and ".layer4." not in n and n.startswith("image_encoder.") for n in late)
+    assert any(".layer2." in n for n in late) and (spans[2][1] - spans[2][0]) < 0.02 * A.total
+    B = Arena.__new__(Arena)          # no image encoder of that shape: one span
+    B.names, B.index, B.total = Arena.layout([(n, p) for n, p in M.named_parameters() if n.startswith("text_encoder.")])
+    assert FusedSGD.norm_spans(types.SimpleNamespace(arena=B, _norm_spans=None)) == [(0, B.total)]
