@@ -279,7 +279,7 @@ ConvGeom geom_dense(int rows, int K, int ld) {
   g.H = 1; g.W = 1; g.C = K;
   g.sN = ld; g.sH = 0; g.sW = 0;
   g.RH = 1; g.RW = 1; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.padw = 0;
-  g.rows = rows;
+  g.rows = rows; g.concat = 0;
   g.div_hw = fastdiv_make(1);
   g.div_w = fastdiv_make(1);
   return g;
@@ -289,7 +289,7 @@ ConvGeom geom_fwd(const clite_conv& c) {
   g.H = c.H; g.W = c.W; g.C = c.C;
   g.sN = c.H * c.W * c.C; g.sH = c.W * c.C; g.sW = c.C;
   g.RH = c.Ho; g.RW = c.Wo; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
-  g.rows = c.N * c.Ho * c.Wo;
+  g.rows = c.N * c.Ho * c.Wo; g.concat = 0;
   g.div_hw = fastdiv_make(c.Ho * c.Wo);
   g.div_w = fastdiv_make(c.Wo);
   return g;
@@ -391,7 +391,7 @@ ConvGeom geom_dgrad8(const clite_conv& c) {
   g.H = c.Ho; g.W = c.Wo; g.C = c.K;
   g.sN = c.Ho * c.Wo * c.K; g.sH = c.Wo * c.K; g.sW = c.K;
   g.RH = c.H; g.RW = c.W; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
-  g.rows = c.N * c.H * c.W;
+  g.rows = c.N * c.H * c.W; g.concat = 0;
   g.div_hw = fastdiv_make(c.H * c.W);
   g.div_w = fastdiv_make(c.W);
   return g;

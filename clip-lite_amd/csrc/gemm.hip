@@ -29,7 +29,7 @@ ConvGeom geom_dense(int rows, int K, int ld = 0) {  // [rows][K] (row stride ld)
   g.H = 1; g.W = 1; g.C = K;
   g.sN = ld ? ld : K; g.sH = 0; g.sW = 0;
   g.RH = 1; g.RW = 1; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.padw = 0;
-  g.rows = rows;
+  g.rows = rows; g.concat = 0;
   g.div_hw = fastdiv_make(1);
   g.div_w = fastdiv_make(1);
   return g;
@@ -198,13 +198,13 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
     constexpr int STAGE = DA::BYTES + DB::BYTES;
     if (ep.bn_y || ep.mask_after_residual) {     // BatchNorm-backward epilogue: its own (register-heavier) instantiation, dgrad loaders only
       // it implements exactly: out = [(alpha*acc) (* relu'(aux))] (+ residual) [(* relu'(aux))], colsum; nothing else
-      if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || (ep.dact_aux && ep.relu_bits) || splits != 1) return -1;
+      if (ep.atomic || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || (ep.dact_aux && ep.relu_bits) || splits != 1) return -1;
       if constexpr (IsDgrad<LA>::value) {
         // the two forms of the bf16 ResNet backward get their own instantiations (igemm_epilogue_bn's FORM); everything else the run-time form
         constexpr bool kc_b = !LB::XC;
         int form = 0;
         if (sizeof(T) == 2 && kc_b && ep.relu_bits && ep.bn_y && !ep.dact_aux && !ep.out_f32 && ep.alpha == 1.f) {
-          if (!ep.residual && !ep.mask_after_residual) form = 1;
+          if (!ep.residual && !ep.mask_after_residual) form = ep.bias ? 5 : 1;
           else if (ep.residual && ep.mask_after_residual) form = rm.on == 2 ? 3 : 2;
         }
         // row-range persistent form (igemm_dma_bn_kernel) for the short-K (1 x 1) dgrads whose tile count exceeds the resident slots — two
@@ -213,7 +213,7 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
         const int slots = (CLITE_BN_HALF && form && CFG::BM == 128) ? CLITE_BN_SLOTS * 3 / 2 : CLITE_BN_SLOTS;
         const int tiles_n = (N + CFG::BN - 1) / CFG::BN, tiles_m = (M + CFG::BM - 1) / CFG::BM;
         int rows_per_wg = CFG::BM, slices = tiles_m;
-        if (la.g.R * la.g.S == 1 && (long)tiles_m * tiles_n > slots && tiles_n <= slots && !deterministic()) {
+        if ((la.g.R * la.g.S == 1 || la.g.concat) && (long)tiles_m * tiles_n > slots && tiles_n <= slots && !deterministic()) {
           slices = slots / tiles_n;
           rows_per_wg = ((M + slices - 1) / slices + 7) & ~7;
           if (rows_per_wg < CFG::BM) rows_per_wg = CFG::BM;
@@ -224,6 +224,7 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
           if (form == 1) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 1>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
           else if (form == 2) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 2>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
           else if (form == 3) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 3>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
+          else if (form == 5) hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 5>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
           else hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 0>), g, dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles, rows_per_wg, nullptr, nullptr);
         } else {
           bool done = false;
@@ -494,7 +495,7 @@ ConvGeom geom_fwd(const clite_conv& c) {   // rows = output pixels, gather x
   g.H = c.H; g.W = c.W; g.C = c.C;
   g.sN = c.H * c.W * c.C; g.sH = c.W * c.C; g.sW = c.C;
   g.RH = c.Ho; g.RW = c.Wo; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
-  g.rows = c.N * c.Ho * c.Wo;
+  g.rows = c.N * c.Ho * c.Wo; g.concat = 0;
   g.div_hw = fastdiv_make(c.Ho * c.Wo);
   g.div_w = fastdiv_make(c.Wo);
   return g;
@@ -504,7 +505,7 @@ ConvGeom geom_dgrad(const clite_conv& c) {  // rows = input pixels, gather dy
   g.H = c.Ho; g.W = c.Wo; g.C = c.K;
   g.sN = c.Ho * c.Wo * c.K; g.sH = c.Wo * c.K; g.sW = c.K;
   g.RH = c.H; g.RW = c.W; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
-  g.rows = c.N * c.H * c.W;
+  g.rows = c.N * c.H * c.W; g.concat = 0;
   g.div_hw = fastdiv_make(c.H * c.W);
   g.div_w = fastdiv_make(c.W);
   return g;
@@ -619,7 +620,7 @@ int conv_dgrad_s2class(const void* dy, const void* wsub, const clite_conv& c, in
   g.H = c.Ho; g.W = c.Wo; g.C = c.K;
   g.sN = c.Ho * c.Wo * c.K; g.sH = c.Wo * c.K; g.sW = c.K;
   g.RH = Hq; g.RW = Wq; g.R = na; g.S = nb; g.stride = 1; g.pad = ch; g.padw = cw;
-  g.rows = c.N * Hq * Wq;
+  g.rows = c.N * Hq * Wq; g.concat = 0;
   g.div_hw = fastdiv_make(Hq * Wq);
   g.div_w = fastdiv_make(Wq);
   RowMap rm;
@@ -676,7 +677,7 @@ ConvGeom geom_stem(int N, int Hp, int Wp, int Ho, int Wo) {
   g.H = Hp; g.W = Wp; g.C = 32;
   g.sN = Hp * Wp * 4; g.sH = Wp * 4; g.sW = 4;
   g.RH = Ho; g.RW = Wo; g.R = 7; g.S = 1; g.stride = 2; g.pad = 0; g.padw = 0;
-  g.rows = N * Ho * Wo;
+  g.rows = N * Ho * Wo; g.concat = 0;
   g.div_hw = fastdiv_make(Ho * Wo);
   g.div_w = fastdiv_make(Wo);
   return g;
@@ -774,6 +775,33 @@ extern "C" int clite_conv_dgrad_s2class(const void* dy, const void* wsub, const 
 extern "C" int clite_conv_dgrad_wt(const void* dy, const void* wt, const clite_conv* cv, const clite_epilogue* ep, void* stream) {
   if (check_conv(cv) || check_ep(ep, cv->C)) return -1;
   return cv->dtype == CLITE_BF16 ? conv_dgrad<bf16, true>(dy, wt, *cv, ep, (hipStream_t)stream) : conv_dgrad<float, true>(dy, wt, *cv, ep, (hipStream_t)stream);
+}
+// The block-output BatchNorm backward folded into the 1 x 1 convolution's input gradient (include/clite.h, ABI v12): A = [dz | y] as a two-slot "window" over
+// the pair buffer [2][M][K] — the dgrad gather with R = 2, S = 1, pad 1 over a 2 x M "image" whose single output row is the M pixels: r = 0 reads slot 1 (y),
+// r = 1 slot 0 (dz) — B = w2 [Cin][2][K] (k-contiguous rows of 2K), the BatchNorm-backward epilogue with the constant row as its bias.
+extern "C" int clite_conv_dgrad_bnfold(const void* pair, const void* w2, int M, int K, int Cin, const clite_epilogue* ep, void* stream) {
+  typedef bf16 T;
+  constexpr int BK = Cfg<T>::BK;
+  if (!pair || !w2 || M <= 0 || K <= 0 || Cin <= 0 || K % 64 || Cin % 8 || check_ep(ep, Cin)) return -1;
+  if (!ep->bn_y || !ep->relu_bits || !ep->bias || ep->residual || ep->mask_after_residual || ep->out_f32 || ep->alpha != 1.f || ep->residual_subsample > 1) return -1;
+  if (!fits32((size_t)2 * M * K, sizeof(T)) || (size_t)2 * M * K >= ((size_t)1 << 31)) return -1;
+  ConvGeom g;
+  g.H = 2; g.W = M; g.C = K;
+  g.sN = 0; g.sH = M * K; g.sW = K;
+  g.RH = 1; g.RW = M; g.R = 2; g.S = 1; g.stride = 1; g.pad = 1; g.padw = 0;
+  g.rows = M; g.concat = 1;
+  g.div_hw = fastdiv_make(M);
+  g.div_w = fastdiv_make(M);
+  const uint32_t ab = (uint32_t)((size_t)2 * M * K * sizeof(T)), wb = (uint32_t)((size_t)Cin * 2 * K * sizeof(T));
+  hipStream_t st = (hipStream_t)stream;
+  if (Cin <= 64) {
+    GatherKC<T, 256, BK, true> la{pair, ab, g};
+    GatherKC<T, 64, BK, false> lb{w2, wb, geom_dense(Cin, 2 * K)};
+    return launch<T, typename Cfg<T>::C256x64>(la, lb, *ep, M, Cin, 2 * K, 1, st);
+  }
+  GatherKC<T, 128, BK, true> la{pair, ab, g};
+  GatherKC<T, 128, BK, false> lb{w2, wb, geom_dense(Cin, 2 * K)};
+  return launch<T, typename Cfg<T>::C128>(la, lb, *ep, M, Cin, 2 * K, 1, st);
 }
 extern "C" int clite_conv_dgrad_s2class_wt(const void* dy, const void* wtsub, const clite_conv* cv, int ph, int pw, const clite_epilogue* ep, void* stream) {
   if (check_conv(cv) || check_ep(ep, cv->C)) return -1;

@@ -35,6 +35,7 @@ struct GroupItem {
   float* out;
   int ldc, M, N, ktiles, chunk;
   int zeroed;          // CLITE_WGRAD_ZEROED: `out` is known to hold zeros on entry
+  const float* row_scale;   // clite_wgrad_item.row_scale (ABI v12): per-output-row factor, or NULL
 };
 struct WgEntry { uint32_t item, tile_m, tile_n, kchunk; };      // one per workgroup
 
@@ -130,10 +131,11 @@ __global__ __launch_bounds__(256) void igemm_group_kernel(const GroupItem<LA, LB
   // accumulator tile of a BERT weight gradient took ~50 us to drain, about as long as its main loop: 437 MB of atomic traffic per step for the
   // 109 M BERT parameters. (A plain read-modify-write instead of the store was measured SLOWER than the atomics: 15.29 vs 15.11 ms per step —
   // the loads put a round trip to HBM in front of every store.)
+  const float* rs = it.row_scale;          // (workgroup-uniform: the folded BatchNorm backward's ka on a weight gradient contracted against dz)
 #ifdef CLITE_GROUP_ATOMIC_ALWAYS          // A/B builds only
   const bool single = false;
 #else
-  const bool single = wave_uniform((int)(it.ktiles <= it.chunk && it.zeroed));
+  const bool single = wave_uniform((int)(it.ktiles <= it.chunk && it.zeroed && !rs));          // (a row_scale member's correction terms are added from elsewhere: always +=)
 #endif
 #pragma unroll
   for (int i = 0; i < RM; ++i)
@@ -145,7 +147,8 @@ __global__ __launch_bounds__(256) void igemm_group_kernel(const GroupItem<LA, LB
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M && col < N) {
           float* q = out + (size_t)row * ldc + col;
-          if (single) *q = acc[i][j][r]; else atomic_add_f32(q, acc[i][j][r]);
+          const float v = rs ? acc[i][j][r] * rs[row] : acc[i][j][r];
+          if (single) *q = v; else atomic_add_f32(q, v);
         }
       }
     }
@@ -246,10 +249,11 @@ __global__ __launch_bounds__(512) void igemm_group_wide_kernel(const GroupItem<L
   // accumulator tile of a BERT weight gradient took ~50 us to drain, about as long as its main loop: 437 MB of atomic traffic per step for the
   // 109 M BERT parameters. (A plain read-modify-write instead of the store was measured SLOWER than the atomics: 15.29 vs 15.11 ms per step —
   // the loads put a round trip to HBM in front of every store.)
+  const float* rs = it.row_scale;          // (workgroup-uniform: the folded BatchNorm backward's ka on a weight gradient contracted against dz)
 #ifdef CLITE_GROUP_ATOMIC_ALWAYS          // A/B builds only
   const bool single = false;
 #else
-  const bool single = wave_uniform((int)(it.ktiles <= it.chunk && it.zeroed));
+  const bool single = wave_uniform((int)(it.ktiles <= it.chunk && it.zeroed && !rs));          // (a row_scale member's correction terms are added from elsewhere: always +=)
 #endif
 #pragma unroll
   for (int i = 0; i < RM; ++i)
@@ -261,7 +265,8 @@ __global__ __launch_bounds__(512) void igemm_group_wide_kernel(const GroupItem<L
         const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M && col < N) {
           float* q = out + (size_t)row * ldc + col;
-          if (single) *q = acc[i][j][r]; else atomic_add_f32(q, acc[i][j][r]);
+          const float v = rs ? acc[i][j][r] * rs[row] : acc[i][j][r];
+          if (single) *q = v; else atomic_add_f32(q, v);
         }
       }
     }
@@ -294,7 +299,7 @@ ConvGeom geom_fwd(const clite_conv& c) {
   g.H = c.H; g.W = c.W; g.C = c.C;
   g.sN = c.H * c.W * c.C; g.sH = c.W * c.C; g.sW = c.C;
   g.RH = c.Ho; g.RW = c.Wo; g.R = c.R; g.S = c.S; g.stride = c.stride; g.pad = c.pad; g.padw = c.pad;
-  g.rows = c.N * c.Ho * c.Wo;
+  g.rows = c.N * c.Ho * c.Wo; g.concat = 0;
   g.div_hw = fastdiv_make(c.Ho * c.Wo);
   g.div_w = fastdiv_make(c.Wo);
   return g;
@@ -322,9 +327,10 @@ struct Bucket {
   std::vector<GroupItem<LA, LB>> items;
   std::vector<Plan> plans;
   std::vector<WgEntry> map;
-  void add(const LA& la, const LB& lb, float* out, int ldc, const Plan& p, int zeroed) {
+  void add(const LA& la, const LB& lb, float* out, int ldc, const Plan& p, int zeroed, const float* row_scale = nullptr) {
     GroupItem<LA, LB> it;
     it.la = la; it.lb = lb; it.out = out; it.ldc = ldc; it.M = p.M; it.N = p.N; it.ktiles = p.ktiles; it.chunk = p.chunk; it.zeroed = zeroed;
+    it.row_scale = row_scale;
     items.push_back(it);
     plans.push_back(p);
   }
@@ -400,7 +406,8 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
     for (int i = 0; i < n; ++i) {
       const clite_wgrad_item& w = items[i];
       int rc;
-      if ((w.kind & ~(CLITE_WGRAD_NARROW | CLITE_WGRAD_ZEROED)) == 0) {
+      if (w.row_scale) return -1;          // (grouped launches only)
+      if ((w.kind & ~(CLITE_WGRAD_NARROW | CLITE_WGRAD_ZEROED | CLITE_WGRAD_SHORTK)) == 0) {
         rc = clite_conv_wgrad(w.a, w.b, &w.cv, w.out, stream);
       } else {
         clite_epilogue ep = {};
@@ -423,23 +430,24 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
     if (!w.a || !w.b || !w.out) return -1;
     const bool wide = wide_all && !(w.kind & CLITE_WGRAD_NARROW);
     const int zeroed = (w.kind & CLITE_WGRAD_ZEROED) ? 1 : 0;
-    const int kind = w.kind & ~(CLITE_WGRAD_NARROW | CLITE_WGRAD_ZEROED);
+    const int kind = w.kind & ~(CLITE_WGRAD_NARROW | CLITE_WGRAD_ZEROED | CLITE_WGRAD_SHORTK);
+    const int kc = (w.kind & CLITE_WGRAD_SHORTK) ? KCHUNK / 4 : KCHUNK, wkc = (w.kind & CLITE_WGRAD_SHORTK) ? WKCHUNK / 4 : WKCHUNK;
     if (kind == 0) {
       const clite_conv& c = w.cv;
       if (c.dtype != CLITE_BF16 || c.C % 8 || c.K % 8 || (c.R * c.S > 1 && (c.C % 32 || c.K % 32))) return -1;
       if (!fits32((size_t)c.N * c.H * c.W * c.C, 4) || !fits32((size_t)c.N * c.Ho * c.Wo * c.K, 4)) return -1;
       const int P = c.N * c.Ho * c.Wo, Ncols = c.R * c.S * c.C;
       const uint32_t yb = (uint32_t)((size_t)P * c.K * 2), xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C * 2);
-      if (wide && c.K >= 256 && Ncols >= 256) conv_w256.add(WS256{w.a, yb, c.K, c.K, P, 1}, WG256{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 256, 256, WIDE_BK, WKCHUNK), zeroed);
-      else if (c.K <= 64) conv_fewk.add(XS64{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 64, 128), zeroed);
-      else if (Ncols <= 64) conv_fewc.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG64{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 64), zeroed);
-      else conv_full.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 128), zeroed);
+      if (wide && c.K >= 256 && Ncols >= 256) conv_w256.add(WS256{w.a, yb, c.K, c.K, P, 1}, WG256{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 256, 256, WIDE_BK, wkc), zeroed, w.row_scale);
+      else if (c.K <= 64) conv_fewk.add(XS64{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 64, 128, GBK, kc), zeroed, w.row_scale);
+      else if (Ncols <= 64) conv_fewc.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG64{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 64, GBK, kc), zeroed, w.row_scale);
+      else conv_full.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 128, GBK, kc), zeroed, w.row_scale);
     } else if (kind == 1) {
       if (w.M <= 0 || w.N <= 0 || w.K <= 0 || w.M % 8 || w.N % 8 || w.lda % 8 || w.ldb % 8 || w.lda < w.M || w.ldb < w.N) return -1;
       if (!fits32((size_t)w.K * w.lda, 4) || !fits32((size_t)w.K * w.ldb, 4)) return -1;
       const uint32_t ab = (uint32_t)((((size_t)w.K - 1) * w.lda + w.M) * 2), bb = (uint32_t)((((size_t)w.K - 1) * w.ldb + w.N) * 2);
-      if (wide && w.M >= 256 && w.N >= 256) linear_w256.add(WS256{w.a, ab, w.lda, w.M, w.K, 1}, WS256{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 256, 256, WIDE_BK, WKCHUNK), zeroed);
-      else linear.add(XS128{w.a, ab, w.lda, w.M, w.K, 1}, XS128{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 128, 128), zeroed);
+      if (wide && w.M >= 256 && w.N >= 256) linear_w256.add(WS256{w.a, ab, w.lda, w.M, w.K, 1}, WS256{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 256, 256, WIDE_BK, wkc), zeroed, w.row_scale);
+      else linear.add(XS128{w.a, ab, w.lda, w.M, w.K, 1}, XS128{w.b, bb, w.ldb, w.N, w.K, 1}, w.out, w.ldc, plan(w.M, w.N, w.K, 128, 128, GBK, kc), zeroed, w.row_scale);
     } else {
       return -1;
     }

@@ -91,7 +91,8 @@ int dispatch(const WideOperand& a, const WideOperand& b, const clite_epilogue& e
   const bool bn = ep.bn_y || ep.mask_after_residual;
   if (bn) {
     // BatchNorm-backward epilogue: out = [(alpha*acc) (* relu'(aux))] (+ residual) [(* relu'(aux))], statistics; conv dgrad operands only
-    if (ep.atomic || ep.bias || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || splits != 1) return -1;
+    // (ep.bias: the constant row of the folded BatchNorm backward, added before the mask — clite_conv_dgrad_bnfold)
+    if (ep.atomic || ep.act || ep.preact || ep.drop_p > 0.f || (ep.dact_aux && ep.dact != 1) || splits != 1) return -1;
     if (a.kind == WOP_KC_DGRAD && b.kind == WOP_XC_STRIDED) return go<CFG, 1>(mk_kcd<BM>(a), mk_xs<BN>(b), ep, rm, M, N, Ktot, 1, st);
     if (a.kind == WOP_KC_DGRAD && b.kind == WOP_KC) return go<CFG, 1>(mk_kcd<BM>(a), mk_kc<BN>(b), ep, rm, M, N, Ktot, 1, st);      // transposed weights
     return -1;
@@ -142,7 +143,7 @@ int clite::launch_wide(const WideOperand& a, const WideOperand& b, const clite_e
     //    two k-groups per tile (FFN2 36.3 -> 30.8 us, 512 -> 512 3x3 dgrad 66.4 -> 58.7)
     //  * N >= 1024 with >= 128 tiles of 256 x 256 (FFN1 / QKV, the 512 <-> 2048 1x1 convs): 256 x 256 (28.8 -> 24.8, 29.9 -> 24.2)
     //  * windowed convs and K >= 1024 on larger grids: 256 x 128 (256 -> 256 3x3 44.4 -> 40.8, 1024 -> 256 1x1 27.7 -> 23.3)
-    const bool window = (a.kind == WOP_KC || a.kind == WOP_KC_DGRAD) && a.g.R * a.g.S > 1;
+    const bool window = (a.kind == WOP_KC || a.kind == WOP_KC_DGRAD) && a.g.R * a.g.S > 1 && !a.g.concat;
     if (Ktot < 512) return WIDE_NOT_TAKEN;
     //  * inside the step (tools/layer_profile.py, profiles/r2_layers_*.txt) one 8-wave workgroup per CU exposes its epilogue — nothing else
     //    on the CU computes meanwhile — so launches whose epilogue is VALU-heavy (erf-GELU forward / derivative over a 3840 x 3072 tile set:

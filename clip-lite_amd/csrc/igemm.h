@@ -60,6 +60,8 @@ struct ConvGeom {
   int R, S;           // window
   int stride, pad, padw;   // pad: rows (h), padw: columns (w); equal except in the parity-class dgrads of strided convs
   int rows;           // N * RH * RW
+  int concat;         // 1: the "window" is a K-concatenation of R tensors laid out back to back (clite_conv_dgrad_bnfold: H = R slots, W = rows) —
+                      // a short-K 1 x 1 problem for the launch policies, not a sliding window
   FastDiv div_hw, div_w;  // by RH*RW and by RW
 };
 
@@ -665,13 +667,14 @@ DEV void igemm_epilogue_plain(f32x16 (&acc)[CFG::RM][CFG::RN], const Epilogue& e
 // memory traffic still took 42 of the 85 us of the 1024 <- 256 dgrad at 14 x 14: the per-tile fixed costs, not the bytes, were half the launch.)
 struct BnEpiState {
   float bn_mean[8], csum[8], csq[8];
+  float bias[8];          // FORM 5 only (clite_epilogue.bias in the BatchNorm-backward form: the folded BatchNorm backward's constant row)
 };
 template <class CFG>
 DEV void bn_epi_begin(BnEpiState& st, const Epilogue& ep, int N, int n0, int tid) {
   constexpr int CPRE = CFG::BN / 8;
   const int gcol = n0 + (tid % CPRE) * 8;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { st.bn_mean[e] = 0.f; st.csum[e] = 0.f; st.csq[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { st.bn_mean[e] = 0.f; st.csum[e] = 0.f; st.csq[e] = 0.f; st.bias[e] = (gcol < N && ep.bias) ? ep.bias[gcol + e] : 0.f; }
   if (gcol < N && ep.bn_y) {
     for (int r = 0; r < ep.bn_replicas; ++r)
 #pragma unroll
@@ -721,6 +724,7 @@ struct BnRows {
   // 1024 <- 256 dgrad at 14 x 14).
   DEV void request(int q, const Epilogue& ep, const RowMap& rm, int M, int N, int m0, int n0, int tid) {
     const int gcol = n0 + (tid % CPRE) * 8;
+    // (FORM 5 = FORM 1 + a bias row: the same operands)
     const bool has_bits = FORM ? FORM != 4 : ep.relu_bits != nullptr, has_aux = FORM ? false : ep.dact_aux != nullptr, has_y = FORM ? FORM != 4 : ep.bn_y != nullptr,
                has_res = FORM ? (FORM == 2 || FORM == 3) : ep.residual != nullptr;
     const rsrc_t r_bits = make_rsrc(ep.relu_bits, RSRC_WHOLE), r_aux = make_rsrc(ep.dact_aux, RSRC_WHOLE), r_y = make_rsrc(ep.bn_y, RSRC_WHOLE),
@@ -851,7 +855,7 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, BnRo
       for (int e = 0; e < 8; ++e) {
         // relu' mask: packed bits, or the sign of the tensor operand, or none (ReLU' only here: check_ep enforces dact == 1)
         msk[e] = has_bits ? ((pb[q] >> e) & 1u ? 1.f : 0.f) : (has_aux ? (av[e] > 0.f ? 1.f : 0.f) : 1.f);
-        const float a = v[e] * ep.alpha;
+        const float a = v[e] * ep.alpha + st.bias[e];
         v[e] = mask_after ? (a + rv[e]) * msk[e] : a * msk[e] + rv[e];
         if (!okr[q]) v[e] = 0.f;          // (out-of-range rows / columns: nothing stored, nothing added to the statistics)
       }
@@ -862,6 +866,10 @@ DEV void igemm_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], BnEpiState& st, BnRo
         pr[q].get(rv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (pb[q] >> e) & 1u ? v[e] + rv[e] : 0.f;
+      } else if constexpr (FORM == 5) {
+        // the folded BatchNorm backward (clite_conv_dgrad_bnfold): + the constant row, then the mask. Out-of-range rows / columns read zero bits
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (pb[q] >> e) & 1u ? v[e] + st.bias[e] : 0.f;
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (pb[q] >> e) & 1u ? v[e] : 0.f;

@@ -447,9 +447,9 @@ DEV void wide_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], WideBnOperands<CFG>& 
   const int ecol = (tid % CPRE) * 8, erow0 = tid / CPRE;
   const int gcol = n0 + ecol;
   const bool colok = gcol < N;
-  float csum[8], csq[8], bn_mean[8];
+  float csum[8], csq[8], bn_mean[8], bias[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; bn_mean[e] = 0.f; }
+  for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; bn_mean[e] = 0.f; bias[e] = (colok && ep.bias) ? ep.bias[gcol + e] : 0.f; }
   if (colok && ep.bn_y) {
     for (int r = 0; r < ep.bn_replicas; ++r)
 #pragma unroll
@@ -487,7 +487,7 @@ DEV void wide_epilogue_bn(f32x16 (&acc)[CFG::RM][CFG::RN], WideBnOperands<CFG>& 
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       float msk[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v[e] *= ep.alpha; msk[e] = 1.f; }
+      for (int e = 0; e < 8; ++e) { v[e] = v[e] * ep.alpha + bias[e]; msk[e] = 1.f; }
       if (ep.relu_bits) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) msk[e] = (ops.pb[q] >> e) & 1u ? 1.f : 0.f;

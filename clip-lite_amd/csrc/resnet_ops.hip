@@ -55,7 +55,8 @@ constexpr size_t BN_NT_BYTES = (size_t)64 << 20;
 
 // Q (bf16): the producer-fused e4m3 quantiser of the fp8 forward (clite_bn.fp8_out / fp8_scale / fp8_amax): the e4m3 copy of the stored value
 // at last step's scale goes out beside it, and this step's max |out| is folded into fp8_amax — one integer atomic max per workgroup.
-template <typename T, bool NT, bool Q = false>
+// S (bf16): clite_bn.out_sum — the column sums of `out` as stored, for the folded BatchNorm backward's weight gradient (bn_fold.hip)
+template <typename T, bool NT, bool Q = false, bool S = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ out, int rows_per_block) {
   const int CPR = p.C / 8, RPS = 256 / CPR;
   const int tid = threadIdx.x, cc = tid % CPR, r0 = tid / CPR, c0 = cc * 8;
@@ -86,6 +87,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
   float qmax = 0.f;
   bool qnan = false;
   const float qscale = (Q && p.fp8_out) ? p.fp8_scale[0] : 1.f;
+  float osum[8];
+  zero8(osum);
 #pragma unroll 4
   for (int rb = row_begin; rb < row_end; rb += RPS) {
     const int r = rb + r0;
@@ -128,6 +131,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
       }
     }
     if (live) st8<NT>(out + idx, v);
+    if constexpr (S) {
+      round8_bf16(v);          // the sum of what was stored
+#pragma unroll
+      for (int e = 0; e < 8; ++e) osum[e] += live ? v[e] : 0.f;
+    }
     if constexpr (Q) {
       round8_bf16(v);          // quantise / measure the value as stored, so that the copy equals clite_fp8_quantize of `out` at the same scale
 #pragma unroll
@@ -143,6 +151,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(clite_bn p, const T* __re
         }
         *(u32x2*)(p.fp8_out + idx) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
       }
+    }
+  }
+  if constexpr (S) {
+    __shared__ float sred[4 * 64 * 8];
+    if (chunk_fold<8>(osum, CPR, sred)) {          // one float atomic per column and workgroup, into the workgroup's replica
+      float* dst = p.out_sum + (size_t)(blockIdx.x % p.out_sum_replicas) * p.out_sum_stride + c0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomic_add_f32(dst + e, osum[e]);
     }
   }
   if constexpr (Q) {
@@ -708,7 +724,7 @@ __global__ __launch_bounds__(256) void image_to_nhwc4_kernel(const float* __rest
 // out[c] += sum_m x[m][c]  (bias gradients). Workgroup = 32 column chunks (256 columns) x 8 row lanes; grid = (column
 // groups, row slabs); the 8 row lanes fold through LDS and every slab ends in one float atomic per column.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int M, int N, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int M, int N, int rows_per_block, int nfold) {
   __shared__ float red[8][32 * 8];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int chunk = blockIdx.x * 32 + cx;
@@ -735,7 +751,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) s += red[r][col];
-    atomic_add_f32(out + gcol, s);
+    atomic_add_f32(out + (nfold ? gcol % nfold : gcol), s);          // nfold: the matrix is a narrow [M * N / nfold][nfold] one seen 256 columns wide (clite_colsum)
   }
 }
 
@@ -755,6 +771,12 @@ extern "C" int clite_bn_apply(const clite_bn* p, int dtype, const void* y, const
   int grid = bn_grid(p->M, p->C, &rpb);
   hipStream_t st = (hipStream_t)stream;
   const bool nt = (size_t)p->M * p->C * (dtype == CLITE_BF16 ? 2 : 4) >= BN_NT_BYTES;
+  if (p->out_sum) {          // column sums of the stored output (clite_bn.out_sum; bf16, not together with the fp8 producer)
+    if (dtype != CLITE_BF16 || p->fp8_out || p->fp8_amax || p->out_sum_replicas < 1) return -1;
+    if (nt) hipLaunchKernelGGL((bn_apply_kernel<bf16, true, false, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb);
+    else hipLaunchKernelGGL((bn_apply_kernel<bf16, false, false, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb);
+    return (int)hipGetLastError();
+  }
   if (p->fp8_out || p->fp8_amax) {          // producer-fused e4m3 copy / amax (bf16 activations only)
     if (dtype != CLITE_BF16 || (p->fp8_out && !p->fp8_scale)) return -1;
     if (nt) hipLaunchKernelGGL((bn_apply_kernel<bf16, true, true>), dim3(grid), dim3(256), 0, st, *p, (const bf16*)y, (const bf16*)res, (bf16*)out, rpb);
@@ -938,17 +960,22 @@ extern "C" int clite_image_to_nhwc4(int dtype, const float* img, void* out, int 
 
 extern "C" int clite_colsum(int dtype, const void* x, float* out, int M, int N, void* stream) {
   if (M <= 0 || N <= 0 || N % 8) return -1;
+  // A narrow matrix (N = 64 / 128: the folded BatchNorm backward's colsum(a) over 100k - 400k pixels) would use a quarter / half of each workgroup's
+  // 256 column lanes: 256 / N consecutive rows are one 256-wide row of the same memory, and column j of that view belongs to column j % N
+  int nfold = 0;
+  if (N < 256 && 256 % N == 0 && M % (256 / N) == 0 && M / (256 / N) >= 64) { nfold = N; M /= 256 / N; N = 256; }
   int gx = (N / 8 + 31) / 32;
   int slabs = 256 / gx;           // ~256 workgroups; every slab ends in one float atomic per column (a few dozen per address)
   if (slabs < 8) slabs = 8;
   if (slabs > 64) slabs = 64;
+  if (nfold && M >= 64 * 1024) slabs = 1024;          // tens of MB: enough workgroups to stream at the HBM rate (4 x 1024 atomics per address)
   if (slabs > M) slabs = M;
   if (clite::deterministic()) slabs = 1;      // det.h: one contribution per column
   int rpb = (M + slabs - 1) / slabs;
   slabs = (M + rpb - 1) / rpb;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH(dtype,
-           hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(gx, slabs), dim3(256), 0, st, (const bf16*)x, out, M, N, rpb),
-           hipLaunchKernelGGL(colsum_kernel<float>, dim3(gx, slabs), dim3(256), 0, st, (const float*)x, out, M, N, rpb));
+           hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(gx, slabs), dim3(256), 0, st, (const bf16*)x, out, M, N, rpb, nfold),
+           hipLaunchKernelGGL(colsum_kernel<float>, dim3(gx, slabs), dim3(256), 0, st, (const float*)x, out, M, N, rpb, nfold));
   return (int)hipGetLastError();
 }

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLITE_HIP_LIB") or os.path.join(_HERE, "lib", "libclite_hip.so")     # override: diagnostic builds only
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 BF16, F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
@@ -45,12 +45,14 @@ class Bn(C.Structure):
         ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
         ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p), ("relu_bits", C.c_void_p),
         ("fp8_out", C.c_void_p), ("fp8_scale", C.c_void_p), ("fp8_amax", C.c_void_p),
+        ("out_sum", C.c_void_p), ("out_sum_replicas", C.c_int32), ("out_sum_stride", C.c_int32),
     ]
 
 
 class WgradItem(C.Structure):
     _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
-                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32)]
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                ("row_scale", C.c_void_p)]
 
 
 class Fp8Item(C.Structure):
@@ -82,6 +84,9 @@ _SIGNATURES = {
     "clite_conv_dgrad_s2class": [_V, _V, _V, _I, _I, _V, _V],
     "clite_conv_dgrad_wt": [_V, _V, _V, _V, _V],
     "clite_conv_dgrad_s2class_wt": [_V, _V, _V, _I, _I, _V, _V],
+    "clite_bn_fold_prepare": [_V, _V, _V, _I, _V, _V, _V, _V, _V, _V],
+    "clite_conv_dgrad_bnfold": [_V, _V, _I, _I, _I, _V, _V],
+    "clite_bn_fold_wgrad_finish": [_V, _V, _I, _I, _V, _V, _I, _I, _I, _V, _V],
     "clite_transpose_weights": [_V, _V, _V, _I, _U32, _V],
     "clite_conv_wgrad": [_V, _V, _V, _V, _V],
     "clite_conv_wgrad_patch_workspace": [_V],
@@ -309,6 +314,37 @@ def conv_dgrad(dy, w, cv, ep, wt=False):
     check(fn(p(dy), p(w), C.byref(cv), C.byref(ep), stream_ptr(dy)), "conv_dgrad")
 
 
+class BnFold:
+    """What clite_bn_fold_prepare leaves for the folded BatchNorm backward of one 1 x 1 conv -> BatchNorm unit (include/clite.h, ABI v12)."""
+    __slots__ = ("w2", "bias", "coef", "K", "Cin")
+
+
+def bn_fold_prepare(desc, dstats, wt, Cin, dgamma, dbeta):
+    """desc: the BatchNorm (hip.bn_desc, training statistics); dstats: its two backward reductions (Stats, same replica layout); wt: the bf16 TRANSPOSED
+    weights [Cin][K] of the 1 x 1 convolution in front of it. Accumulates dgamma / dbeta."""
+    K = desc.C
+    f = BnFold()
+    f.K, f.Cin = K, Cin
+    dev = wt.device
+    f.w2 = torch.empty(Cin, 2, K, dtype=torch.bfloat16, device=dev)
+    f.bias = torch.empty(Cin, dtype=torch.float32, device=dev)
+    f.coef = torch.empty(3, K, dtype=torch.float32, device=dev)
+    assert dstats.R == desc.replicas and dstats.rstride == desc.rstride
+    check(lib().clite_bn_fold_prepare(C.byref(desc), p(dstats.t), p(wt), Cin, p(f.w2), p(f.bias), p(f.coef), p(dgamma), p(dbeta), stream_ptr(wt)), "bn_fold_prepare")
+    return f
+
+
+def conv_dgrad_bnfold(pair, w2, M, K, Cin, ep):
+    """pair: bf16 [2][M][K] (slot 0 = dz, slot 1 = y); ep: the BatchNorm-backward form (relu_bits, bn, colsum) with bias = BnFold.bias."""
+    assert pair.is_contiguous() and tuple(pair.shape) == (2, M, K)
+    check(lib().clite_conv_dgrad_bnfold(p(pair), p(w2), M, K, Cin, C.byref(ep), stream_ptr(pair)), "conv_dgrad_bnfold")
+
+
+def bn_fold_wgrad_finish(G, asum, coef, wt, M, K, Cin, dw):
+    """asum: Stats whose row 0 holds the column sums of the activation (bn_desc(out_sum=...) of the bn_apply that wrote it)."""
+    check(lib().clite_bn_fold_wgrad_finish(p(G), p(asum.t), asum.R, asum.rstride, p(coef), p(wt), M, K, Cin, p(dw), stream_ptr(G)), "bn_fold_wgrad_finish")
+
+
 def transpose_weights(src, dst, items_dev, n_items, total_tiles):
     check(lib().clite_transpose_weights(p(src), p(dst), p(items_dev), n_items, total_tiles, stream_ptr(src)), "transpose_weights")
 
@@ -406,6 +442,7 @@ class WgradGroup:
         gradient buffer holds zeros when the group is launched (CLITE_WGRAD_ZEROED: plain stores instead of float atomics for the members whose
         contraction fits one K chunk) — the captured train step, which visits every weight once per step behind an update that zeroes the arena."""
         self.dt, self.items, self.extra, self.keep, self.wgs = dt, [], [], [], 0
+        self.post = []          # after(): launches that read what the grouped launch wrote - right behind it, on ITS stream (never with the extras)
         self.kflags = 0x200 if zeroed else 0
         self.ws_dev, self.ws_host = workspace if workspace is not None else (None, None)
 
@@ -427,19 +464,22 @@ class WgradGroup:
     # ungrouped paths (hip.conv_wgrad_patch) and as a tested entry point of the C ABI.
     patch = False
 
-    def conv(self, dy, x, cv, dw):
-        if self.patch and self.wide and conv_wgrad_patch_applies(cv) and not is_deterministic():
+    def conv(self, dy, x, cv, dw, row_scale=None, short_k=False):
+        """row_scale: f32 [K] per-output-channel factor on this member's product (clite_wgrad_item.row_scale; the folded BatchNorm backward).
+        short_k: K chunks of a quarter of the usual length (CLITE_WGRAD_SHORTK: a tiny output over a very long contraction)."""
+        if row_scale is None and self.patch and self.wide and conv_wgrad_patch_applies(cv) and not is_deterministic():
             # the 64 -> 64 3 x 3 members run on the patch-resident kernel behind the grouped launch (97 -> ~30 us each): a launch of their own,
             # on the stream of launch()
             self.keep += [dy, x, dw]
             self.extra.append(lambda: conv_wgrad_patch(dy, x, cv, dw))
             return
         it = WgradItem()
-        it.kind, it.a, it.b, it.out, it.cv = (0 if self.wide else 0x100) | self.kflags, p(dy), p(x), p(dw), cv
+        it.kind, it.a, it.b, it.out, it.cv = (0 if self.wide else 0x100) | self.kflags | (0x400 if short_k else 0), p(dy), p(x), p(dw), cv
+        it.row_scale = p(row_scale)
         self.items.append(it)
-        self.keep += [dy, x, dw]
+        self.keep += [dy, x, dw, row_scale]
         ncols = cv.R * cv.S * cv.C
-        self.wgs += self._wgs(cv.K, ncols, cv.N * cv.Ho * cv.Wo, 64 if cv.K <= 64 else 128, 64 if ncols <= 64 else 128)
+        self.wgs += self._wgs(cv.K, ncols, cv.N * cv.Ho * cv.Wo, 64 if cv.K <= 64 else 128, 64 if ncols <= 64 else 128) * (4 if short_k else 1)
 
     def linear(self, A, B, M, N, K, out, lda=None, ldb=None, ldc=None):
         """out[M][N] += A[K][M]^T B[K][N] (f32 accumulate)."""
@@ -452,6 +492,11 @@ class WgradGroup:
 
     def call(self, fn):
         self.extra.append(fn)
+
+    def after(self, fn):
+        """fn() launches something that READS a member's result (the folded BatchNorm backward's correction terms: they need the group's Gram matrix):
+        enqueued by launch() right behind the grouped launch, on the same stream - unlike the extras, which a caller may replay elsewhere."""
+        self.post.append(fn)
 
     def launch_extras(self):
         """The members that are launches of their own (bias column sums, the stem's packed gradient, the patch-resident 3 x 3 weight gradients):
@@ -491,6 +536,8 @@ class WgradGroup:
                 while _inflight_groups and _inflight_groups[0][0].query():
                     _inflight_groups.popleft()
                 _inflight_groups.append((ev, self))
+        for fn in self.post:
+            fn()
         if extras:
             self.launch_extras()
 
@@ -617,7 +664,7 @@ def stem_unpack_grad(dwv, dw):
 
 
 # ------------------------------------------------------------------------------------------------ BN / pools
-def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, eps, relu, res_bn=None, centered=False, relu_bits=None, fp8=None):
+def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, eps, relu, res_bn=None, centered=False, relu_bits=None, fp8=None, out_sum=None):
     """stats: hip.Stats (training) or None (eval: running statistics). relu_bits: uint8 [M][C / 8] that bn_apply fills with the packed ReLU mask.
     fp8: (q uint8 [M][C] or None, scales f32[2] or None, amax f32[1] or None) — bn_apply's producer-fused e4m3 copy (clite_bn.fp8_*)."""
     b = Bn()
@@ -634,6 +681,8 @@ def bn_desc(M, Cc, stats, gamma, beta, rmean, rvar, training, update, momentum, 
     b.relu_bits = p(relu_bits)
     if fp8 is not None:
         b.fp8_out, b.fp8_scale, b.fp8_amax = p(fp8[0]), p(fp8[1]), p(fp8[2])
+    if out_sum is not None:          # Stats: row 0 of every replica receives the column sums of the stored output (clite_bn.out_sum)
+        b.out_sum, b.out_sum_replicas, b.out_sum_stride = p(out_sum.t), out_sum.R, out_sum.rstride
     return b
 
 

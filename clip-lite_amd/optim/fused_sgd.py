@@ -357,12 +357,14 @@ class Lookahead(object):
 
     def load_slow_weights(self):
         a = self.optimizer.arena
+        a.flush_pending()          # a deferred share of the last update must land on the FAST weights, not on top of the slow ones
         self._backup = a.flat_p.clone()
         a.flat_p.copy_(self.optimizer.flat_slow)
         a.refresh_lowp()
 
     def restore_fast_weights(self):
         a = self.optimizer.arena
+        a.flush_pending()
         a.flat_p.copy_(self._backup)
         del self._backup
         a.refresh_lowp()

@@ -109,20 +109,20 @@ class ResNet(nn.Module):
 # ---------------------------------------------------------------------------------------------------- executor
 class _Unit:
     """Saved tensors of one conv->BN unit."""
-    __slots__ = ("conv", "bn", "cv", "x", "y", "stats", "out", "bits")
+    __slots__ = ("conv", "bn", "cv", "x", "y", "stats", "out", "bits", "pair", "xsum")
 
 
 def _alloc(rt, *shape):
     return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
 
 
-def _bn_desc(rt, bn, M, stats, relu, training, res=None, bits=None, fp8=None):
+def _bn_desc(rt, bn, M, stats, relu, training, res=None, bits=None, fp8=None, out_sum=None):
     res_bn = None
     if res is not None:
         rbn, rstats = res
         res_bn = (rstats, rbn.weight, rbn.bias, rbn.running_mean, rbn.running_var)
     return hip.bn_desc(M, bn.num_features, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                       training, training, bn.momentum, bn.eps, relu, res_bn, centered=rt.precise_bn, relu_bits=bits, fp8=fp8)
+                       training, training, bn.momentum, bn.eps, relu, res_bn, centered=rt.precise_bn, relu_bits=bits, fp8=fp8, out_sum=out_sum)
 
 
 def _relu_bits(rt, M, Cc, training):
@@ -131,11 +131,13 @@ def _relu_bits(rt, M, Cc, training):
     return torch.empty(M, Cc // 8, device=rt.device, dtype=torch.uint8) if training else None
 
 
-def _conv(rt, x, N, H, W, conv, training, f8=None, x8=None):
-    """f8: the network's fp8.Fp8Forward (or None); x8: the e4m3 copy of x its producer wrote (hip.Fp8View), when it did."""
+def _conv(rt, x, N, H, W, conv, training, f8=None, x8=None, pair=False):
+    """f8: the network's fp8.Fp8Forward (or None); x8: the e4m3 copy of x its producer wrote (hip.Fp8View), when it did.
+    pair: y is slot 1 of a [2][M][K] buffer whose slot 0 will hold the masked gradient w.r.t. the BatchNorm output in backward (_fold_ok)."""
     cv = hip.conv_desc(rt.dt, N, H, W, conv.in_channels, conv.out_channels, conv.k, conv.k, conv.stride, conv.pad)
     M = N * cv.Ho * cv.Wo
-    y = _alloc(rt, M, conv.out_channels)
+    pr = _alloc(rt, 2, M, conv.out_channels) if pair else None
+    y = pr[1] if pair else _alloc(rt, M, conv.out_channels)
     stats = rt.new_stats(conv.out_channels, M) if training else None
     if f8 is not None and f8.wants(conv, H):
         # OCP e4m3 operands (include/clite.h: clite_conv_fwd_fp8; policy and scaling: fp8.py); y, the statistics and everything backward stay as they are.
@@ -146,8 +148,16 @@ def _conv(rt, x, N, H, W, conv, training, f8=None, x8=None):
     if training and rt.precise_bn:
         hip.bn_centered_var(rt.dt, y, stats, M, conv.out_channels)
     u = _Unit()
-    u.conv, u.cv, u.x, u.y, u.stats = conv, cv, x, y, stats
+    u.conv, u.cv, u.x, u.y, u.stats, u.pair, u.xsum = conv, cv, x, y, stats, pr, None
     return u
+
+
+def _fold_wanted(rt, conv, rows, training, last_block):
+    """Forward-time half of the decision to fold a block-output BatchNorm's backward into conv3's gradients (DeviceRuntime.bn_fold; hip.bn_fold_prepare):
+    a 1 x 1 / stride 1 convolution with enough rows that its apply pass is HBM-bound (the 56 x 56 and 28 x 28 stages at batch 128; at 14 x 14 the doubled
+    K of the input gradient costs what the pass saves), bf16, not the network's last block (its gradient comes from the pooling, unmasked and without sums)."""
+    return (training and rt.bn_fold and rt.lowp and rt.fuse_bn_backward and rt.transposed_dgrad and not last_block and conv.k == 1 and conv.stride == 1
+            and conv.out_channels % 64 == 0 and rows >= rt.bn_fold_min_rows and 2 * rows * conv.out_channels < 2 ** 31)
 
 
 def _wd(rt, conv):
@@ -232,17 +242,24 @@ def resnet_forward(rt, net, image, training, staged=None):
         xin, xin8, Hin, Win = x, x8, Hc, Wc
         h, h8, Hh, Wh = xin, xin8, Hin, Win
         specs = blk.units()
+        fold_blk = (len(specs) == 3 and _fold_wanted(rt, specs[-1][0], N * ((Hin + 2 - 3) // specs[1][0].stride + 1) * ((Win + 2 - 3) // specs[1][0].stride + 1), training,
+                                                   bi == len(blocks) - 1) and not (f8 is not None and f8.wants(specs[-1][0], (Hin + 2 - 3) // specs[1][0].stride + 1)))
         for i, (conv, bn) in enumerate(specs):
-            u = _conv(rt, h, N, Hh, Wh, conv, training, f8, h8)
+            last = i == len(specs) - 1
+            u = _conv(rt, h, N, Hh, Wh, conv, training, f8, h8, pair=last and fold_blk)
             u.bn = bn
             Hh, Wh = u.cv.Ho, u.cv.Wo
             M = N * Hh * Wh
-            last = i == len(specs) - 1
             u.out = _alloc(rt, M, conv.out_channels)
             u.bits = _relu_bits(rt, M, conv.out_channels, training)
             if not last:
                 q, h8 = f8.producer(bn, M, conv.out_channels, f8.wants(specs[i + 1][0], Hh), training) if f8 is not None else (None, None)
-                hip.bn_apply(dt, _bn_desc(rt, bn, M, u.stats, True, training, bits=u.bits, fp8=q), u.y, None, u.out)
+                # conv3's input in a folding block: its column sums come out of this pass (the folded weight gradient's colsum(a))
+                # (32 replicas: the apply pass's ~1024 workgroups all reach their 8 atomics per thread at the end of the launch — with the 2 - 4 replicas
+                # of the convolutions' statistics, whose tiles arrive spread over the launch, that burst cost 40 - 70 us per pass)
+                osum = hip.Stats(rt.zpool.take(32 * 3 * conv.out_channels), 32, conv.out_channels) if (fold_blk and i == len(specs) - 2 and q is None) else None
+                hip.bn_apply(dt, _bn_desc(rt, bn, M, u.stats, True, training, bits=u.bits, fp8=q, out_sum=osum), u.y, None, u.out)
+                u.xsum = osum
             units.append(u)
             h = u.out
         ud = None
@@ -297,6 +314,22 @@ def _bn_backward_apply(rt, u, dz, dstats, fp8=None):
     db = rt.arena.g(bn.bias) if bn.bias.requires_grad else None
     hip.bn_bwd_apply(rt.dt, desc, dz, None, u.y, dstats, dy, None, dg, db)
     return dy
+
+
+def _fold_wgrad(rt, group, u, asum, dz, f):
+    """conv3's weight gradient with bn3's backward folded in: dW = diag(ka) (dz^T a) + kb (x) colsum(a) + diag(kc) W Cov(a) (include/clite.h, ABI v12). The
+    first term and the Gram matrix a^T a are members of the grouped launch; the two correction terms follow it on its stream (WgradGroup.after): one small
+    f32 kernel. asum: the column sums of a, left by the bn_apply that wrote it."""
+    Mr, Kc, Cin = u.y.shape[0], u.y.shape[1], u.conv.in_channels
+    dw = rt.arena.g(u.conv.weight)
+    a = u.x
+    group.conv(dz, a, u.cv, dw, row_scale=f.coef[0])
+    G = rt.zpool.take(Cin * Cin)
+    # the Gram matrix as a 1 x 1 "convolution" member (dy := a, x := a): the conv buckets have the 64-row tile that a 64 x 64 output wants
+    group.conv(a, a, hip.conv_desc(rt.dt, 1, 1, Mr, Cin, Cin, 1, 1, 1, 0), G, short_k=True)
+    wt = _wd(rt, u.conv)[0]
+    group.keep += [f.coef, G, asum.t, wt]
+    group.after(lambda: hip.bn_fold_wgrad_finish(G, asum, f.coef, wt, Mr, Kc, Cin, dw))
 
 
 def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False):
@@ -363,6 +396,7 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         identity = ud is None
         # block output = relu(bn_last(y_last) + shortcut): the mask is the block output itself
         dyd = None
+        folded = None
         q8, dy8 = gq(last, len(units) - 1)
         if pre is None:
             dy, dz = _bn_backward(rt, last, dout, last.bits, N, want_dz=identity, fp8=q8)
@@ -370,16 +404,43 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 dyd, _ = _bn_backward(rt, ud, dout, last.bits, N)
         else:
             dz = dout
-            dy = _bn_backward_apply(rt, last, dz, pre, fp8=q8)
+            if (last.pair is not None and units[-2].xsum is not None and q8 is None and defer is not None and dz.data_ptr() == last.pair.data_ptr()
+                    and not hip.is_deterministic() and _wd(rt, last.conv)[1]):
+                # fold bn3's backward into conv3's two gradients: no apply pass, no dy (205 MB per layer1 block at batch 128)
+                bn3 = last.bn
+                desc = hip.bn_desc(last.y.shape[0], last.y.shape[1], last.stats, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var, True, False, bn3.momentum,
+                                   bn3.eps, False, centered=rt.precise_bn)
+                folded = hip.bn_fold_prepare(desc, pre, _wd(rt, last.conv)[0], last.conv.in_channels,
+                                             rt.arena.g(bn3.weight) if bn3.weight.requires_grad else None, rt.arena.g(bn3.bias) if bn3.bias.requires_grad else None)
+                dy = None
+            else:
+                dy = _bn_backward_apply(rt, last, dz, pre, fp8=q8)
             if ud is not None:
                 dyd, _ = _bn_backward(rt, ud, dz, None, N)
         pre = None
         for i in range(len(units) - 1, -1, -1):
             u = units[i]
+            if folded is not None and i == len(units) - 1:
+                # conv3 with its BatchNorm's backward folded in (hip.bn_fold_prepare): dy is never formed. Weight gradient = ka . (dz^T a) as the group's
+                # member (row_scale) + the two correction terms behind the group; input gradient = [dz | y] [ka W ; kc W] + a constant row through the
+                # usual BatchNorm-backward epilogue (the mask and reductions of bn2)
+                Mr, Kc, Cin = u.y.shape[0], u.y.shape[1], u.conv.in_channels
+                if u.conv.weight.requires_grad:
+                    _fold_wgrad(rt, defer, u, units[i - 1].xsum, dz, folded)
+                prev = units[i - 1]
+                dstats = rt.new_stats(Cin, prev.y.shape[0])
+                dx = _alloc(rt, u.x.shape[0], Cin)
+                hip.conv_dgrad_bnfold(u.pair, folded.w2, Mr, Kc, Cin,
+                                      hip.epilogue(dx, Cin, relu_bits=prev.bits, colsum=dstats, bn=(prev.y, prev.stats, prev.y.shape[0]), bias=folded.bias))
+                q8, dy8 = gq(prev, i - 1)
+                dy = _bn_backward_apply(rt, prev, dx, dstats, fp8=q8)
+                continue
             if u.conv.weight.requires_grad:
                 wgrad(dy, u)
             Cin = u.conv.in_channels
-            dx = _alloc(rt, u.x.shape[0], Cin)
+            # the gradient this block hands to the previous one goes straight into slot 0 of that block's pair buffer (beside its y3) when it folds
+            pl_pair = recs[bi - 1][0][-1].pair if (i == 0 and bi > 0) else None
+            dx = pl_pair[0] if pl_pair is not None else _alloc(rt, u.x.shape[0], Cin)
             wd, wt = _wd(rt, u.conv)
             if i > 0 and not rt.fuse_bn_backward:
                 hip.conv_dgrad(dy, wd, u.cv, hip.epilogue(dx, Cin), wt=wt)
@@ -407,7 +468,8 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                                    hip.epilogue(dx, Cin, residual=dz, relu_bits=pl.bits, mask_after_residual=True, colsum=pre,
                                                 bn=(pl.y, pl.stats, pl.y.shape[0])), wt=wt)
                 elif (ud is not None and bi > 0 and rt.fuse_bn_backward and rt.lowp and wt and ud.cv.stride == 2 and ud.cv.R == 1 and u.cv.R == 1
-                      and u.cv.stride == 1 and u.cv.H % 2 == 0 and u.cv.W % 2 == 0 and not hip.is_deterministic() and rt.compact_shortcut):
+                      and u.cv.stride == 1 and u.cv.H % 2 == 0 and u.cv.W % 2 == 0 and not hip.is_deterministic() and rt.compact_shortcut
+                      and _wd(rt, ud.conv)[1]):          # (the shortcut's GEMM below reads the TRANSPOSED copy as [Cin][K]: it must exist)
                     # First block of a stride-2 stage (Bottleneck): the block-input gradient is conv1's dgrad (dense, full resolution) plus the
                     # strided 1 x 1 shortcut's dgrad, which only reaches every second pixel. The shortcut's gradient stays COMPACT ([N][H/2][W/2][Cin],
                     # one forward-form GEMM) and enters conv1's dgrad as a row-mapped residual (clite_epilogue.residual_subsample) of the

@@ -87,6 +87,7 @@ class TrainStep:
         # train_loop.main and bench.py switch it on; the constructor default stays off (tests build TrainStep directly).
         self.defer_update = bool(defer_update)
         self._pending_rest = False
+        self._rest_ev = None           # recorded on the side stream behind a deferred update_rest replay; the main stream waits on it before the heads
         if self.defer_update:          # readers of the parameters outside the step complete the update first (Arena.flush_pending)
             self.inner.arena.pending_update = self.finish
         self.graph_warmup = graph_warmup
@@ -107,9 +108,12 @@ class TrainStep:
             self._graphs["update_rest"].replay()
         main.wait_stream(side)
         self._pending_rest = False
+        self._rest_ev = None
 
     def _eager(self, batch):
+        # (another TrainStep on the same model may hold the pending share: Arena.flush_pending reaches whichever one registered last — ADVICE r4)
         self.finish()
+        self.inner.arena.flush_pending()
         self.eager_steps += 1
         self.optimizer.zero_grad()
         output_dict = self.model(batch)
@@ -323,12 +327,21 @@ class TrainStep:
                 capture("heads_t2", pool_side, heads_t2)
                 capture("heads_m2", pool_main, heads_m2)
                 capture("text_bwd", pool_side, text_bwd)
-                for i, sg in enumerate(segs):       # every segment's weight gradients but the last one's replay on the side stream
+                # Which stream replays a segment's grouped weight gradients: the side stream (behind BERT's backward) by default, the main stream (behind
+                # the whole chain) for the segments in `wgrad_main` ("1", "0,1": tools/ab_runtime.py step.wgrad_main=1) — always the last one. Measured with
+                # the folded BatchNorm backward (which shortens the chain): layer2's group on the main stream 15.03 ms against 14.86 on the side stream,
+                # same box — whatever runs beside the chain slows it by about what the move gains; the default stays the side stream.
+                on_main = self._wgrad_on_main = sorted(set(int(x) for x in str(getattr(self, "wgrad_main", "")).split(",") if x != "" and int(x) < len(segs) - 1) | {len(segs) - 1})
+                for i, sg in enumerate(segs):
                     capture("image_bwd_" + sg, pool_main, image_bwd(i))
-                    if i == 0:
+                    if i == 0 and (keep["wg_h"].items or keep["wg_h"].extra):          # (never an empty capture: the A/B switch defer_head_wgrads=0 leaves the group empty)
                         capture("wgrad_heads", pool_side, wgrad_heads)          # (capture order = replay order on a stream: shared pool)
-                    capture("wgrad_" + sg, pool_side if i < len(segs) - 1 else pool_main, wgrad(i))
-                capture("wgrad_last_extras", pool_side, wgrad_last_extras)
+                    if i not in on_main:
+                        capture("wgrad_" + sg, pool_side, wgrad(i))
+                for i in on_main:          # behind the chain, in segment order
+                    capture("wgrad_" + segs[i], pool_main, wgrad(i))
+                if keep["wg_" + segs[-1]].extra:
+                    capture("wgrad_last_extras", pool_side, wgrad_last_extras)
                 if self.clip and self.clip > 0:          # (without clipping there is no norm: an empty capture is not worth finding out about)
                     capture("norm_early", pool_main, norm_early)
                 capture("norm", pool_main, norm)
@@ -364,6 +377,11 @@ class TrainStep:
             G["heads_t1"].replay()                 # text half of the heads: hidden under the tail of the image forward
             side.wait_stream(main)                 # (the image features)
             G["heads_p1"].replay()                 # image prior discriminator, forward + backward ...
+        if self._rest_ev is not None:
+            # the deferred update_rest (side stream, start of this step) rewrites the loss module's parameters, which heads_b1 reads on THIS stream:
+            # only timing ordered the two (0.7 ms of update against 5 ms of image forward). The event has long fired by now: no cost
+            main.wait_event(self._rest_ev)
+            self._rest_ev = None
         G["heads_b1"].replay()                     # ... beside the image MI block's forward
         main.wait_stream(side)
         G["heads_m1"].replay()                     # critic forward + backward
@@ -374,26 +392,34 @@ class TrainStep:
         G["heads_m2"].replay()                     # image block backward, beside it
         if ex is not None:
             ex.reduce_span(*self._regions["text_encoder"], after=side)          # ordered after BERT's backward only (the event is taken now)
-        for i, sg in enumerate(self._segs[:-1]):   # a segment's weight gradients go to the side stream as soon as its chain is enqueued
+        on_main = self._wgrad_on_main
+        ev_early = None
+        for i, sg in enumerate(self._segs[:-1]):   # a segment's weight gradients go to the side stream as soon as its chain is enqueued (or wait for the chain's end: on_main)
             G["image_bwd_" + sg].replay()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 if i == 0:
                     # the image heads' weight gradients (collected by heads_p1 / heads_m2; the text heads' rode in BERT's group): behind BERT's
                     # backward and behind the main stream's heads_m2. Every gradient of the loss module is final after this launch
-                    G["wgrad_heads"].replay()
+                    if "wgrad_heads" in G:
+                        G["wgrad_heads"].replay()
                     if ex is not None:
                         ex.reduce_span(*self._regions["loss"], after=side)
-                G["wgrad_" + sg].replay()
+                if i not in on_main:
+                    G["wgrad_" + sg].replay()
                 if i == 0:
-                    ev_early = side.record_event()          # text encoder, loss heads, layer3 / layer4: every gradient of the norm's early spans is final
-            if ex is not None:                     # BatchNorm gradients came with the chain (main), weight gradients with the group (side, which waited for main)
+                    ev_early = side.record_event()          # text encoder, loss heads (+ layer3 / layer4 unless on_main): the side stream's share of the norm's early spans
+            if ex is not None and i not in on_main:   # BatchNorm gradients came with the chain (main), weight gradients with the group (side, which waited for main)
                 ex.reduce_span(*self._seg_spans[i], after=side)
         G["image_bwd_" + self._segs[-1]].replay()
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            G["wgrad_last_extras"].replay()        # three 3 x 3 weight gradients + the stem's, beside ...
-        G["wgrad_" + self._segs[-1]].replay()      # ... the grouped launch of the segment's 1 x 1 members
+            if "wgrad_last_extras" in G:
+                G["wgrad_last_extras"].replay()    # three 3 x 3 weight gradients + the stem's, beside ...
+        for i in on_main:                          # ... the grouped launches behind the chain
+            G["wgrad_" + self._segs[i]].replay()
+            if ex is not None and i < len(self._segs) - 1:
+                ex.reduce_span(*self._seg_spans[i], after=main)
         early_done = ex is None and getattr(self, "norm_overlap", True) and "norm_early" in G
         if early_done:
             main.wait_event(ev_early)
@@ -497,6 +523,7 @@ class TrainStep:
             if self._pending_rest:            # the deferred share of the previous step's update: ahead of this step's hyper-parameter upload
                 with torch.cuda.stream(feed):
                     self._graphs["update_rest"].replay()
+                    self._rest_ev = feed.record_event()
                 self._pending_rest = False
         for k, v in batch.items():
             if torch.is_tensor(v):

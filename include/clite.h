@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CLITE_ABI_VERSION 11
+#define CLITE_ABI_VERSION 12
 int clite_abi_version(void);
 
 /* Deterministic-reduction mode (process-wide, default off; the counterpart of torch.use_deterministic_algorithms for this library).
@@ -179,6 +179,9 @@ int clite_conv_wgrad_patch(const void* dy, const void* x, const clite_conv* cv, 
                                     * gradient arena zeroed and the step visits this weight once). A member whose contraction fits one K chunk — every BERT
                                     * matrix, the 7 x 7-resolution convolutions — then writes its result with plain stores instead of float atomics
                                     * (memory-side, ~1.3 TB/s chip-wide: 437 MB per step for BERT's 109 M parameters). Same values; without the flag `+=`. */
+#define CLITE_WGRAD_SHORTK 0x400   /* ABI v12, OR-ed into `kind`: K chunks of a quarter of the usual length — a member with a tiny output and a very long contraction (the
+                                    * folded BatchNorm backward's Gram matrix a^T a: 64 x 64 ... 128 x 128 outputs over 100k - 400k pixels), whose few long workgroups
+                                    * would otherwise be the tail of the launch; more chunks cost only more float atomics into that tiny output */
 typedef struct clite_wgrad_item {
   int32_t kind;
   const void* a;
@@ -186,6 +189,9 @@ typedef struct clite_wgrad_item {
   float* out;
   clite_conv cv;                 /* kind 0 */
   int32_t M, N, K, lda, ldb, ldc;  /* kind 1 */
+  const float* row_scale;        /* ABI v12. NULL, or device f32 [rows of out]: out[r][:] += row_scale[r] * (A^T B)[r][:] — the folded BatchNorm backward's
+                                  * per-channel factor ka (clite_bn_fold_prepare) on a weight gradient contracted against dz instead of dy. Grouped
+                                  * launches only: -1 where the members run one by one (f32, deterministic mode, no workspace). */
 } clite_wgrad_item;
 int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n, void* ws_dev, void* ws_host, uint64_t ws_bytes, void* stream);
 int clite_wgrad_group_workspace(int n_items, int64_t total_workgroups, uint64_t* bytes);
@@ -290,6 +296,12 @@ typedef struct clite_bn {
   uint8_t* fp8_out;
   const float* fp8_scale;
   float* fp8_amax;
+  /* ABI v12, clite_bn_apply only (bf16, without the fp8 fields): out_sum[(b % out_sum_replicas) * out_sum_stride + c] += sum over workgroup b's rows of
+   * out[m][c] as stored — the column sums of the activation that the folded BatchNorm backward's weight gradient needs (clite_bn_fold_wgrad_finish),
+   * taken by the pass that writes it instead of a pass of their own. ZERO on entry. NULL: not accumulated. */
+  float* out_sum;
+  int32_t out_sum_replicas;
+  int32_t out_sum_stride;
 } clite_bn;
 
 /* Second pass of a two-pass variance (used by the exact-f32 parity mode): stats[2][c] += sum_m (y[m][c] - stats[0][c]/M)^2;
@@ -305,6 +317,34 @@ int clite_bn_bwd_reduce(int dtype, const void* dout, const void* mask, const uin
 /* dy = BN backward of dz through batch statistics; dz (optional) <- masked dout; dgamma/dbeta (optional) += . */
 int clite_bn_bwd_apply(const clite_bn* p, int dtype, const void* dout, const void* mask, const uint8_t* mask_bits, const void* y, const float* dstats,
                        void* dy, void* dz, float* dgamma, float* dbeta, void* stream);
+
+/* ---- ABI v12: the block-output BatchNorm backward FOLDED into its consumers (bf16; reference model_zoo/resnet.py:60-100 block arithmetic, autograd of
+ * encoder.py:63's torchvision Bottleneck: bn3 backward -> conv3 input gradient + conv3 weight gradient). BatchNorm backward is linear in dz:
+ *     dy = ka . dz + kb + kc . (y - mean),   ka = gamma rstd,  kb = -ka S1 / M,  kc = -ka rstd^2 S2 / M     (per channel k; S1 = sum dz, S2 = sum dz (y - mean))
+ * so for the 1 x 1 convolution y = a W^T (W [K][Cin]) that produced y
+ *     da = dy W          = [dz | y] [diag(ka) W ; diag(kc) W] + (kb - kc . mean) W       one GEMM over the K-concatenation of dz and y, a bias row
+ *     dW = dy^T a        = diag(ka) (dz^T a) + kb (x) colsum(a) + diag(kc) W Cov(a),     Cov(a) = a^T a - colsum(a) colsum(a)^T / M   (y = a W^T, mean = colsum(a) W^T / M)
+ * and the apply pass (read dz, read y, write dy) with its dy tensor disappears: the dgrad reads dz and y instead of dy, the weight gradient reads dz instead of dy.
+ *
+ * clite_bn_fold_prepare: from the BatchNorm's forward sums `p->stats`, its two backward reductions `dstats` (same replica layout) and the TRANSPOSED bf16
+ * weights wt [Cin][K] (K = p->C) makes, in one launch of Cin workgroups:
+ *   w2   bf16 [Cin][2][K]   w2[c][0][k] = bf16(kc[k] wt[c][k]) (multiplies y), w2[c][1][k] = bf16(ka[k] wt[c][k]) (multiplies dz): clite_conv_dgrad_bnfold's weights
+ *   bias f32  [Cin]         sum_k kb[k] wt[c][k] - sum_k mean[k] w2[c][0][k]   (with the ROUNDED w2: sum_k (y - mean) w2 then cancels exactly as in y - mean)
+ *   coef f32  [3][K]        ka, kb, kc
+ *   dgamma[k] += rstd S2, dbeta[k] += S1 (either may be NULL). */
+int clite_bn_fold_prepare(const clite_bn* p, const float* dstats, const void* wt, int Cin, void* w2, float* bias, float* coef, float* dgamma, float* dbeta,
+                          void* stream);
+/* da [M][Cin] = [pair[0] | pair[1]] [w2[:, 1, :] | w2[:, 0, :]]^T + ep->bias through the BatchNorm-backward form of the epilogue (relu_bits + bn_y + colsum:
+ * the NEXT BatchNorm backward's mask and reductions), i.e. what clite_bn_bwd_apply followed by clite_conv_dgrad_wt computes. pair = bf16 [2][M][K]: slot 0 the
+ * masked gradient dz, slot 1 the BatchNorm input y (the producer of each writes it there). K % 64 == 0, Cin % 8 == 0, 2 M K < 2^31. */
+int clite_conv_dgrad_bnfold(const void* pair, const void* w2, int M, int K, int Cin, const clite_epilogue* ep, void* stream);
+/* Weight-gradient side: the two correction terms, in f32, with G = a^T a (f32 [Cin][Cin], left by a member of the grouped launch) and the column sums
+ * s[c] = sum_r asum[r * asum_stride + c] (clite_bn.out_sum of the clite_bn_apply that wrote a):
+ *   dw[k][c] += kb[k] s[c] + kc[k] sum_c' wt[c'][k] (G[c'][c] - s[c'] s[c] / M)                  (float atomics: the member that accumulates ka (dz^T a) may run beside it)
+ * The rank-1 term cancels against ka (dz^T a) wherever dz has a mean: nothing here is rounded to bf16. */
+int clite_bn_fold_wgrad_finish(const float* G, const float* asum, int asum_replicas, int asum_stride, const float* coef, const void* wt, int M, int K, int Cin,
+                               float* dw, void* stream);
+
 
 /* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem; idx holds the window position (0..8) of the first maximum. */
 int clite_maxpool3x3s2_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream);

@@ -313,3 +313,87 @@ def test_resnet50_bert_bf16_backward_against_fp32_oracle():
     print("worst weight-gradient relative L2:", worst, cos)
     assert worst[1] <= 0.5, worst
     assert all(c >= 0.93 for c in cos.values()), cos
+
+
+# the four conv3 -> bn3 shapes of ResNet-50 at batch 128: rows, K = 4 x width, Cin = width; + a ragged small one (partial tiles)
+@pytest.mark.parametrize("policy,M,K,Cin", [(0, 401408, 256, 64), (0, 100352, 512, 128), (0, 25088, 1024, 256), (0, 6272, 2048, 512), (0, 3000, 128, 64),
+                                            (4, 100352, 512, 128), (2, 25088, 1024, 256), (1, 3000, 128, 128)])
+def test_folded_batchnorm_backward_matches_torch_bn_backward_then_conv_backward(policy, M, K, Cin):
+    """The block-output BatchNorm backward folded into conv3's two gradients (include/clite.h ABI v12: clite_bn_fold_prepare, clite_conv_dgrad_bnfold,
+    clite_wgrad_item.row_scale, clite_bn.out_sum, clite_bn_fold_wgrad_finish) against a plain torch fp32 evaluation of batch_norm backward followed by the 1 x 1 convolution's
+    backward on the same bf16-rounded tensors: the masked input gradient dz2 and its two reductions (the next BatchNorm backward's), the weight gradient,
+    dgamma / dbeta. Bars: 4e-3 of max on dz2 (one bf16 rounding on top of the existing 2e-3 bar), 5e-3 on its reductions, 2e-3 of max on the weight gradient
+    and on dgamma / dbeta."""
+    hip = _hip()
+    hip.set_tile_policy(policy)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(M + K)
+        a = torch.relu(torch.randn(M, Cin, device="cuda", generator=g) + 0.3).bfloat16()          # conv3's input: post-ReLU activation
+        W = (torch.randn(K, Cin, device="cuda", generator=g) * (2.0 / Cin) ** 0.5).bfloat16()
+        y = (a.float() @ W.float().t()).bfloat16()                                                 # what conv3's forward stored
+        dz = (torch.randn(M, K, device="cuda", generator=g) * 0.1 + 0.02 * torch.randn(K, device="cuda", generator=g)).bfloat16()
+        dz = dz * (torch.rand(M, K, device="cuda", generator=g) > 0.4)                              # masked by the block output's relu'
+        gamma = torch.rand(K, device="cuda", generator=g) + 0.5
+        R = 2
+        st = hip.Stats(torch.zeros(R, 3, K, device="cuda"), R, K)
+        st.t[:, 0] = y.float().sum(0) / R
+        st.t[:, 1] = (y.float() ** 2).sum(0) / R
+        mean = y.float().mean(0)
+        var = ((y.float() ** 2).mean(0) - mean * mean).clamp_min(0)
+        rstd = torch.rsqrt(var + 1e-5)
+        pre = hip.Stats(torch.zeros(R, 3, K, device="cuda"), R, K)
+        S1, S2 = dz.float().sum(0), (dz.float() * (y.float() - mean)).sum(0)
+        pre.t[:, 0], pre.t[:, 1] = S1 / R, S2 / R
+        # reference (fp32): BatchNorm backward, then the convolution's two gradients
+        xhat = (y.float() - mean) * rstd
+        dy = gamma * rstd * (dz.float() - S1 / M - xhat * (dz.float() * xhat).sum(0) / M)
+        da_ref = dy @ W.float()
+        dW_ref = dy.t() @ a.float()
+        dgamma_ref, dbeta_ref = (dz.float() * xhat).sum(0), S1
+        # the unit in front (bn2): its input, forward sums and relu' bits
+        y2 = (torch.randn(M, Cin, device="cuda", generator=g) + 1.0).bfloat16()
+        st2 = hip.Stats(torch.zeros(R, 3, Cin, device="cuda"), R, Cin)
+        st2.t[:, 0] = y2.float().sum(0) / R
+        mean2 = y2.float().mean(0)
+        mask = torch.rand(M, Cin, device="cuda", generator=g) > 0.3
+        bits = torch.from_numpy(np.packbits(mask.cpu().numpy(), axis=-1, bitorder="little")).cuda()
+        # HIP
+        pair = torch.empty(2, M, K, device="cuda", dtype=torch.bfloat16)
+        pair[0], pair[1] = dz, y
+        rm, rv = torch.zeros(K, device="cuda"), torch.ones(K, device="cuda")
+        dgamma, dbeta = torch.zeros(K, device="cuda"), torch.zeros(K, device="cuda")
+        desc = hip.bn_desc(M, K, st, gamma, torch.zeros(K, device="cuda"), rm, rv, True, False, 0.1, 1e-5, False)
+        f = hip.bn_fold_prepare(desc, pre, W.t().contiguous(), Cin, dgamma, dbeta)
+        dz2 = torch.empty(M, Cin, device="cuda", dtype=torch.bfloat16)
+        d2 = hip.Stats(torch.zeros(R, 3, Cin, device="cuda"), R, Cin)
+        hip.conv_dgrad_bnfold(pair, f.w2, M, K, Cin, hip.epilogue(dz2, Cin, relu_bits=bits, colsum=d2, bn=(y2, st2, M), bias=f.bias))
+        want = da_ref * mask
+        assert _rel(dz2, want) < 4e-3
+        stored = dz2.float()
+        got = d2.t.sum(0)
+        assert _rel(got[0], stored.sum(0)) < 5e-3 and _rel(got[1], (stored * (y2.float() - mean2)).sum(0)) < 5e-3
+        assert _rel(dgamma, dgamma_ref) < 2e-3 and _rel(dbeta, dbeta_ref) < 2e-3
+        # weight gradient: the grouped launch (ka . dz^T a, the Gram matrix) + the two correction terms
+        dw = torch.zeros(K, Cin, device="cuda")
+        G = torch.zeros(Cin, Cin, device="cuda")
+        # colsum(a) as clite_bn_apply leaves it (clite_bn.out_sum): an identity BatchNorm + ReLU over a reproduces a and sums its columns
+        asum = hip.Stats(torch.zeros(R, 3, Cin, device="cuda"), R, Cin)
+        ist = hip.Stats(torch.zeros(R, 3, Cin, device="cuda"), R, Cin)
+        ist.t[:, 1] = M * (1.0 - 1e-5) / R          # mean 0, var + eps = 1
+        a_out = torch.empty_like(a)
+        one, zero = torch.ones(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+        hip.bn_apply(BF16, hip.bn_desc(M, Cin, ist, one, zero, zero.clone(), one.clone(), True, False, 0.1, 1e-5, True, out_sum=asum), a, None, a_out)
+        assert torch.equal(a_out, a)
+        assert _rel(asum.t[:, 0].sum(0), a.float().sum(0)) < 1e-4
+        cv = hip.conv_desc(BF16, 1, 1, M, Cin, K, 1, 1, 1, 0)
+        grp = hip.WgradGroup(BF16)
+        grp.conv(dz, a, cv, dw, row_scale=f.coef[0])
+        grp.conv(a, a, hip.conv_desc(BF16, 1, 1, M, Cin, Cin, 1, 1, 1, 0), G)
+        Wt = W.t().contiguous()
+        grp.after(lambda: hip.bn_fold_wgrad_finish(G, asum, f.coef, Wt, M, K, Cin, dw))
+        grp.launch()
+        torch.cuda.synchronize()
+        assert _rel(G, a.float().t() @ a.float()) < 1e-3
+        assert _rel(dw, dW_ref) < 2e-3, _rel(dw, dW_ref)
+    finally:
+        hip.set_tile_policy(0)

@@ -12,12 +12,12 @@ from detfill import det_fill
 pytestmark = pytest.mark.gpu
 
 
-def _model(lowp=False):
+def _model(lowp=False, mode="sbert"):
     from clip_lite_amd.encoder import ImageEncoder, TextEncoder
     from clip_lite_amd.loss import JSDInfoMaxLoss
     from clip_lite_amd.model import VLInfoModel
-    te = TextEncoder(mode="sbert", num_hidden_layers=1)
-    return det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "sbert", is_amp=lowp)).to("cuda").train()
+    te = TextEncoder(mode=mode, num_hidden_layers=1)
+    return det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), mode, is_amp=lowp)).to("cuda").train()
 
 
 def _groups(named):
@@ -92,3 +92,45 @@ def test_optimizer_factory_builds_adamw_and_it_trains_through_the_captured_step(
     torch.cuda.synchronize()
     assert step.graph and step.replays >= 1 and all(np.isfinite(l) for l in losses)
     assert losses[-1] < losses[0], losses
+
+
+def test_adamw_per_phase_graphs_with_deferred_update_match_the_eager_step_bitwise():
+    """the test above builds an `sbert` model, which TrainStep captures as ONE graph (no per-phase graphs, defer_update without effect). Here
+    the model is `train_sbert` (token ids, a BERT layer in the loop), i.e. the path train_loop.main takes: per-phase graphs, FusedAdamW.launch(span=...) split
+    into update_img / update_rest, the text encoder's and the heads' share deferred to the start of the next step — incl. the ordering of the
+    bias-correction hyper-parameter upload against the deferred share. In the deterministic-reduction mode the parameters and both moments after
+    finish() must equal the eager launches of the same six steps bit for bit (dropout and prior noise on: eager and replayed steps draw the same masks)."""
+    from clip_lite_amd import hip
+    from clip_lite_amd.optim import FusedAdamW, Lookahead
+    from clip_lite_amd.optim.lr_scheduler import LinearWarmupCosineAnnealingLR
+    from clip_lite_amd.train_loop import TrainStep
+    from clip_lite_amd.utils.common import GradScaler
+    from detfill import det_tensor
+    B, L = 8, 10
+    batches = []
+    for i in range(3):
+        ids = torch.randint(1000, 30522, (B, L), generator=torch.Generator().manual_seed(40 + i))
+        batches.append({"image": det_tensor(f"aw_img{i}", (B, 3, 64, 64), "normal").cuda(), "input_ids": ids.cuda(),
+                        "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()})
+    hip.set_deterministic(True)
+    try:
+        res = []
+        for graph in (False, True):
+            torch.manual_seed(11)
+            M = _model(lowp=True, mode="train_sbert")
+            opt = Lookahead(FusedAdamW(_groups(list(M.named_parameters()))), k=3, alpha=0.5)
+            sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=2)
+            step = TrainStep(M, opt, sched, GradScaler(True), 1.0, None, graph=graph, graph_warmup=2, defer_update=graph)
+            losses = [step(batches[s % 3])["loss"].item() for s in range(6)]
+            if graph:
+                assert step._graphs is not None and step.replays == 4 and step._pending_rest
+            step.finish()
+            torch.cuda.synchronize()
+            A = M.runtime.arena
+            assert not A.flat_g.any()
+            res.append((losses, A.flat_p.clone(), opt.optimizer.flat_v.clone(), opt.optimizer.flat_v2.clone(), A.flat_lp.clone()))
+    finally:
+        hip.set_deterministic(False)
+    (l0, p0, v0, w0, lp0), (l1, p1, v1, w1, lp1) = res
+    assert l0 == l1
+    assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(w0, w1) and torch.equal(lp0, lp1)

@@ -592,7 +592,7 @@ def test_deferred_update_is_bit_identical_after_finish():
         batches.append({"image": det_tensor(f"gimg{i}", (B, 3, 64, 64), "normal").cuda(), "input_ids": ids.cuda(),
                         "attention_mask": torch.ones(B, L, dtype=torch.long).cuda()})
     res = []
-    for defer in (False, True):
+    for defer, delay in ((False, False), (True, False), (True, True)):
         torch.manual_seed(7)
         te = TextEncoder(mode="train_sbert", num_hidden_layers=2)
         M = det_fill(VLInfoModel(te, ImageEncoder("resnet18"), JSDInfoMaxLoss(512, 768, "dot", 0.1, True, True), "train_sbert", is_amp=True)).to("cuda").train()
@@ -600,7 +600,15 @@ def test_deferred_update_is_bit_identical_after_finish():
         opt = Lookahead(FusedSGD(groups, momentum=0.9), k=3, alpha=0.5)
         sched = LinearWarmupCosineAnnealingLR(opt, total_steps=40, warmup_steps=3)
         step = TrainStep(M, opt, sched, GradScaler(True), 10.0, None, graph=True, graph_warmup=2, defer_update=defer)
-        losses = [step(batches[s % 3])["loss"].item() for s in range(6)]
+        losses = []
+        for s in range(6):
+            if delay:
+                # the deferred update replays on the SIDE stream at the start of the next step and rewrites the loss heads' parameters,
+                # which the main stream's heads_b1 reads. Hold the side stream back (~20 ms of spinning, far longer than this image forward):
+                # without the event hand-over the heads would read stale weights and the losses below would differ
+                with torch.cuda.stream(M.runtime.side_stream):
+                    torch.cuda._sleep(50_000_000)
+            losses.append(step(batches[s % 3])["loss"].item())
         A = M.runtime.arena
         if defer:
             assert step._pending_rest and step.replays == 4
@@ -615,9 +623,10 @@ def test_deferred_update_is_bit_identical_after_finish():
         torch.cuda.synchronize()
         assert not step._pending_rest and not A.flat_g.any()
         res.append((losses, A.flat_p.clone(), opt.optimizer.flat_v.clone(), opt.optimizer.flat_slow.clone(), A.flat_lp.clone()))
-    (l0, p0, v0, s0, lp0), (l1, p1, v1, s1, lp1) = res
-    assert l0 == l1
-    assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(s0, s1) and torch.equal(lp0, lp1)
+    (l0, p0, v0, s0, lp0) = res[0]
+    for (l1, p1, v1, s1, lp1) in res[1:]:
+        assert l0 == l1
+        assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(s0, s1) and torch.equal(lp0, lp1)
 
 
 @pytest.mark.gpu

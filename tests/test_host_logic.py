@@ -20,7 +20,7 @@ def test_c_abi_library_exports_header_symbols():
     declared = sorted(set(re.findall(r"\bint (clite_\w+)\(", hdr)))
     assert declared == hip.exported_symbols()
     lib = hip.lib()                     # dlopen + bind every symbol + ABI version check
-    assert lib.clite_abi_version() == hip.ABI_VERSION == 11
+    assert lib.clite_abi_version() == hip.ABI_VERSION == 12
     raw = C.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name

@@ -19,6 +19,10 @@ def main():
     from clip_lite_amd.utils.common import GradScaler
     device = torch.device("cuda", 0)
     model, opt, sched = bench.build(args, device)
+    for kv in sys.argv[1:]:          # runtime switches, as tools/ab_runtime.py: attr=value on the DeviceRuntime
+        k_, v_ = kv.split("=")
+        old = getattr(model.runtime, k_)
+        setattr(model.runtime, k_, type(old)(int(v_)))
     step = TrainStep(model, opt, sched, GradScaler(True), 10.0, None, graph=True)
     batches = bench.synthetic_batches(args, device, 0)
     for i in range(6):
