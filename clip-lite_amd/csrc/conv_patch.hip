@@ -552,17 +552,6 @@ constexpr int SW_STAGE = SW_DYB + SW_XB;
 constexpr int SW_OUT = 64 * 224;
 static_assert(2 * SW_STAGE <= 160 * 1024 && SW_OUT * 4 <= 2 * SW_STAGE && 3 * SW_STAGE <= 160 * 1024, "LDS budget");
 
-// What the FUSED form adds (stem_bwd_fused: bn1's backward formed in LDS instead of read from memory): the operands of stem_bn_pool_bwd_apply
-struct StemFuse {
-  clite_bn p;                           // bn1: forward statistics, gamma (M = N Ho Wo of the un-pooled tensor)
-  const void* dpool;                    // [N][Hq][Wq][64] pooled gradient (already masked by relu' of the pooled output)
-  const uint8_t* idx;                   // [N][Hq][Wq][64] window argmax
-  const void* y;                        // [N][Ho][Wo][64] conv1 output (the BatchNorm input)
-  const float* dstats;                  // the two backward reductions (replicated like p.stats)
-  float* dgamma;
-  float* dbeta;
-  int Hq, Wq;
-};
 struct StemWgradArgs {
   const void* dy;
   const void* x;
@@ -578,12 +567,8 @@ struct StemWgradArgs {
 #ifndef CLITE_STEM_WGRAD_NW
 #define CLITE_STEM_WGRAD_NW 4
 #endif
-// FUSED (NW = 4): the dy strip is not loaded but FORMED - every thread gathers the pooled gradients of its 7 (pixel, 8-channel) chunks
-// (stem_bn.h: stem_dz, the same routine stem_bn_pool_bwd_apply runs), applies bn1's backward with the reductions the caller supplies and writes the
-// bf16 values into the strip's LDS image, where the K loop reads them. The un-pooled gradient (205 MB at batch 128) is then neither written nor read.
-template <int NW, bool FUSED = false>
-__global__ __launch_bounds__(NW * 64, FUSED ? 2 : 1) void stem_wgrad_patch_kernel(StemWgradArgs a, int strips_per_wg, StemFuse f) {
-  static_assert(!FUSED || NW == 4, "the fused form is the single-stage one");
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void stem_wgrad_patch_kernel(StemWgradArgs a, int strips_per_wg) {
   constexpr int NSTG = NW == 8 ? 2 : 1;
   constexpr int KSTEP = NW == 8 ? 2 : 1;
   __shared__ __attribute__((aligned(1024))) char smem[NSTG * SW_STAGE];
@@ -607,13 +592,11 @@ __global__ __launch_bounds__(NW * 64, FUSED ? 2 : 1) void stem_wgrad_patch_kerne
     const int oy0 = (strip - n * a.strips_per_img) * 2;
     const int rows = a.Ho - oy0 < 2 ? a.Ho - oy0 : 2;          // (an odd Ho leaves a one-row strip: its second row gathers as zeros)
     const uint32_t dbase = (uint32_t)((n * a.Ho + oy0) * a.Wo) * PIXB;
-    if constexpr (!FUSED) {
-      for (int i = wave; i < ndy; i += NW) {
-        const int pix = i * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
-        const bool v = pix < rows * a.Wo;
-        PATCH_LOAD(rdy, v ? dbase + (uint32_t)(pix * PIXB + chunk * 16) : OOB_OFF, dst + i * 1024);
-      }
+    for (int i = wave; i < ndy; i += NW) {
+      const int pix = i * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ (((pix >> 1) & 1) << 2);
+      const bool v = pix < rows * a.Wo;
+      PATCH_LOAD(rdy, v ? dbase + (uint32_t)(pix * PIXB + chunk * 16) : OOB_OFF, dst + i * 1024);
     }
     // the patch: 9 input rows from row 2 oy0, as they lie (rows past the image's padded height read as zeros: the buffer's bound, and for an image
     // that is not the last the one-row strip's second output row is masked by its zero dy)
@@ -622,49 +605,6 @@ __global__ __launch_bounds__(NW * 64, FUSED ? 2 : 1) void stem_wgrad_patch_kerne
     for (int i = wave; i < nx; i += NW) {
       const uint32_t off = xbase + (uint32_t)(i * 1024 + lane * 16);
       PATCH_LOAD(rx, (i * 1024 + lane * 16 < xbytes_strip && off < xend) ? off : OOB_OFF, dst + SW_DYB + i * 1024);
-    }
-  };
-
-  // FUSED: bn1's backward coefficients of this thread's 8 channels (dy = ka dz + kb + kc (y - mean)), as stem_bn_pool_bwd_apply_kernel forms them
-  const int fc0 = (tid & 7) * 8;
-  BnCoef fk;
-  float fmean[8], fka[8], fkb[8], fkc[8];
-  if constexpr (FUSED) {
-    const float inv_count = 1.0f / (float)f.p.M;
-    float var[8], S1[8], S2[8];
-    bn_coef(f.p.stats, f.p.replicas, f.p.rstride, f.p.gamma, f.p.beta, f.p.running_mean, f.p.running_var, 1, f.p.centered, inv_count, f.p.eps, 64, fc0, fk, fmean, var);
-    rsum8(f.dstats + fc0, f.p.replicas, f.p.rstride, S1);
-    rsum8(f.dstats + 64 + fc0, f.p.replicas, f.p.rstride, S2);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float rstd = rsqrtf(var[e] + f.p.eps);
-      const float G = rstd * S2[e];
-      const float ga = f.p.gamma[fc0 + e] * rstd;
-      fka[e] = ga;
-      fkc[e] = -ga * rstd * G * inv_count;
-      fkb[e] = -ga * S1[e] * inv_count;
-      if (blockIdx.x == 0 && tid < 8) {
-        if (f.dgamma) f.dgamma[fc0 + e] += G;
-        if (f.dbeta) f.dbeta[fc0 + e] += S1[e];
-      }
-    }
-  }
-  auto form_dy = [&](int strip, char* dst) {
-    const int n = strip / a.strips_per_img;
-    const int oy0 = (strip - n * a.strips_per_img) * 2;
-    // the strip's two rows are one row of 2 x 2 pixel groups (strips start on even rows): stem_dz4 - four window loads serve a group's four pixels
-    for (int gj = tid >> 3; gj < (a.Wo >> 1); gj += NW * 8) {
-      float dz[4][8], yc[4][8];
-      stem_dz4((const bf16*)f.dpool, f.idx, (const bf16*)f.y, n, oy0 >> 1, gj, a.Ho, a.Wo, f.Hq, f.Wq, 64, fc0, fmean, fk, dz, yc);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int oyl = q >> 1, pix = oyl * a.Wo + 2 * gj + (q & 1);
-        const bool live = oy0 + oyl < a.Ho;          // (an odd Ho: the last strip's second row does not exist - zeros)
-        Chunk16 ch;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ch.e[e] = f2bf(live ? fka[e] * dz[q][e] + fkb[e] + fkc[e] * yc[q][e] : 0.f);
-        *(u32x4*)(dst + pix * PIXB + (((tid & 7) ^ (((pix >> 1) & 1) << 2)) << 4)) = ch.u;
-      }
     }
   };
 
@@ -683,7 +623,6 @@ __global__ __launch_bounds__(NW * 64, FUSED ? 2 : 1) void stem_wgrad_patch_kerne
     if (NSTG == 1) {
       if (strip > s_begin) lds_barrier();          // every wave is past the K loop that read the stage
       issue(strip, smem);
-      if constexpr (FUSED) form_dy(strip, smem);          // (its gathers run beside the patch's DMA)
     }
     wait_vmcnt<0>();
     lds_barrier();          // the strip's images landed (every wave's part); (two stages:) every wave is past the K loop that read the other stage
@@ -786,34 +725,7 @@ int clite::launch_stem_wgrad_patch(const void* dy, const void* xpad, int N, int 
   const int grid = a.nstrips < WGS ? a.nstrips : WGS;
   const int per = (a.nstrips + grid - 1) / grid;
   const int g2 = (a.nstrips + per - 1) / per;
-  hipLaunchKernelGGL((stem_wgrad_patch_kernel<CLITE_STEM_WGRAD_NW, false>), dim3(g2), dim3(CLITE_STEM_WGRAD_NW * 64), 0, st, a, per, StemFuse{});
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 147 + 255) / 256, 8), dim3(256), 0, st, (const float*)ws, dw, g2);
-  return (int)hipGetLastError();
-}
-
-int clite::launch_stem_bwd_fused(const clite_bn& p, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, const void* xpad, int N, int Hp, int Wp,
-                                 int Ho, int Wo, float* dw, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t st) {
-#ifdef CLITE_NO_PATCH
-  return WIDE_NOT_TAKEN;
-#endif
-  constexpr int WGS = 2 * CLITE_PATCH_WGS;          // two workgroups per CU (the gather's coefficients cost the third its registers)
-  if (p.C != 64 || Wo % 16 || 2 * Wo > SW_MAXPIX || 10 * Wp * 8 + 128 > SW_XB || Hp < 2 * (Ho - 1) + 7 || Wp < 2 * (Wo - 1) + 8) return WIDE_NOT_TAKEN;
-  if (!ws || ws_bytes < (size_t)WGS * SW_OUT * sizeof(float)) return WIDE_NOT_TAKEN;
-  if ((size_t)N * Ho * Wo * PIXB >= 0xF0000000ull || (size_t)N * Hp * Wp * 8 >= 0xF0000000ull) return WIDE_NOT_TAKEN;
-  StemWgradArgs a;
-  a.dy = nullptr; a.x = xpad;
-  a.dybytes = 0; a.xbytes = (uint32_t)((size_t)N * Hp * Wp * 8);
-  a.N = N; a.Hp = Hp; a.Wp = Wp; a.Ho = Ho; a.Wo = Wo;
-  a.strips_per_img = (Ho + 1) / 2;
-  a.nstrips = N * a.strips_per_img;
-  a.ws = (float*)ws;
-  StemFuse f;
-  f.p = p; f.dpool = dpool; f.idx = idx; f.y = y; f.dstats = dstats; f.dgamma = dgamma; f.dbeta = dbeta;
-  f.Hq = (Ho + 2 - 3) / 2 + 1; f.Wq = (Wo + 2 - 3) / 2 + 1;
-  const int grid = a.nstrips < WGS ? a.nstrips : WGS;
-  const int per = (a.nstrips + grid - 1) / grid;
-  const int g2 = (a.nstrips + per - 1) / per;
-  hipLaunchKernelGGL((stem_wgrad_patch_kernel<4, true>), dim3(g2), dim3(256), 0, st, a, per, f);
+  hipLaunchKernelGGL((stem_wgrad_patch_kernel<CLITE_STEM_WGRAD_NW>), dim3(g2), dim3(CLITE_STEM_WGRAD_NW * 64), 0, st, a, per);
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 147 + 255) / 256, 8), dim3(256), 0, st, (const float*)ws, dw, g2);
   return (int)hipGetLastError();
 }

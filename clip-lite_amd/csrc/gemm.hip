@@ -839,17 +839,6 @@ extern "C" int clite_stem_wgrad_patch(const void* dy, const void* xpad, int dtyp
   return rc == WIDE_NOT_TAKEN ? 1 : rc;
 }
 
-// bn1's backward + conv1's weight gradient in one kernel (conv_patch.hip: the un-pooled gradient lives in LDS only). Same return convention.
-extern "C" int clite_stem_bwd_fused(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, const void* xpad,
-                                    int N, int Hp, int Wp, int Ho, int Wo, float* dw, float* dgamma, float* dbeta, void* ws, uint64_t ws_bytes, void* stream) {
-  if (check_stem(dtype, N, Hp, Wp, Ho, Wo) || !p || !dpool || !idx || !y || !dstats || !xpad || !dw || p->M != N * Ho * Wo || p->C != 64 || p->replicas < 1 || !p->stats ||
-      !p->gamma)
-    return -1;
-  if (dtype != CLITE_BF16 || deterministic() || tile_policy_value() != 0) return 1;
-  const int rc = launch_stem_bwd_fused(*p, dpool, idx, y, dstats, xpad, N, Hp, Wp, Ho, Wo, dw, dgamma, dbeta, ws, (size_t)ws_bytes, (hipStream_t)stream);
-  return rc == WIDE_NOT_TAKEN ? 1 : rc;
-}
-
 extern "C" int clite_stem_fwd(const void* xpad, const void* wv, int dtype, int N, int Hp, int Wp, int Ho, int Wo, const clite_epilogue* ep, void* stream) {
   if (check_stem(dtype, N, Hp, Wp, Ho, Wo) || check_ep(ep, 64)) return -1;
   return dtype == CLITE_BF16 ? stem_fwd<bf16>(xpad, wv, N, Hp, Wp, Ho, Wo, ep, (hipStream_t)stream)

@@ -25,8 +25,7 @@ size_t conv3x3_wgrad_patch_workspace();
 int launch_conv3x3_wgrad_patch(const void* dy, const void* x, const clite_conv& c, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // the stem's weight gradient on the same scheme (dw f32 [64][7][7][3] +=; the same workspace serves)
 // ... and fused with bn1's backward (the un-pooled gradient formed in LDS from the pooled gradient, the window indices and conv1's output)
-int launch_stem_bwd_fused(const clite_bn& p, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, const void* xpad, int N, int Hp, int Wp,
-                          int Ho, int Wo, float* dw, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t st);
+
 int launch_stem_wgrad_patch(const void* dy, const void* xpad, int N, int Hp, int Wp, int Ho, int Wo, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
 // the tile policy set by clite_set_tile_policy (gemm_wide.hip): 0 = automatic; the forced forms keep every launch on the kernel family they name
 int tile_policy_value();

@@ -102,7 +102,6 @@ _SIGNATURES = {
     "clite_stem_fwd": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
     "clite_stem_wgrad": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V],
     "clite_stem_wgrad_patch": [_V, _V, _I, _I, _I, _I, _I, _I, _V, _V, _U64, _V],
-    "clite_stem_bwd_fused": [_V, _I, _V, _V, _V, _V, _V, _I, _I, _I, _I, _I, _V, _V, _V, _V, _U64, _V],
     "clite_stem_pack": [_V, _V, _I, _V],
     "clite_stem_unpack_grad": [_V, _V, _V],
     "clite_bn_apply": [_V, _I, _V, _V, _V, _V],
@@ -639,19 +638,6 @@ def stem_wgrad_patch(dt, dy, xpad, N, Hp, Wp, Ho, Wo, dw):
     if rc == 1:
         return False
     check(rc, "stem_wgrad_patch")
-    return True
-
-
-def stem_bwd_fused(dt, bn, dpool, idx, y, dstats, xpad, N, Hp, Wp, Ho, Wo, dw, dgamma, dbeta):
-    """bn1's backward and conv1's weight gradient in one kernel (include/clite.h: clite_stem_bwd_fused). False: not covered, nothing launched."""
-    ws = _patch_ws.get(_indexed(y.device))
-    if ws is None:
-        return False
-    rc = lib().clite_stem_bwd_fused(C.byref(bn), dt, p(dpool), p(idx), p(y), p(dstats.t), p(xpad), N, Hp, Wp, Ho, Wo, p(dw), p(dgamma), p(dbeta), p(ws), ws.numel(),
-                                    stream_ptr(y))
-    if rc == 1:
-        return False
-    check(rc, "stem_bwd_fused")
     return True
 
 

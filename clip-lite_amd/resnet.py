@@ -537,9 +537,6 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                             centered=rt.precise_bn)
         dg = rt.arena.g(bn1.weight) if bn1.weight.requires_grad else None
         db = rt.arena.g(bn1.bias) if bn1.bias.requires_grad else None
-        if (stem_pre is not None and rt.stem_bwd_fused and rt.lowp and net.conv1.weight.requires_grad
-                and hip.stem_bwd_fused(dt, desc0, dout, idx, y0, stem_pre, xpad, N, Hp, Wp, Ho, Wo, rt.arena.g(net.conv1.weight), dg, db)):
-            return          # one kernel: the un-pooled gradient existed in LDS only
         dst0 = rt.new_stats(64, N * Ho * Wo)
         dy0 = _alloc(rt, N * Ho * Wo, 64)
         if stem_pre is not None:          # the reductions came out of the epilogue that wrote `dout` (already masked by relu'(pooled output))

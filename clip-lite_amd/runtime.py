@@ -317,8 +317,6 @@ class DeviceRuntime:
         self.zero_chunk = 512 * 1024       # floats per chunk of the zero pool (ZeroPool): every captured phase starts a fresh pool, and most need a few KB of statistics -
                                            # a 16 MB chunk per phase cost ~14 fills of 10 - 20 us per step
         self.stem_tail_deferred = True     # bn1's backward + conv1's weight gradient with the collected weight gradients (off the dependent chain) when the caller defers them
-        self.stem_bwd_fused = False        # ... both in ONE kernel when the reductions are there (hip.stem_bwd_fused: the un-pooled gradient formed in LDS only). Built, tested,
-                                           # OFF: 198 us against 134 + 79 for the two kernels stand-alone and no difference in the step - the pooled-gradient gather, not the 410 MB it saves, is what costs
         self.stem_wgrad_patch = True       # conv1's weight gradient on the patch-resident kernel (hip.stem_wgrad_patch; bf16 mode)
         self.stem_pooled_stats = True      # bn1's backward reductions from pooled-size operands in the epilogue of layer1's first input gradient (resnet.py; bf16 mode)
         self.fp8_dgrad = False             # ... and the input gradients of the image encoder's 3 x 3 (>= 128 channels) / late 1 x 1 convs inside a block: e5m2 gradient x e4m3

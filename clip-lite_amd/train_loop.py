@@ -255,11 +255,6 @@ class TrainStep:
         # more of its weight gradients overlap the chain was measured slower, 18.9 vs 18.6 ms: a group of one block's four weight gradients
         # takes as long — 0.8 ms — as the group of all three blocks', which is the point of grouping.)
         cuts = [n1 + n2, n1, 0]
-        # layer1_cut = k (0 < k < len(layer1)): one more cut, between layer1's blocks k - 1 and k - the weight gradients of blocks k.. replay on the side
-        # stream behind layer2's group, only blocks 0 .. k - 1 and the stem's follow the chain on the main stream (a shorter tail on main, a longer one on side)
-        k1 = int(getattr(self, "layer1_cut", 0) or 0)
-        if 0 < k1 < n1:
-            cuts = [n1 + n2, n1, k1, 0]
         segs = [f"s{i}" for i in range(len(cuts))]
         from . import hip
         ws = {k: hip.WgradGroup.alloc_workspace(rt.device) for k in segs + ["t", "h"]}      # pinned staging cannot be allocated inside a capture
@@ -360,10 +355,6 @@ class TrainStep:
         l2, l3, l4, img = A.region(pre + "layer2."), A.region(pre + "layer3."), A.region(pre + "layer4."), self._regions["image_encoder"]
         assert img[0] <= l2[0] <= l2[1] <= l3[0] <= l3[1] <= l4[0] <= l4[1] <= img[1]
         self._seg_spans = [(l3[0], img[1]), (l2[0], l3[0]), (img[0], l2[0])]          # s0 = [layer4, layer3], s1 = layer2, s2 = layer1 + stem
-        if len(cuts) == 4:
-            lk = A.region(pre + f"layer1.{cuts[2]}.")
-            assert img[0] <= lk[0] <= l2[0]
-            self._seg_spans = [(l3[0], img[1]), (l2[0], l3[0]), (lk[0], l2[0]), (img[0], lk[0])]
         self._g, self._graphs, self._keep, self._static_out = graphs["update_img"], graphs, keep, keep["result"]
         self._segs = segs
 

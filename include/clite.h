@@ -367,11 +367,6 @@ int clite_stem_bn_pool_bwd(const clite_bn* p, int dtype, const void* dpool, cons
 int clite_stem_bn_pool_fwd_ex(const clite_bn* p, int dtype, const void* y, void* pooled, uint8_t* idx, void* ymax, int N, int H, int W, void* stream);
 int clite_stem_bn_pool_bwd_apply(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, void* dy,
                                  float* dgamma, float* dbeta, int N, int H, int W, void* stream);
-/* ABI v11. clite_stem_bn_pool_bwd_apply + clite_stem_wgrad_patch in one kernel: the un-pooled gradient dy (205 MB at batch 128) is formed strip by strip in
- * LDS from (dpool, idx, y, dstats) and multiplied there - never written, never read back. dw f32 [64][7][7][3] +=, dgamma / dbeta (optional) += as the
- * apply pass. Same coverage and return convention as clite_stem_wgrad_patch (1: not taken, nothing launched). */
-int clite_stem_bwd_fused(const clite_bn* p, int dtype, const void* dpool, const uint8_t* idx, const void* y, const float* dstats, const void* xpad,
-                         int N, int Hp, int Wp, int Ho, int Wo, float* dw, float* dgamma, float* dbeta, void* ws, uint64_t ws_bytes, void* stream);
 /* nn.AdaptiveAvgPool2d((1,1)) + view (reference encoder.py:63-65): [N][HW][C] -> [N][C] */
 int clite_avgpool_fwd(int dtype, const void* x, void* out, int N, int HW, int C, void* stream);
 int clite_avgpool_bwd(int dtype, const void* dout, void* dx, int N, int HW, int C, void* stream);

@@ -358,60 +358,6 @@ def test_stem_weight_gradient_patch_resident(N, H, W, extra_rows):
     assert L.clite_stem_wgrad_patch(ptr(dyb), ptr(xpad), BF16, N, Hp, Wp, Ho, Wo2, ptr(dw), ptr(ws), nb.value, None) == 1
 
 
-@pytest.mark.policy_independent
-@pytest.mark.parametrize("N,H,W", [(2, 10, 32), (1, 12, 64)])
-def test_stem_backward_fused_equals_apply_then_weight_gradient(N, H, W):
-    """clite_stem_bwd_fused (ABI v11): bn1's backward formed in LDS in front of conv1's weight gradient. Same operands as the two-kernel sequence
-    clite_stem_bn_pool_bwd_apply -> clite_stem_wgrad_patch (random pooled gradient, window indices from the fused forward, reductions given): the weight
-    gradient agrees to summation order (the bf16 values that meet the MFMA are the ones the apply pass would have stored), dgamma / dbeta are the apply
-    pass's bit for bit; an odd number of output rows included."""
-    from simlib import Bn
-    assert lib().clite_set_tile_policy(0) == 0
-    L = lib()
-    rng = np.random.default_rng(H * W)
-    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
-    Hp, Wp = H + 6, W + 8
-    Cc, M, P, R = 64, N * Ho * Wo, N * Hq * Wq, 2
-    img = rng.standard_normal((N, 3, H, W), dtype=np.float32)
-    xpad = np.zeros((N, Hp, Wp, 4), np.uint16)
-    assert L.clite_image_to_nhwc4(BF16, ptr(img), ptr(xpad), N, H, W, 3, Hp, Wp, None) == 0
-    y, yb = _prep(np.round(rng.standard_normal((M, Cc), dtype=np.float32) * 2) / 2, BF16)
-    gamma = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
-    beta = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
-    stats = np.zeros((R, 3, Cc), np.float32)
-    stats[0, 0], stats[0, 1] = y.sum(0), (y * y).sum(0)
-    rm, rv = np.zeros(Cc, np.float32), np.ones(Cc, np.float32)
-
-    def desc():
-        return Bn(M, Cc, ptr(stats), ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 1, 0, 0.1, 1e-5, 1, R, 3 * Cc, 0, None, None, None, None, None)
-    p0, idx = np.zeros((P, Cc), np.uint16), np.zeros((P, Cc), np.uint8)
-    assert L.clite_stem_bn_pool_fwd(C.byref(desc()), BF16, ptr(yb), ptr(p0), ptr(idx), N, Ho, Wo, None) == 0
-    dpool, dpoolb = _prep(rng.standard_normal((P, Cc), dtype=np.float32) * (from_bf16(p0) > 0), BF16)
-    ds = np.zeros((R, 3, Cc), np.float32)
-    ds[0, 0], ds[1, 1] = rng.standard_normal(Cc), rng.standard_normal(Cc)          # any reductions: both paths take them as given
-    L.clite_stem_bn_pool_bwd_apply.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_void_p]
-    L.clite_stem_wgrad_patch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
-    L.clite_stem_bwd_fused.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_uint64, C.c_void_p]
-    nb = C.c_uint64(0)
-    assert L.clite_conv_wgrad_patch_workspace(C.byref(nb)) == 0
-    ws = np.full(nb.value // 4, np.nan, np.float32)
-    dy = np.zeros((M, Cc), np.uint16)
-    dg0, db0 = np.ones(Cc, np.float32), np.ones(Cc, np.float32)
-    assert L.clite_stem_bn_pool_bwd_apply(C.byref(desc()), BF16, ptr(dpoolb), ptr(idx), ptr(yb), ptr(ds), ptr(dy), ptr(dg0), ptr(db0), N, Ho, Wo, None) == 0
-    dw0 = np.full((64, 7, 7, 3), 0.5, np.float32)
-    assert L.clite_stem_wgrad_patch(ptr(dy), ptr(xpad), BF16, N, Hp, Wp, Ho, Wo, ptr(dw0), ptr(ws), nb.value, None) == 0
-    dw1 = np.full((64, 7, 7, 3), 0.5, np.float32)
-    dg1, db1 = np.ones(Cc, np.float32), np.ones(Cc, np.float32)
-    ws[:] = np.nan
-    assert L.clite_stem_bwd_fused(C.byref(desc()), BF16, ptr(dpoolb), ptr(idx), ptr(yb), ptr(ds), ptr(xpad), N, Hp, Wp, Ho, Wo, ptr(dw1), ptr(dg1), ptr(db1), ptr(ws),
-                                  nb.value, None) == 0
-    assert np.array_equal(dg0, dg1) and np.array_equal(db0, db1)
-    _close(dw1 - 0.5, dw0 - 0.5, 1e-4)
-    assert np.abs(dw0 - 0.5).max() > 0
-    assert L.clite_stem_bwd_fused(C.byref(desc()), F32, ptr(dpoolb), ptr(idx), ptr(yb), ptr(ds), ptr(xpad), N, Hp, Wp, Ho, Wo, ptr(dw1), None, None, ptr(ws), nb.value, None) == 1
-    assert L.clite_stem_bwd_fused(C.byref(desc()), BF16, ptr(dpoolb), ptr(idx), ptr(yb), ptr(ds), ptr(xpad), N, Hp, Wp, Ho, Wo, ptr(dw1), None, None, ptr(ws), 4096, None) == 1
-
 
 @pytest.mark.policy_independent
 def test_grouped_weight_gradients():

@@ -51,4 +51,3 @@ ds.t.view(8, 3, 64)[0, 0] = 1.0
 dy0 = torch.empty(N * Ho * Wo, 64, device="cuda", dtype=torch.bfloat16)
 dg, db = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
 print(f"stem_bn_pool_bwd_apply    {timed(lambda: hip.stem_bn_pool_bwd_apply(dt, desc(), dpool, idx, y, ds, dy0, dg, db, N, Ho, Wo)):8.1f} us")
-print(f"stem_bwd_fused            {timed(lambda: hip.stem_bwd_fused(dt, desc(), dpool, idx, y, ds, xpad, N, Hp, Wp, Ho, Wo, dw, dg, db)):8.1f} us   (apply + weight gradient in one kernel)")
