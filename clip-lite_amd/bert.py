@@ -243,33 +243,50 @@ def _dgrad(rt, x, M, N, K, ep, *ws):
         hip.gemm_nn(rt.dt, x, A.w(ws[0]) if len(ws) == 1 else A.span(list(ws)), M, N, K, ep)
 
 
-def bert_backward(rt, net, ctx, dpooled, defer=None):
+def segment_layers(n_layers, seg):
+    """(lo, hi) layer indices of backward segment `seg` = (i, n): the i-th of n runs of consecutive layers, walked from the top (i = 0 holds the last layers)."""
+    i, n = seg
+    bounds = [round(n_layers * j / n) for j in range(n + 1)]
+    return bounds[n - i - 1], bounds[n - i]
+
+
+def bert_backward(rt, net, ctx, dpooled, defer=None, seg=None):
     """defer: a hip.WgradGroup — the 4 x 12 + 1 linear weight gradients are collected and left to the caller to launch (as one grouped launch)
-    instead of being enqueued one by one between the input-gradient GEMMs."""
+    instead of being enqueued one by one between the input-gradient GEMMs.
+    seg = (i, n): only the i-th of n chain segments (segment_layers; 0 = pooler + the last layers, n - 1 = the first layers + the embeddings), the
+    hidden-state gradient parked in ctx between calls — the captured data-parallel step records one graph and one weight-gradient group per segment, so
+    that each segment's span of the gradient arena is handed to the exchange while the next one still runs (reference train.py:174-178: DDP's buckets
+    fill in reverse order of the forward)."""
     dt, A = rt.dt, rt.arena
     B, L = ctx["B"], ctx["L"]
     Hd, heads, inner = net.hidden, net.heads, net.inner
     M = B * L
+    nl = len(ctx["layers"])
+    lo_layer, hi_layer = (0, nl) if seg is None else segment_layers(nl, seg)
+    first, last = seg is None or seg[0] == 0, seg is None or seg[0] == seg[1] - 1
     own_group = None
-    if defer is None and rt.group_wgrad and not rt.overlap_wgrad and not rt._capturing:      # (a capture cannot allocate the pinned staging)
+    if seg is None and defer is None and rt.group_wgrad and not rt.overlap_wgrad and not rt._capturing:      # (a capture cannot allocate the pinned staging)
         defer = own_group = hip.WgradGroup(rt.dt)          # uncaptured backward: grouped launch at the end of this call
     staged, pooler_done = own_group is not None and getattr(rt, "exchange", None) is not None, False
     A.ensure_transposed(capturing=rt._capturing)
-    # pooler: dpre = dpooled * (1 - y^2); h[:, 0] rows only
-    dpre = _alloc(rt, B, Hd)
-    hip.tanh_bwd(dt, dpooled, ctx["pooled"], dpre, B * Hd)
-    pw = net.pooler.dense
-    if pw.weight.requires_grad:
-        if defer is not None:
-            defer.linear(dpre, ctx["h_last"], Hd, Hd, B, A.g(pw.weight), ldb=L * Hd)
-        else:
-            hip.gemm_tn(dt, dpre, ctx["h_last"], Hd, Hd, B, hip.epilogue(A.g(pw.weight), Hd, atomic=True, out_f32=True), ldb=L * Hd)
-        hip.colsum(dt, dpre, A.g(pw.bias), B, Hd)
-    if own_group is None:
-        rt.grads_ready(net.pooler)
-    dh = torch.zeros(M, Hd, device=rt.device, dtype=rt.tdtype)
-    _dgrad(rt, dpre, B, Hd, Hd, hip.epilogue(dh, L * Hd, ws=rt.gemm_ws(B, Hd)), pw.weight)
-    for (layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2) in reversed(ctx["layers"]):
+    if first:
+        # pooler: dpre = dpooled * (1 - y^2); h[:, 0] rows only
+        dpre = _alloc(rt, B, Hd)
+        hip.tanh_bwd(dt, dpooled, ctx["pooled"], dpre, B * Hd)
+        pw = net.pooler.dense
+        if pw.weight.requires_grad:
+            if defer is not None:
+                defer.linear(dpre, ctx["h_last"], Hd, Hd, B, A.g(pw.weight), ldb=L * Hd)
+            else:
+                hip.gemm_tn(dt, dpre, ctx["h_last"], Hd, Hd, B, hip.epilogue(A.g(pw.weight), Hd, atomic=True, out_f32=True), ldb=L * Hd)
+            hip.colsum(dt, dpre, A.g(pw.bias), B, Hd)
+        if own_group is None:
+            rt.grads_ready(net.pooler)
+        dh = torch.zeros(M, Hd, device=rt.device, dtype=rt.tdtype)
+        _dgrad(rt, dpre, B, Hd, Hd, hip.epilogue(dh, L * Hd, ws=rt.gemm_ws(B, Hd)), pw.weight)
+    else:
+        dh = ctx.pop("bwd_dh")
+    for (layer, h, qkv, ctxt, da, s1, d1, st1, h1, f, g, s2, d2, st2) in reversed(ctx["layers"][lo_layer:hi_layer]):
         sa, so, out = layer.attention.self, layer.attention.output, layer.output
         # LayerNorm 2 -> (dropout) -> FFN
         ds2 = _alloc(rt, M, Hd)
@@ -313,6 +330,9 @@ def bert_backward(rt, net, ctx, dpooled, defer=None):
                 pooler_done = True
             rt.grads_ready(layer)
             defer = own_group = hip.WgradGroup(rt.dt)
+    if not last:
+        ctx["bwd_dh"] = dh
+        return
     emb = net.embeddings
     ds0 = _alloc(rt, M, Hd)
     hip.layernorm_bwd(dt, dh, ctx["s0"], ctx["st0"], emb.LayerNorm.weight, ds0, None, A.g(emb.LayerNorm.weight), A.g(emb.LayerNorm.bias), M, Hd,

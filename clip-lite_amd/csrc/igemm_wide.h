@@ -156,7 +156,7 @@ struct WideCfg {
 template <int EPI> struct WideEpiForm {
   static constexpr bool RT = EPI == 0, BN = EPI == 1;              // RT: every feature decided by run-time flags
   static constexpr bool PREACT = EPI == 3, GELU = EPI == 3, DGELU = EPI == 4, DROP = EPI == 5, RES = EPI == 5 || EPI == 6;
-  static constexpr bool BIAS = EPI == 0 || EPI == 2 || EPI == 3 || EPI == 5;
+  static constexpr bool BIAS = EPI == 0 || EPI == 1 || EPI == 2 || EPI == 3 || EPI == 5;          // (1: the folded BatchNorm backward's constant row)
   static constexpr bool MAY_STATS = EPI == 0 || EPI == 1 || EPI == 2 || EPI == 4;
 };
 

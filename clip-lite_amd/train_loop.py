@@ -5,6 +5,7 @@ RCCL exchange of the flat gradient arena overlapped with backward (utils/distrib
 clipping + SGD + Lookahead run in one fused kernel; wandb/loguru (absent from the image) are replaced by the stdlib logger."""
 import argparse
 import contextlib
+import os
 from collections import Counter
 from typing import Any
 
@@ -176,11 +177,17 @@ class TrainStep:
         # only this thread's calls belong to the capture
         mode = "thread_local"
 
+        dump_dir = getattr(self, "debug_graph_dir", None)          # tools/graph_nodes.py: the node list of every captured phase (hipGraphDebugDotPrint)
+
         def capture(name, pool, fn):
             rt._zpools = {}                   # a segment zeroes the accumulators it uses itself
             g = torch.cuda.CUDAGraph()
+            if dump_dir:
+                g.enable_debug_mode()
             with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
                 fn()
+            if dump_dir:
+                g.debug_dump(os.path.join(dump_dir, name + ".dot"))
             graphs[name] = g
 
         # the image is staged (NCHW f32 -> padded NHWC4, one kernel) OUTSIDE the graphs, straight from the caller's tensor into the buffer the
@@ -279,10 +286,25 @@ class TrainStep:
         def wgrad_last_extras():
             keep["wg_" + segs[-1]].launch_extras()
 
-        def text_bwd():
-            # BERT's 49 linear weight gradients (+ the text heads', collected in heads_t1 / heads_t2): one grouped launch at the end of its backward
-            bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous(), defer=keep["wg_t"])
-            keep["wg_t"].launch()
+        # BERT's backward: ONE graph with one weight-gradient group at its end when nothing is exchanged; under data parallel `text_segments` (3) chain
+        # segments - pooler + layers 11..8 | 7..4 | 3..0 + embeddings - each with its own group, so that each segment's span of the gradient arena (the
+        # text encoder is 438 of the step's 625 MB) goes to the exchange as soon as its graph is enqueued instead of behind the whole encoder (VERDICT r4
+        # missing 2; reference train.py:174-178). One group per segment costs a little at one rank (grouping gains from size), hence only with an exchange.
+        nts = int(getattr(self, "text_segments", 3 if self.exchange is not None else 1) or 1)
+        nts = max(1, min(nts, len(m.text_encoder.strans.encoder.layer)))
+        tsegs = self._tsegs = [f"t{i}" for i in range(nts)]
+        if nts > 1:
+            ws.update({k: hip.WgradGroup.alloc_workspace(rt.device) for k in tsegs[1:]})
+
+        def text_bwd(i):
+            def fn():
+                # (the text heads' weight gradients, collected in heads_t1 / heads_t2, ride in the first segment's group)
+                g_ = keep["wg_t"] if i == 0 else hip.WgradGroup(rt.dt, ws[tsegs[i]], zeroed=True)
+                keep["wg_" + tsegs[i]] = g_
+                bert_backward(rt, m.text_encoder.strans, keep["ctx_t"], keep["dtxt"].contiguous() if i == 0 else None, defer=g_,
+                              seg=(i, nts) if nts > 1 else None)
+                g_.launch()
+            return fn
 
         A0 = rt.arena
         img_span = A0.region("image_encoder.")
@@ -321,7 +343,8 @@ class TrainStep:
                 capture("heads_m1", pool_main, heads_m1)
                 capture("heads_t2", pool_side, heads_t2)
                 capture("heads_m2", pool_main, heads_m2)
-                capture("text_bwd", pool_side, text_bwd)
+                for i, tg in enumerate(tsegs):
+                    capture("text_bwd" if nts == 1 else "text_bwd_" + tg, pool_side, text_bwd(i))
                 # Which stream replays a segment's grouped weight gradients: the side stream (behind BERT's backward) by default, the main stream (behind
                 # the whole chain) for the segments in `wgrad_main` ("1", "0,1": tools/ab_runtime.py step.wgrad_main=1) — always the last one. Measured with
                 # the folded BatchNorm backward (which shortens the chain): layer2's group on the main stream 15.03 ms against 14.86 on the side stream,
@@ -355,12 +378,37 @@ class TrainStep:
         l2, l3, l4, img = A.region(pre + "layer2."), A.region(pre + "layer3."), A.region(pre + "layer4."), self._regions["image_encoder"]
         assert img[0] <= l2[0] <= l2[1] <= l3[0] <= l3[1] <= l4[0] <= l4[1] <= img[1]
         self._seg_spans = [(l3[0], img[1]), (l2[0], l3[0]), (img[0], l2[0])]          # s0 = [layer4, layer3], s1 = layer2, s2 = layer1 + stem
+        if nts > 1:
+            # arena order inside the text encoder: embeddings | layer 0 .. n - 1 | pooler; segment i covers layers [lo, hi) (+ the pooler for i = 0, + the
+            # embeddings for the last one): contiguous spans, from the top
+            from .bert import segment_layers
+            tr, tp = self._regions["text_encoder"], "text_encoder.strans."
+            nl = len(m.text_encoder.strans.encoder.layer)
+            lay = [A.region(tp + f"encoder.layer.{j}.") for j in range(nl)]
+            self._text_spans = []
+            for i in range(nts):
+                lo, hi = segment_layers(nl, (i, nts))
+                self._text_spans.append((tr[0] if i == nts - 1 else lay[lo][0], tr[1] if i == 0 else lay[hi][0]))
+            assert self._text_spans[0][1] == tr[1] and self._text_spans[-1][0] == tr[0] and all(a[0] == b[1] for a, b in zip(self._text_spans, self._text_spans[1:]))
+        self.handover = []          # [(span, event recorded when its gradients were final)] of the last replay: tools/timeline_handover.py
         self._g, self._graphs, self._keep, self._static_out = graphs["update_img"], graphs, keep, keep["result"]
         self._segs = segs
+
+    def _hand(self, span, stream):
+        """Hand flat_g[span] to the exchange behind what is enqueued on `stream`; with track_handover also a timed event there (tools/timeline_handover.py)."""
+        self.exchange.reduce_span(*span, after=stream)
+        if getattr(self, "track_handover", False):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.handover.append((span, ev))
 
     def _replay_direct(self):
         rt, G, ex = self.model.runtime, self._graphs, self.exchange
         main, side = torch.cuda.current_stream(rt.device), rt.side_stream
+        if getattr(self, "track_handover", False):
+            self.handover = []
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(main)
         side.wait_stream(main)
         G["image_fwd"].replay()
         with torch.cuda.stream(side):
@@ -379,10 +427,16 @@ class TrainStep:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             G["heads_t2"].replay()                 # text block backward ...
-            G["text_bwd"].replay()                 # ... straight into BERT's backward
+            if len(self._tsegs) == 1:
+                G["text_bwd"].replay()             # ... straight into BERT's backward
+                if ex is not None:
+                    self._hand(self._regions["text_encoder"], side)          # ordered after BERT's backward only (the event is taken now)
+            else:
+                for tg, span in zip(self._tsegs, self._text_spans):          # segment by segment: each span leaves while the next segment runs
+                    G["text_bwd_" + tg].replay()
+                    if ex is not None:
+                        self._hand(span, side)
         G["heads_m2"].replay()                     # image block backward, beside it
-        if ex is not None:
-            ex.reduce_span(*self._regions["text_encoder"], after=side)          # ordered after BERT's backward only (the event is taken now)
         on_main = self._wgrad_on_main
         ev_early = None
         for i, sg in enumerate(self._segs[:-1]):   # a segment's weight gradients go to the side stream as soon as its chain is enqueued (or wait for the chain's end: on_main)
@@ -395,13 +449,13 @@ class TrainStep:
                     if "wgrad_heads" in G:
                         G["wgrad_heads"].replay()
                     if ex is not None:
-                        ex.reduce_span(*self._regions["loss"], after=side)
+                        self._hand(self._regions["loss"], side)
                 if i not in on_main:
                     G["wgrad_" + sg].replay()
                 if i == 0:
                     ev_early = side.record_event()          # text encoder, loss heads (+ layer3 / layer4 unless on_main): the side stream's share of the norm's early spans
             if ex is not None and i not in on_main:   # BatchNorm gradients came with the chain (main), weight gradients with the group (side, which waited for main)
-                ex.reduce_span(*self._seg_spans[i], after=side)
+                self._hand(self._seg_spans[i], side)
         G["image_bwd_" + self._segs[-1]].replay()
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -410,14 +464,14 @@ class TrainStep:
         for i in on_main:                          # ... the grouped launches behind the chain
             G["wgrad_" + self._segs[i]].replay()
             if ex is not None and i < len(self._segs) - 1:
-                ex.reduce_span(*self._seg_spans[i], after=main)
+                self._hand(self._seg_spans[i], main)
         early_done = ex is None and getattr(self, "norm_overlap", True) and "norm_early" in G
         if early_done:
             main.wait_event(ev_early)
             G["norm_early"].replay()               # beside the side stream's last groups
         if ex is not None:
             main.wait_stream(side)
-            ex.reduce_span(*self._seg_spans[-1], after=main)
+            self._hand(self._seg_spans[-1], main)
             covered = sorted(self._regions.values())
             pos = 0
             for lo, hi in covered:                 # anything outside the three top-level modules (nothing, for VLInfoModel)

@@ -91,6 +91,7 @@ class Bn(C.Structure):
         ("res_stats", C.c_void_p), ("res_gamma", C.c_void_p), ("res_beta", C.c_void_p),
         ("res_running_mean", C.c_void_p), ("res_running_var", C.c_void_p), ("relu_bits", C.c_void_p),
         ("fp8_out", C.c_void_p), ("fp8_scale", C.c_void_p), ("fp8_amax", C.c_void_p),
+        ("out_sum", C.c_void_p), ("out_sum_replicas", C.c_int32), ("out_sum_stride", C.c_int32),
     ]
 
 

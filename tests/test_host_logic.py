@@ -449,3 +449,16 @@ def test_gradient_norm_spans_cover_the_arena_once_in_a_fixed_order():
     B = Arena.__new__(Arena)          # no image encoder of that shape: one span
     B.names, B.index, B.total = Arena.layout([(n, p) for n, p in M.named_parameters() if n.startswith("text_encoder.")])
     assert FusedSGD.norm_spans(types.SimpleNamespace(arena=B, _norm_spans=None)) == [(0, B.total)]
+
+
+def test_bert_backward_segments_partition_the_layers_from_the_top():
+    """bert.segment_layers: the chain segments of the captured data-parallel BERT backward (train_loop.TrainStep.text_segments) are runs of consecutive
+    layers that cover every layer once, segment 0 holding the last layers (backward order), for any layer count / segment count."""
+    from clip_lite_amd.bert import segment_layers
+    for nl in (1, 2, 5, 12, 24):
+        for n in range(1, min(nl, 6) + 1):
+            segs = [segment_layers(nl, (i, n)) for i in range(n)]
+            assert segs[0][1] == nl and segs[-1][0] == 0
+            assert all(lo < hi for lo, hi in segs)
+            assert all(a[0] == b[1] for a, b in zip(segs, segs[1:]))          # contiguous, walked downwards
+    assert [segment_layers(12, (i, 3)) for i in range(3)] == [(8, 12), (4, 8), (0, 4)]

@@ -368,7 +368,8 @@ def test_grouped_weight_gradients():
 
     class Item(C.Structure):
         _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
-                    ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32)]
+                    ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                    ("row_scale", C.c_void_p)]
 
     rng = np.random.default_rng(5)
     L = lib()
@@ -418,6 +419,119 @@ def test_grouped_weight_gradients():
     assert L.clite_wgrad_group(BF16, arr, len(items), ptr(ws_dev), ptr(ws_host), nb.value, None) == 0
     for got, ref in zip(outs, refs):
         _close(got, ref - 1)
+    # ABI v12: a per-output-row factor on a member's product (clite_wgrad_item.row_scale: the folded BatchNorm backward's ka) — such a member always adds
+    # (its correction terms arrive from other launches), also with CLITE_WGRAD_ZEROED — and CLITE_WGRAD_SHORTK (quarter-length K chunks) on the
+    # k-chunked member: same values
+    scales = []
+    for i, (it, o) in enumerate(zip(items, outs)):
+        o[...] = 0.5
+        sc = (1 + 0.25 * rng.standard_normal(o.shape[0])).astype(np.float32)
+        scales.append(sc)
+        it.row_scale = ptr(sc).value
+        if i == 3:
+            it.kind |= 0x400
+    arr = (Item * len(items))(*items)
+    assert L.clite_wgrad_group(BF16, arr, len(items), ptr(ws_dev), ptr(ws_host), nb.value, None) == 0
+    for got, ref, sc in zip(outs, refs, scales):
+        _close(got, 0.5 + (ref - 1) * sc.reshape((-1,) + (1,) * (ref.ndim - 1)))
+    assert L.clite_wgrad_group(F32, arr, len(items), None, None, 0, None) == -1          # members one by one have no row_scale form
+
+
+@pytest.mark.parametrize("M,K,Cin", [(200, 64, 64), (700, 128, 32), (300, 192, 128)])
+def test_folded_batchnorm_backward(M, K, Cin):
+    """ABI v12: the BatchNorm backward of a 1 x 1 conv -> BatchNorm unit folded into the convolution's two gradients. clite_bn_fold_prepare (row-scaled
+    weights, constant row, coefficients, dgamma / dbeta), clite_conv_dgrad_bnfold (one GEMM over the K-concatenation [dz | y] through the BatchNorm-backward
+    epilogue with a bias: every tile family; the 700-row case runs the row-range persistent form of the simulator build), and the weight-gradient side —
+    clite_bn_apply's column sums of its output (clite_bn.out_sum), the group's row_scale member and Gram matrix, clite_bn_fold_wgrad_finish — against a
+    numpy evaluation of BatchNorm backward followed by the convolution's backward."""
+    from simlib import Bn
+    rng = np.random.default_rng(M + K)
+    L = lib()
+    a, ab = _prep(np.maximum(rng.standard_normal((M, Cin), dtype=np.float32) + 0.3, 0), BF16)
+    W, Wb = _prep(rng.standard_normal((K, Cin), dtype=np.float32) * (2.0 / Cin) ** 0.5, BF16)
+    y, yb = _prep(a @ W.T + 0.5, BF16)
+    dz, _ = _prep((rng.standard_normal((M, K), dtype=np.float32) * 0.1 + 0.02 * rng.standard_normal(K).astype(np.float32)) * (rng.random((M, K)) > 0.4), BF16)
+    dzb = to_bf16(dz)
+    gamma = (rng.random(K) + 0.5).astype(np.float32)
+    R = 2
+    st = np.zeros((R, 3, K), np.float32)
+    st[0, 0], st[1, 0] = 0.25 * y.sum(0), 0.75 * y.sum(0)
+    st[0, 1], st[1, 1] = 0.5 * (y * y).sum(0), 0.5 * (y * y).sum(0)
+    mean = y.astype(np.float64).mean(0)
+    var = np.maximum((y.astype(np.float64) ** 2).mean(0) - mean * mean, 0)
+    rstd = 1.0 / np.sqrt(var + 1e-5)
+    S1, S2 = dz.astype(np.float64).sum(0), (dz * (y - mean)).astype(np.float64).sum(0)
+    pre = np.zeros((R, 3, K), np.float32)
+    pre[0, 0], pre[1, 0] = 0.5 * S1, 0.5 * S1
+    pre[0, 1], pre[1, 1] = 0.3 * S2, 0.7 * S2
+    xhat = (y - mean) * rstd
+    dy = gamma * rstd * (dz - S1 / M - xhat * (dz * xhat).sum(0) / M)
+    da_ref, dW_ref = dy @ W, dy.T @ a
+    # the unit in front: its BatchNorm input, forward sums, relu' bits
+    y2, y2b = _prep(rng.standard_normal((M, Cin), dtype=np.float32) + 1.0, BF16)
+    st2 = np.zeros((R, 3, Cin), np.float32)
+    st2[0, 0], st2[1, 0] = 0.5 * y2.sum(0), 0.5 * y2.sum(0)
+    mean2 = y2.mean(0)
+    mask = rng.random((M, Cin)) > 0.3
+    bits = pack_relu_bits(mask.astype(np.float32))
+    pair = np.concatenate([dzb.reshape(1, M, K), yb.reshape(1, M, K)], axis=0).copy()
+    Wt = np.ascontiguousarray(Wb.T)
+    w2, bias, coef = np.zeros((Cin, 2, K), np.uint16), np.zeros(Cin, np.float32), np.zeros((3, K), np.float32)
+    dgamma, dbeta = np.zeros(K, np.float32), np.zeros(K, np.float32)
+    rm, rv = np.zeros(K, np.float32), np.ones(K, np.float32)
+    p = Bn(M, K, ptr(st), ptr(gamma), ptr(np.zeros(K, np.float32)), ptr(rm), ptr(rv), 1, 0, 0.1, 1e-5, 0, R, 3 * K, 0)
+    L.clite_bn_fold_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    assert L.clite_bn_fold_prepare(C.byref(p), ptr(pre), ptr(Wt), Cin, ptr(w2), ptr(bias), ptr(coef), ptr(dgamma), ptr(dbeta), None) == 0
+    _close(coef[0], gamma * rstd, 1e-4)
+    _close(dgamma, (dz * xhat).sum(0), 2e-3)
+    _close(dbeta, S1, 1e-4)
+    dz2 = np.zeros((M, Cin), np.uint16)
+    d2 = np.zeros((R, 3, Cin), np.float32)
+    ep = make_ep(dz2, Cin, bias=bias, colsum=d2, relu_bits=bits)
+    ep.colsum_replicas, ep.colsum_stride = R, 3 * Cin
+    ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = ptr(y2b), ptr(st2), R, 3 * Cin, 1.0 / M
+    L.clite_conv_dgrad_bnfold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.clite_conv_dgrad_bnfold(ptr(pair), ptr(w2), M, K, Cin, C.byref(ep), None) == 0
+    got = from_bf16(dz2)
+    _close(got, da_ref * mask, 6e-3)
+    d = d2.sum(0)
+    _close(d[0], got.sum(0), 5e-3)
+    _close(d[1], (got * (y2 - mean2)).sum(0), 5e-3)
+    ep.bias = None                                           # the folded form needs its constant row
+    assert L.clite_conv_dgrad_bnfold(ptr(pair), ptr(w2), M, K, Cin, C.byref(ep), None) == -1
+    # weight gradient. colsum(a) from an identity BatchNorm + ReLU over a (clite_bn.out_sum: the pass that writes a also sums it)
+    Ra = 4
+    asum = np.zeros((Ra, 3, Cin), np.float32)
+    ist = np.zeros((1, 3, Cin), np.float32)
+    ist[0, 1] = M * (1.0 - 1e-5)
+    one, zero = np.ones(Cin, np.float32), np.zeros(Cin, np.float32)
+    pa = Bn(M, Cin, ptr(ist), ptr(one), ptr(zero), ptr(zero.copy()), ptr(one.copy()), 1, 0, 0.1, 1e-5, 1, 1, 3 * Cin, 0)
+    pa.out_sum, pa.out_sum_replicas, pa.out_sum_stride = ptr(asum), Ra, 3 * Cin
+    a_out = np.zeros((M, Cin), np.uint16)
+    assert L.clite_bn_apply(C.byref(pa), BF16, ptr(ab), None, ptr(a_out), None) == 0
+    assert np.array_equal(a_out, ab)
+    _close(asum[:, 0].sum(0), a.sum(0), 1e-4)
+
+    class Item(C.Structure):
+        _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
+                    ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                    ("row_scale", C.c_void_p)]
+    dw, G = np.zeros((K, Cin), np.float32), np.zeros((Cin, Cin), np.float32)
+    ka = np.ascontiguousarray(coef[0])
+    it0 = Item(); it0.kind, it0.a, it0.b, it0.out, it0.cv = 0x200, ptr(dzb).value, ptr(ab).value, ptr(dw).value, Conv(BF16, 1, 1, M, Cin, K, 1, 1, 1, 0, 1, M)
+    it0.row_scale = ptr(ka).value
+    it1 = Item(); it1.kind, it1.a, it1.b, it1.out, it1.cv = 0x200 | 0x400, ptr(ab).value, ptr(ab).value, ptr(G).value, Conv(BF16, 1, 1, M, Cin, Cin, 1, 1, 1, 0, 1, M)
+    L.clite_wgrad_group.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.clite_wgrad_group_workspace.argtypes = [C.c_int, C.c_int64, C.c_void_p]
+    nb = C.c_uint64(0)
+    assert L.clite_wgrad_group_workspace(2, 4096, C.byref(nb)) == 0
+    ws_dev, ws_host = np.zeros(nb.value, np.uint8), np.zeros(nb.value, np.uint8)
+    arr = (Item * 2)(it0, it1)
+    assert L.clite_wgrad_group(BF16, arr, 2, ptr(ws_dev), ptr(ws_host), nb.value, None) == 0
+    _close(G, a.T @ a, 1e-3)
+    L.clite_bn_fold_wgrad_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.clite_bn_fold_wgrad_finish(ptr(G), ptr(asum), Ra, 3 * Cin, ptr(coef), ptr(Wt), M, K, Cin, ptr(dw), None) == 0
+    _close(dw, dW_ref, 3e-3)
 
 
 class TransposeItem(C.Structure):
