@@ -306,6 +306,7 @@ def main():
                     "with delayed scaling, weights per step with current scaling: clip-lite_amd/fp8.py); everything else, and every backward GEMM, stays bf16")
     ap.add_argument("--no-fp8-text", action="store_true", help="with --fp8: leave the text encoder in bf16 (A/B)")
     ap.add_argument("--no-fp8-dgrad", action="store_true", help="with --fp8: leave the image encoder's input gradients in bf16 (A/B)")
+    ap.add_argument("--no-fp8-wgrad", action="store_true", help="with --fp8: leave the weight gradients in bf16 (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="skip the two extra single-GPU records of the default run (the whole bs = 1024 step on "
                     "one GPU; the exact-f32 parity mode): profiling runs and A/B loops")
@@ -362,6 +363,7 @@ def main():
     model.runtime.fp8 = bool(args.fp8)
     model.runtime.fp8_text = bool(args.fp8) and not args.no_fp8_text
     model.runtime.fp8_dgrad = bool(args.fp8) and not args.no_fp8_dgrad
+    model.runtime.fp8_wgrad = bool(args.fp8) and not getattr(args, "no_fp8_wgrad", False)
     exchange = None
     if dist_on:
         exchange = cdist.GradientExchange(model.runtime.arena, algorithm=args.exchange)
@@ -437,7 +439,7 @@ def main():
             "metric": "image-caption pairs/sec (global batch) — ResNet-50+BERT bs1024, 1/2/4/8 MI355X",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.f32 else ("fp8 (e4m3 operands of the image encoder's 3x3 / late 1x1 forward convs" + ("" if args.no_fp8_text else " and BERT's QKV / FFN forward linears") + ("" if args.no_fp8_dgrad else "; e5m2 x e4m3 input gradients of the 3x3 / late 1x1 convs") + ") + bf16" if args.fp8 else "bf16"), "data": "synthetic" + (", fed from pinned host memory every step" if args.host_input else ""),
+            "dtype": "f32" if args.f32 else ("fp8 (e4m3 operands of the image encoder's 3x3 / late 1x1 forward convs" + ("" if args.no_fp8_text else " and BERT's QKV / FFN forward linears") + ("" if args.no_fp8_dgrad else "; e5m2 x e4m3 input gradients" + ("" if getattr(args, "no_fp8_wgrad", False) else " and weight gradients") + " of the 3x3 / late 1x1 convs") + ") + bf16" if args.fp8 else "bf16"), "data": "synthetic" + (", fed from pinned host memory every step" if args.host_input else ""),
             "config": {"workload": f"{args.visual} + BERT-base({args.layers}L) + JSD-MI heads/priors, per-GPU batch {args.batch}, 224x224 images, "
                                    f"30-token captions, dropout 0.1 + prior noise on, clip 10 + SGD(0.9, wd 1e-4) + Lookahead(5, 0.5)" + ("" if args.loss == "jsd" else ", InfoNCE all-pairs loss"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}"},

@@ -36,6 +36,8 @@ struct GroupItem {
   int ldc, M, N, ktiles, chunk;
   int zeroed;          // CLITE_WGRAD_ZEROED: `out` is known to hold zeros on entry
   const float* row_scale;   // clite_wgrad_item.row_scale (ABI v12): per-output-row factor, or NULL
+  const float* sa;          // kind 2 (fp8 operands): device {scale, 1 / scale} of a (dy, e5m2) ...
+  const float* sb;          // ... and of b (x, e4m3); the product is de-quantised by sa[1] * sb[1] in the epilogue
 };
 struct WgEntry { uint32_t item, tile_m, tile_n, kchunk; };      // one per workgroup
 
@@ -272,6 +274,123 @@ __global__ __launch_bounds__(512) void igemm_group_wide_kernel(const GroupItem<L
     }
 }
 
+// ---- fp8 members (ABI v12, CLITE_WGRAD_FP8: BASELINE configs[4]) ------------------------------------------------------------------------------
+// dW += dq * dy8^T x8 with dy8 in OCP e5m2 (the copy clite_bn_bwd_apply's fused quantiser leaves for clite_conv_dgrad_fp8) and x8 in e4m3 (the copy
+// clite_bn_apply leaves for clite_conv_fwd_fp8): the grouped 256 x 256 tile on v_mfma_scale_f32_32x32x64_f8f6f4 — a K tile of 64 pixels is ONE
+// instruction per 32 x 32 block at twice the bf16 rate per k, and both operand images are half the bytes. Both operands are XC images (the contraction
+// index, the pixel, is the slow one): [64 pixels][256 channels x 1 B]; the fragments come out of them through ds_read_b64_tr_b8 (intrin.h: lane s
+// of a 16-lane group points at pixel row s >> 1, 8-byte column chunk s & 1, and lane i receives 8 consecutive pixels of channel i): four reads per
+// operand and lane give 32 pixels — lanes 0..31 pixels 0..31 of the tile, lanes 32..63 pixels 32..63. The MFMA's nominal k order inside a lane differs
+// (intrin.h: two runs of 16), but A and B are loaded by the same rule, and a contraction does not care in which order both operands enumerate k.
+template <int ROWB> DEV int f8_tr_off(int x0, int lane) {
+  const int s = lane & 15, g = lane >> 4;
+  const int k = 32 * (g >> 1) + (s >> 1);                       // + 8 q for read q: same segment swizzle (k & 3 unchanged)
+  const int xb = x0 + 16 * (g & 1) + 8 * (s & 1);               // byte column of this lane's 8-byte chunk
+  return k * ROWB + ((((xb >> 4)) ^ (xc_seg_xor<ROWB>(k) << 2)) << 4) + (xb & 15);
+}
+template <class CFG, class LA, class LB, int NSTAGE>
+__global__ __launch_bounds__(512) void igemm_group_fp8_kernel(const GroupItem<LA, LB>* __restrict__ items, const WgEntry* __restrict__ map) {
+  constexpr int BM = CFG::BM, BN = CFG::BN;
+  constexpr int RM = CFG::RM, RN = CFG::RN;
+  constexpr int STAGE = LA::BYTES + LB::BYTES;
+  constexpr int LOADS_PER_TILE = LA::NI + LB::NI;
+  static_assert(CFG::KG == 1 && NSTAGE * STAGE <= 160 * 1024 && LA::ROWB == 256 && LB::ROWB == 256, "one k-group; LDS budget; 256-byte image rows");
+  __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = wave_uniform(tid >> 6);
+  const int wm0 = (wave / CFG::WAVES_N) * CFG::WM;
+  const int wn0 = (wave % CFG::WAVES_N) * CFG::WN;
+  const WgEntry e = map[blockIdx.x];
+  if (wave_uniform((int)e.item) < 0) return;
+  const GroupItem<LA, LB>& it = items[wave_uniform((int)e.item)];
+  const LA la = it.la;
+  const LB lb = it.lb;
+  const int M = it.M, N = it.N;
+  const int m0 = wave_uniform((int)e.tile_m) * BM, n0 = wave_uniform((int)e.tile_n) * BN;
+  const int t_begin = wave_uniform((int)e.kchunk) * it.chunk;
+  int t_end = t_begin + it.chunk;
+  if (t_end > it.ktiles) t_end = it.ktiles;
+
+  typename LA::State sa;
+  typename LB::State sb;
+  la.init(sa, m0, wave, lane, t_begin);
+  lb.init(sb, n0, wave, lane, t_begin);
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int aoff[RM], boff[RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) aoff[i] = f8_tr_off<LA::ROWB>(wm0 + i * 32, lane);
+#pragma unroll
+  for (int j = 0; j < RN; ++j) boff[j] = f8_tr_off<LB::ROWB>(wn0 + j * 32, lane);
+#pragma unroll
+  for (int pz = 0; pz < NSTAGE - 1; ++pz) {
+    if (t_begin + pz < t_end) {
+      WideIssue<LA>::go(la, sa, smem + pz * STAGE, wave, lane, m0);
+      WideIssue<LB>::go(lb, sb, smem + pz * STAGE + LA::BYTES, wave, lane, n0);
+    }
+  }
+  int buf = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    const int after = t_end - 1 - t;
+    if (NSTAGE >= 3 && after >= 1) wait_vmcnt<LOADS_PER_TILE>();
+    else wait_vmcnt<0>();
+    barrier_raw();
+    const char* abuf = smem + buf * STAGE;
+    const char* bbuf = abuf + LA::BYTES;
+    u32x4 alo[RM], ahi[RM], blo[RN], bhi[RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+      const u32x2 q0 = lds_read_tr8(abuf + aoff[i]), q1 = lds_read_tr8(abuf + aoff[i] + 8 * LA::ROWB), q2 = lds_read_tr8(abuf + aoff[i] + 16 * LA::ROWB),
+                  q3 = lds_read_tr8(abuf + aoff[i] + 24 * LA::ROWB);
+      alo[i] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+      ahi[i] = u32x4{q2[0], q2[1], q3[0], q3[1]};
+    }
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const u32x2 q0 = lds_read_tr8(bbuf + boff[j]), q1 = lds_read_tr8(bbuf + boff[j] + 8 * LB::ROWB), q2 = lds_read_tr8(bbuf + boff[j] + 16 * LB::ROWB),
+                  q3 = lds_read_tr8(bbuf + boff[j] + 24 * LB::ROWB);
+      blo[j] = u32x4{q0[0], q0[1], q1[0], q1[1]};
+      bhi[j] = u32x4{q2[0], q2[1], q3[0], q3[1]};
+    }
+    if (t + NSTAGE - 1 < t_end) {
+      int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
+      WideIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
+      WideIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
+    }
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int j = 0; j < RN; ++j) acc[i][j] = mfma32x64_bf8_fp8(alo[i], ahi[i], blo[j], bhi[j], acc[i][j]);
+    if (++buf == NSTAGE) buf = 0;
+  }
+  float* out = it.out;
+  const int ldc = it.ldc;
+  const float dq = it.sa[1] * it.sb[1];
+  const float* rs = it.row_scale;
+  const bool single = wave_uniform((int)(it.ktiles <= it.chunk && it.zeroed && !rs));
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j) {
+      const int col = n0 + wn0 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M && col < N) {
+          float* q = out + (size_t)row * ldc + col;
+          const float v = (rs ? acc[i][j][r] * rs[row] : acc[i][j][r]) * dq;
+          if (single) *q = v; else atomic_add_f32(q, v);
+        }
+      }
+    }
+}
+
 struct Plan { int M, N, Ktot, ktiles, chunk, nchunks, tm, tn; };
 Plan plan(int M, int N, int Ktot, int BM, int BN, int bk = GBK, int kchunk = KCHUNK) {
   Plan p;
@@ -317,20 +436,24 @@ typedef DmaXCGather<bf16, 64, GBK> XG64;
 typedef WideCfg<256, 256, 128, 64, 1> W256;
 typedef DmaXCStrided<bf16, 256, WIDE_BK, WIDE_NW> WS256;
 typedef DmaXCGather<bf16, 256, WIDE_BK, WIDE_NW> WG256;
+typedef DmaXCStrided<uint8_t, 256, WIDE_BK, WIDE_NW> FS256;          // fp8 operand images: [64 pixels][256 channels x 1 B]
+typedef DmaXCGather<uint8_t, 256, WIDE_BK, WIDE_NW> FG256;
 constexpr int WKCHUNK = 128;            // K tiles of 64 per workgroup at most (8192 pixels / tokens, as KCHUNK)
 template <class CFG> struct GroupStages { static constexpr int n = 3; };
 template <> struct GroupStages<W256> { static constexpr int n = 2; };
 
 // one bucket = one kernel instantiation; items and map entries are appended to the host staging image
-template <class CFG, class LA, class LB, bool WIDE = false>
+template <class CFG, class LA, class LB, bool WIDE = false, bool F8 = false>
 struct Bucket {
   std::vector<GroupItem<LA, LB>> items;
   std::vector<Plan> plans;
   std::vector<WgEntry> map;
-  void add(const LA& la, const LB& lb, float* out, int ldc, const Plan& p, int zeroed, const float* row_scale = nullptr) {
+  void add(const LA& la, const LB& lb, float* out, int ldc, const Plan& p, int zeroed, const float* row_scale = nullptr, const float* sa = nullptr,
+           const float* sb = nullptr) {
     GroupItem<LA, LB> it;
     it.la = la; it.lb = lb; it.out = out; it.ldc = ldc; it.M = p.M; it.N = p.N; it.ktiles = p.ktiles; it.chunk = p.chunk; it.zeroed = zeroed;
     it.row_scale = row_scale;
+    it.sa = sa; it.sb = sb;
     items.push_back(it);
     plans.push_back(p);
   }
@@ -381,7 +504,10 @@ struct Bucket {
   }
   int launch(char* dev, size_t off, hipStream_t st) const {
     if (items.empty()) return 0;
-    if constexpr (WIDE)
+    if constexpr (F8)
+      hipLaunchKernelGGL((igemm_group_fp8_kernel<CFG, LA, LB, 3>), dim3((unsigned)map.size()), dim3(512), 0, st,
+                         (const GroupItem<LA, LB>*)(dev + off), (const WgEntry*)(dev + off + item_bytes()));
+    else if constexpr (WIDE)
       hipLaunchKernelGGL((igemm_group_wide_kernel<CFG, LA, LB, GroupStages<CFG>::n>), dim3((unsigned)map.size()), dim3(512), 0, st,
                          (const GroupItem<LA, LB>*)(dev + off), (const WgEntry*)(dev + off + item_bytes()));
     else
@@ -406,7 +532,7 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
     for (int i = 0; i < n; ++i) {
       const clite_wgrad_item& w = items[i];
       int rc;
-      if (w.row_scale) return -1;          // (grouped launches only)
+      if (w.row_scale || (w.kind & 0xFF) == 2) return -1;          // (grouped launches only)
       if ((w.kind & ~(CLITE_WGRAD_NARROW | CLITE_WGRAD_ZEROED | CLITE_WGRAD_SHORTK)) == 0) {
         rc = clite_conv_wgrad(w.a, w.b, &w.cv, w.out, stream);
       } else {
@@ -424,6 +550,7 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
   Bucket<C128, XS128, XS128> linear;
   Bucket<W256, WS256, WG256, true> conv_w256;             // >= 256 output channels and >= 256 columns
   Bucket<W256, WS256, WS256, true> linear_w256;
+  Bucket<W256, FS256, FG256, true, true> conv_f8;          // fp8 operands (kind 2): the 256 x 256 tile on the block-scaled MFMA
   const bool wide_all = clite_group_wide_enabled();
   for (int i = 0; i < n; ++i) {
     const clite_wgrad_item& w = items[i];
@@ -442,6 +569,15 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
       else if (c.K <= 64) conv_fewk.add(XS64{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 64, 128, GBK, kc), zeroed, w.row_scale);
       else if (Ncols <= 64) conv_fewc.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG64{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 64, GBK, kc), zeroed, w.row_scale);
       else conv_full.add(XS128{w.a, yb, c.K, c.K, P, 1}, XG128{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 128, 128, GBK, kc), zeroed, w.row_scale);
+    } else if (kind == 2) {
+      // conv weight gradient on fp8 operands: a = dy8 [N][Ho][Wo][K] e5m2, b = x8 [N][H][W][C] e4m3, a_scales / b_scales their {scale, 1 / scale}
+      const clite_conv& c = w.cv;
+      if (!w.a_scales || !w.b_scales || c.dtype != CLITE_BF16 || c.C % 16 || c.K % 16 || (c.R * c.S > 1 && (c.C % 32 || c.K % 32))) return -1;
+      if (!fits32((size_t)c.N * c.H * c.W * c.C, 1) || !fits32((size_t)c.N * c.Ho * c.Wo * c.K, 1)) return -1;
+      const int P = c.N * c.Ho * c.Wo, Ncols = c.R * c.S * c.C;
+      const uint32_t yb = (uint32_t)((size_t)P * c.K), xb = (uint32_t)((size_t)c.N * c.H * c.W * c.C);
+      conv_f8.add(FS256{w.a, yb, c.K, c.K, P, 1}, FG256{w.b, xb, geom_fwd(c)}, w.out, Ncols, plan(c.K, Ncols, P, 256, 256, WIDE_BK, wkc), zeroed, w.row_scale, w.a_scales,
+                  w.b_scales);
     } else if (kind == 1) {
       if (w.M <= 0 || w.N <= 0 || w.K <= 0 || w.M % 8 || w.N % 8 || w.lda % 8 || w.ldb % 8 || w.lda < w.M || w.ldb < w.N) return -1;
       if (!fits32((size_t)w.K * w.lda, 4) || !fits32((size_t)w.K * w.ldb, 4)) return -1;
@@ -453,18 +589,19 @@ extern "C" int clite_wgrad_group(int dtype, const clite_wgrad_item* items, int n
     }
   }
   conv_full.build_map(); conv_fewk.build_map(); conv_fewc.build_map(); linear.build_map();
-  conv_w256.build_map(); linear_w256.build_map();
+  conv_w256.build_map(); linear_w256.build_map(); conv_f8.build_map();
   const size_t o0 = 0, o1 = o0 + conv_full.bytes(), o2 = o1 + conv_fewk.bytes(), o3 = o2 + conv_fewc.bytes(), o4 = o3 + linear.bytes(),
-               o7 = o4 + conv_w256.bytes(), need = o7 + linear_w256.bytes();
+               o7 = o4 + conv_w256.bytes(), o8 = o7 + linear_w256.bytes(), need = o8 + conv_f8.bytes();
   if (need > ws_bytes) return -2;
   char* host = (char*)ws_host;
   char* dev = (char*)ws_dev;
   // fill the host image, copy it once, then enqueue the (up to six) launches: they read `dev` after the copy, in stream order. The long
   // one-per-CU workgroups of the wide buckets go first; the 4-wave buckets fill in behind them
   conv_full.stage(host, o0); conv_fewk.stage(host, o1); conv_fewc.stage(host, o2); linear.stage(host, o3);
-  conv_w256.stage(host, o4); linear_w256.stage(host, o7);
+  conv_w256.stage(host, o4); linear_w256.stage(host, o7); conv_f8.stage(host, o8);
   int rc = (int)hipMemcpyAsync(dev, host, need, hipMemcpyHostToDevice, st);
   if (rc) return rc;
+  if ((rc = conv_f8.launch(dev, o8, st))) return rc;
   if ((rc = conv_w256.launch(dev, o4, st))) return rc;
   if ((rc = linear_w256.launch(dev, o7, st))) return rc;
   if ((rc = conv_full.launch(dev, o0, st))) return rc;

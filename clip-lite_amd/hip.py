@@ -52,7 +52,7 @@ class Bn(C.Structure):
 class WgradItem(C.Structure):
     _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
-                ("row_scale", C.c_void_p)]
+                ("a_scales", C.c_void_p), ("b_scales", C.c_void_p), ("row_scale", C.c_void_p)]
 
 
 class Fp8Item(C.Structure):
@@ -479,6 +479,16 @@ class WgradGroup:
         self.keep += [dy, x, dw, row_scale]
         ncols = cv.R * cv.S * cv.C
         self.wgs += self._wgs(cv.K, ncols, cv.N * cv.Ho * cv.Wo, 64 if cv.K <= 64 else 128, 64 if ncols <= 64 else 128) * (4 if short_k else 1)
+
+    def conv_fp8(self, dy8, x8, cv, dw):
+        """The same weight gradient on fp8 operands (clite_wgrad_item kind 2, BASELINE configs[4]): dy8 = Fp8View of the e5m2 gradient copy that
+        bn_bwd_apply's fused quantiser wrote, x8 = Fp8View of the e4m3 activation copy that bn_apply wrote; the 256 x 256 tile on the block-scaled MFMA."""
+        it = WgradItem()
+        it.kind, it.a, it.b, it.out, it.cv = 2 | self.kflags, p(dy8.q), p(x8.q), p(dw), cv
+        it.a_scales, it.b_scales = p(dy8.scales), p(x8.scales)
+        self.items.append(it)
+        self.keep += [dy8.q, x8.q, dy8.scales, x8.scales, dw]
+        self.wgs += self._wgs(cv.K, cv.R * cv.S * cv.C, cv.N * cv.Ho * cv.Wo, 256, 256)
 
     def linear(self, A, B, M, N, K, out, lda=None, ldb=None, ldc=None):
         """out[M][N] += A[K][M]^T B[K][N] (f32 accumulate)."""

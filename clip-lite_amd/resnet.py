@@ -109,7 +109,7 @@ class ResNet(nn.Module):
 # ---------------------------------------------------------------------------------------------------- executor
 class _Unit:
     """Saved tensors of one conv->BN unit."""
-    __slots__ = ("conv", "bn", "cv", "x", "y", "stats", "out", "bits", "pair", "xsum")
+    __slots__ = ("conv", "bn", "cv", "x", "y", "stats", "out", "bits", "pair", "xsum", "x8")
 
 
 def _alloc(rt, *shape):
@@ -139,16 +139,19 @@ def _conv(rt, x, N, H, W, conv, training, f8=None, x8=None, pair=False):
     pr = _alloc(rt, 2, M, conv.out_channels) if pair else None
     y = pr[1] if pair else _alloc(rt, M, conv.out_channels)
     stats = rt.new_stats(conv.out_channels, M) if training else None
+    xq = None
     if f8 is not None and f8.wants(conv, H):
         # OCP e4m3 operands (include/clite.h: clite_conv_fwd_fp8; policy and scaling: fp8.py); y, the statistics and everything backward stay as they are.
         # An input without a producer-written copy (no scale yet on the first step; the pooled stem output) is quantised here, current scaling
-        hip.conv_fwd_fp8(x8 if x8 is not None else hip.Fp8Tensor(x, rt.dt), f8.weight(conv), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
+        xq = x8 if x8 is not None else hip.Fp8Tensor(x, rt.dt)
+        hip.conv_fwd_fp8(xq, f8.weight(conv), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
     else:
         hip.conv_fwd(x, rt.arena.w(conv.weight), cv, hip.epilogue(y, conv.out_channels, colsum=stats))
     if training and rt.precise_bn:
         hip.bn_centered_var(rt.dt, y, stats, M, conv.out_channels)
     u = _Unit()
     u.conv, u.cv, u.x, u.y, u.stats, u.pair, u.xsum = conv, cv, x, y, stats, pr, None
+    u.x8 = xq if training else None          # the e4m3 copy of the input: the fp8 weight gradient's second operand (DeviceRuntime.fp8_wgrad)
     return u
 
 
@@ -359,12 +362,18 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
         stage_first[pos] = layer
         pos += len(layer)
 
-    def wgrad(dy_, u_):
+    def wgrad(dy_, u_, dy8_=None):
         dw = rt.arena.g(u_.conv.weight)
+        cv_ = u_.cv
         if defer is None:
-            rt.aux_launch(lambda: hip.conv_wgrad(dy_, u_.x, u_.cv, dw), dy_)
+            rt.aux_launch(lambda: hip.conv_wgrad(dy_, u_.x, cv_, dw), dy_)
+        elif (f8 is not None and rt.fp8_wgrad and dy8_ is not None and u_.x8 is not None and cv_.K >= 256 and cv_.R * cv_.S * cv_.C >= 256
+              and cv_.K % 16 == 0 and cv_.C % 16 == 0):
+            # both operands exist in fp8 already (x: e4m3, written by the bn_apply in front for the fp8 forward; dy: e5m2, written by bn_bwd_apply for the
+            # fp8 input gradient): the grouped 256 x 256 tile on the block-scaled MFMA (clite_wgrad_item kind 2) at half the operand bytes
+            defer.conv_fp8(dy8_, u_.x8, cv_, dw)
         else:
-            defer.conv(dy_, u_.x, u_.cv, dw)          # hip.WgradGroup: keeps dy / x referenced until it has been launched
+            defer.conv(dy_, u_.x, cv_, dw)          # hip.WgradGroup: keeps dy / x referenced until it has been launched
 
     rt.arena.ensure_transposed(capturing=rt._capturing)
     # fp8 input gradients (DeviceRuntime.fp8_dgrad; fp8.Fp8Forward): the units' dgrads inside a block read the e5m2 copy of dy that the producing
@@ -436,7 +445,7 @@ def resnet_backward(rt, net, ctx, dfeat, defer=None, stop_block=0, resume=False)
                 dy = _bn_backward_apply(rt, prev, dx, dstats, fp8=q8)
                 continue
             if u.conv.weight.requires_grad:
-                wgrad(dy, u)
+                wgrad(dy, u, dy8)
             Cin = u.conv.in_channels
             # the gradient this block hands to the previous one goes straight into slot 0 of that block's pair buffer (beside its y3) when it folds
             pl_pair = recs[bi - 1][0][-1].pair if (i == 0 and bi > 0) else None

@@ -313,6 +313,7 @@ class DeviceRuntime:
                                            # members of the side stream's groups cost what the apply pass saves
         self.stat_replicas_fixed = False   # True: 8 statistics replicas everywhere (new_stats; tools/ab_runtime.py stat_replicas_fixed=1 for the A/B)
         self.fp8 = False                   # image-encoder forward convs on OCP e4m3 operands, quantised by their producers (BASELINE configs[4]; fp8.py); bf16 mode only
+        self.fp8_wgrad = True              # (with fp8 + fp8_dgrad) weight gradients of the convs whose two operands already exist in fp8, on the block-scaled MFMA (resnet.py wgrad)
         self.fp8_text = False              # ... and BERT's QKV / FFN1 / FFN2 forward linears, quantised by the LayerNorm forward and FFN1's epilogue (fp8.Fp8Text)
         self.zero_chunk = 512 * 1024       # floats per chunk of the zero pool (ZeroPool): every captured phase starts a fresh pool, and most need a few KB of statistics -
                                            # a 16 MB chunk per phase cost ~14 fills of 10 - 20 us per step

@@ -169,6 +169,10 @@ int clite_conv_wgrad_patch(const void* dy, const void* x, const clite_conv* cv, 
  * and needs split-K + float atomics to fill 256 CUs: 328 vs 666 TF/s on the BERT FFN gradient; clip-lite_amd/csrc/gemm_group.hip).
  *   kind 0: conv weight gradient — a = dy [N][Ho][Wo][K], b = x [N][H][W][C], cv, out = dw [K][R][S][C]   (as clite_conv_wgrad)
  *   kind 1: linear weight gradient — out[M][N] (row stride ldc) += a[K][M]^T b[K][N]                     (as clite_gemm_tn with ep.atomic)
+ *   kind 2 (ABI v12; BASELINE configs[4]): conv weight gradient on FP8 operands — a = dy8 [N][Ho][Wo][K] OCP e5m2 (the copy clite_bn_bwd_apply's fused
+ *           quantiser leaves for clite_conv_dgrad_fp8), b = x8 [N][H][W][C] OCP e4m3 (the copy clite_bn_apply leaves for clite_conv_fwd_fp8), cv, a_scales /
+ *           b_scales; C % 16 == 0, K % 16 == 0. v_mfma_scale_f32_32x32x64_f8f6f4 (A e5m2, B e4m3) at unit block scales on the grouped 256 x 256 tile,
+ *           fragments by ds_read_b64_tr_b8, f32 accumulate. Grouped launches only (-1 where the members run one by one).
  * ws_dev / ws_host: device workspace and PINNED host staging of ws_bytes each (clite_wgrad_group_workspace gives a sufficient size); the
  * library fills ws_host, copies it with one hipMemcpyAsync on `stream` and launches — under stream capture that is a memcpy node, so ws_host
  * must stay alive and unchanged for as long as the captured graph is replayed. With dtype = CLITE_F32, in deterministic-reduction mode, or
@@ -189,6 +193,8 @@ typedef struct clite_wgrad_item {
   float* out;
   clite_conv cv;                 /* kind 0 */
   int32_t M, N, K, lda, ldb, ldc;  /* kind 1 */
+  const float* a_scales;         /* ABI v12, kind 2 only: device f32 {scale, 1 / scale} of a (clite_bn.fp8_scale of the pass that wrote it) ... */
+  const float* b_scales;         /* ... and of b; out += a_scales[1] * b_scales[1] * (a^T b) */
   const float* row_scale;        /* ABI v12. NULL, or device f32 [rows of out]: out[r][:] += row_scale[r] * (A^T B)[r][:] — the folded BatchNorm backward's
                                   * per-channel factor ka (clite_bn_fold_prepare) on a weight gradient contracted against dz instead of dy. Grouped
                                   * launches only: -1 where the members run one by one (f32, deterministic mode, no workspace). */

@@ -506,3 +506,40 @@ def test_resnet101_fp8_step_against_fp32_oracle():
     assert abs(rows[False][0] - want) < 1e-2 and all(v >= 0.90 for v in rows[False][1].values()), rows[False]
     for k, v in rows[False][1].items():
         assert c8[k] >= v - 0.22, (k, c8[k], v)
+
+
+# the shapes of the benchmark's eligible members (layer3 / layer4 at batch 128: 3 x 3 256 -> 256 @14, 1 x 1 256 -> 1024 and 1024 -> 256 @14, 3 x 3 512 -> 512 @7)
+# + a strided and a ragged one
+@pytest.mark.parametrize("N,H,W,Cc,K,R,st,pad", [(128, 14, 14, 256, 256, 3, 1, 1), (128, 14, 14, 256, 1024, 1, 1, 0), (128, 14, 14, 1024, 256, 1, 1, 0),
+                                                 (128, 7, 7, 512, 512, 3, 1, 1), (16, 28, 28, 256, 256, 3, 2, 1), (3, 9, 11, 288, 320, 3, 1, 1)])
+def test_grouped_weight_gradient_fp8_matches_dequantised_fp32(N, H, W, Cc, K, R, st, pad):
+    """clite_wgrad_group kind 2 (ABI v12): the conv weight gradient with dy in e5m2 and x in e4m3 on the block-scaled MFMA, fragments by
+    ds_read_b64_tr_b8, against torch's f32 weight gradient of the DE-QUANTISED operands (products of two fp8 values are exact in f32; the bar is the
+    summation order's: 2e-3 of max, well inside the review's 6e-3) - beside a bf16 member of the same launch, `+=` semantics and the zeroed-store form."""
+    hip = _hip()
+    cv = hip.conv_desc(BF16, N, H, W, Cc, K, R, R, st, pad)
+    Ho, Wo = cv.Ho, cv.Wo
+    g = torch.Generator(device="cuda").manual_seed(H + K + R)
+    x = torch.relu(torch.randn(N, H, W, Cc, device="cuda", generator=g)).bfloat16()
+    x8 = hip.Fp8Tensor(x, BF16)
+    dy = (torch.randn(N * Ho * Wo, K, device="cuda", generator=g) * 1e-3).bfloat16()
+    a = dy.float().abs().max().item()
+    scales = torch.tensor([448.0 / a, a / 448.0], device="cuda")
+    q = (dy.float() * scales[0]).clamp(-57344, 57344).to(torch.float8_e5m2)
+    dy8 = hip.Fp8View(q.view(torch.uint8), scales)
+    xdeq = (x8.q.view(torch.float8_e4m3fn).float() * x8.scales[1]).permute(0, 3, 1, 2)
+    dydeq = (q.float() * scales[1]).view(N, Ho, Wo, K).permute(0, 3, 1, 2)
+    wz = torch.zeros(K, Cc, R, R, device="cuda", requires_grad=True)
+    with torch.backends.cudnn.flags(enabled=False):
+        F.conv2d(xdeq, wz, stride=st, padding=pad).backward(dydeq)
+    ref = wz.grad.permute(0, 2, 3, 1).contiguous()          # [K][R][S][C]
+    for zeroed, init in ((False, 1.0), (True, 0.0)):
+        dw = torch.full((K, R, R, Cc), init, device="cuda")
+        dwb = torch.zeros(K, R, R, Cc, device="cuda")
+        grp = hip.WgradGroup(BF16, zeroed=zeroed)
+        grp.conv_fp8(dy8, x8, cv, dw)
+        grp.conv(dy, x, cv, dwb)          # a bf16 member beside it: the launch mixes buckets
+        grp.launch()
+        torch.cuda.synchronize()
+        assert _rel(dw - init, ref) < 2e-3, _rel(dw - init, ref)
+        assert _rel(dwb, ref) < 0.2          # (the bf16 member sees the un-quantised operands: fp8's cost on these operands, ~10 %)

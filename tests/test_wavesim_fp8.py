@@ -465,3 +465,53 @@ def test_grouped_weight_quantiser_and_scale_update():
     assert L.clite_fp8_scale_update(ptr(am), ptr(sc), 4, None) == 0
     assert np.allclose(sc[0], [224.0, 2.0 / 448.0]) and np.array_equal(sc[1], [3.0, 5.0]) and np.isnan(sc[2]).all() and np.isnan(sc[3]).all()
     assert not am.view(np.uint32).any()
+
+
+@pytest.mark.parametrize("N,H,W,Cc,K,R,st,pad", [(2, 8, 8, 64, 64, 3, 1, 1), (3, 6, 6, 288, 272, 1, 1, 0), (2, 9, 7, 32, 64, 3, 2, 1), (2, 40, 40, 48, 32, 1, 1, 0)])
+def test_grouped_weight_gradient_on_fp8_operands(N, H, W, Cc, K, R, st, pad):
+    """clite_wgrad_group kind 2 (ABI v12, BASELINE configs[4]): dW += dy8^T x8 * a_scales[1] * b_scales[1] with dy in e5m2 and x in e4m3 — both operand
+    images have the contraction index (the pixel) as the slow one, the fragments come out of them through ds_read_b64_tr_b8 (the layout
+    tools/micro/tr8_probe.hip measured on the hardware, emulated lane-accurately), 64 pixels per v_mfma_scale_f32_32x32x64_f8f6f4 — against numpy on the
+    de-quantised operands (an e5m2 times an e4m3 value is exact in f32). Ragged tiles both ways, a windowed and a strided member, a member whose
+    pixel range is cut into two k-chunks (3200 pixels = 50 tiles of 64 under CLITE_WGRAD_SHORTK's 32-tile chunks), `+=` and the CLITE_WGRAD_ZEROED store form,
+    and a row_scale."""
+    from test_wavesim_igemm import conv_wgrad_ref
+    L = lib()
+    L.clite_fp8_quantize.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.clite_wgrad_group.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.clite_wgrad_group_workspace.argtypes = [C.c_int, C.c_int64, C.c_void_p]
+
+    class Item(C.Structure):
+        _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
+                    ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                    ("a_scales", C.c_void_p), ("b_scales", C.c_void_p), ("row_scale", C.c_void_p)]
+    rng = np.random.default_rng(H * 7 + K)
+    Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+    cv = Conv(BF16, N, H, W, Cc, K, R, R, st, pad, Ho, Wo)
+    x = rng.standard_normal((N, H, W, Cc)).astype(np.float32)
+    qx, sx, _ = _quant(L, x, F32)
+    dy = (rng.standard_normal((N, Ho, Wo, K)) * 1e-3).astype(np.float32)
+    sdy = np.float32(448.0 / np.abs(dy).max())
+    qdy = quantize_e5m2_at(dy, sdy)
+    sy = np.array([sdy, 1 / sdy], np.float32)
+    ref = conv_wgrad_ref(E5M2[qdy], E4M3[qx], (K, R, R, Cc), st, pad) * (sy[1] * sx[1])
+    nb = C.c_uint64(0)
+    assert L.clite_wgrad_group_workspace(1, 4096, C.byref(nb)) == 0
+    ws_dev, ws_host = np.zeros(nb.value, np.uint8), np.zeros(nb.value, np.uint8)
+    for kind, init, rs in ((2 | 0x400, 1.0, None), (2 | 0x200 | 0x400, 0.0, None), (2, 0.25, (1 + 0.5 * rng.standard_normal(K)).astype(np.float32))):
+        dw = np.full((K, R, R, Cc), init, np.float32)
+        it = Item()
+        it.kind, it.a, it.b, it.out, it.cv = kind, ptr(qdy).value, ptr(qx).value, ptr(dw).value, cv
+        it.a_scales, it.b_scales = ptr(sy).value, ptr(sx).value
+        it.row_scale = ptr(rs).value if rs is not None else None
+        arr = (Item * 1)(it)
+        assert L.clite_wgrad_group(BF16, arr, 1, ptr(ws_dev), ptr(ws_host), nb.value, None) == 0
+        want = init + (ref if rs is None else ref * rs.reshape(-1, 1, 1, 1))
+        assert np.abs(dw - want).max() <= 2e-5 * max(np.abs(want).max(), 1e-9), np.abs(dw - want).max()
+    # what the formats cost on these operands (e5m2 carries two mantissa bits): within 15 % of the exact gradient's scale
+    exact = conv_wgrad_ref(dy, x, (K, R, R, Cc), st, pad)
+    assert np.abs(ref - exact).max() <= 0.15 * np.abs(exact).max()
+    it.a_scales = None
+    assert L.clite_wgrad_group(BF16, (Item * 1)(it), 1, ptr(ws_dev), ptr(ws_host), nb.value, None) == -1          # no scales: refused
+    it.a_scales = ptr(sy).value
+    assert L.clite_wgrad_group(BF16, (Item * 1)(it), 1, None, None, 0, None) == -1                                  # members one by one: no fp8 form

@@ -369,7 +369,7 @@ def test_grouped_weight_gradients():
     class Item(C.Structure):
         _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
                     ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
-                    ("row_scale", C.c_void_p)]
+                    ("a_scales", C.c_void_p), ("b_scales", C.c_void_p), ("row_scale", C.c_void_p)]
 
     rng = np.random.default_rng(5)
     L = lib()
@@ -515,7 +515,7 @@ def test_folded_batchnorm_backward(M, K, Cin):
     class Item(C.Structure):
         _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
                     ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
-                    ("row_scale", C.c_void_p)]
+                    ("a_scales", C.c_void_p), ("b_scales", C.c_void_p), ("row_scale", C.c_void_p)]
     dw, G = np.zeros((K, Cin), np.float32), np.zeros((Cin, Cin), np.float32)
     ka = np.ascontiguousarray(coef[0])
     it0 = Item(); it0.kind, it0.a, it0.b, it0.out, it0.cv = 0x200, ptr(dzb).value, ptr(ab).value, ptr(dw).value, Conv(BF16, 1, 1, M, Cin, K, 1, 1, 1, 0, 1, M)

@@ -398,6 +398,26 @@ inline s16x4 lds_read_tr16(const void* p) {
   return r;
 }
 
+// ds_read_b64_tr_b8 as measured by tools/micro/tr8_probe.hip: inside each group of 16 lanes, lane s supplies the address of an 8-byte chunk; lane i
+// receives in byte j byte (i & 7) of the chunk supplied by lane 2 j + (i >> 3).
+inline u32x2 lds_read_tr8(const void* p) {
+  auto& w = wavesim::g_block->waves[wavesim::g_wave];
+  int l = wavesim::g_lane;
+  assert(((uintptr_t)p & 7) == 0 && "ds_read_b64_tr_b8 needs an 8-byte aligned address");
+  w.slot[l][0] = (uint64_t)(uintptr_t)p;
+  wave_barrier_();
+  int g = l & ~15, i = l & 15;
+  uint8_t b[8];
+  for (int j = 0; j < 8; ++j) {
+    const uint8_t* chunk = (const uint8_t*)(uintptr_t)w.slot[g + 2 * j + (i >> 3)][0];
+    b[j] = chunk[i & 7];
+  }
+  wave_barrier_();
+  u32x2 r;
+  memcpy(&r, b, 8);
+  return r;
+}
+
 inline void atomic_max_u32(uint32_t* p, uint32_t v) {
   std::atomic_ref<uint32_t> a(*p);
   uint32_t old = a.load();
