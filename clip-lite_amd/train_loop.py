@@ -358,8 +358,12 @@ class TrainStep:
                         capture("wgrad_" + sg, pool_side, wgrad(i))
                 for i in on_main:          # behind the chain, in segment order
                     capture("wgrad_" + segs[i], pool_main, wgrad(i))
+                # the last segment's stand-alone launches (bn1's backward + conv1's weight gradient, 0.2 ms): beside the last group on the side stream, or
+                # behind it on the main stream (extras_on_main) - whichever stream ends earlier (round 5: the folded BatchNorm backward shortened the main
+                # stream's chain; same-box A/B in DESIGN.md section 5)
+                self._extras_main = bool(getattr(self, "extras_on_main", False))
                 if keep["wg_" + segs[-1]].extra:
-                    capture("wgrad_last_extras", pool_side, wgrad_last_extras)
+                    capture("wgrad_last_extras", pool_main if self._extras_main else pool_side, wgrad_last_extras)
                 if self.clip and self.clip > 0:          # (without clipping there is no norm: an empty capture is not worth finding out about)
                     capture("norm_early", pool_main, norm_early)
                 capture("norm", pool_main, norm)
@@ -458,13 +462,15 @@ class TrainStep:
                 self._hand(self._seg_spans[i], side)
         G["image_bwd_" + self._segs[-1]].replay()
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            if "wgrad_last_extras" in G:
-                G["wgrad_last_extras"].replay()    # three 3 x 3 weight gradients + the stem's, beside ...
+        if "wgrad_last_extras" in G and not self._extras_main:
+            with torch.cuda.stream(side):
+                G["wgrad_last_extras"].replay()    # bn1's backward + the stem's weight gradient, beside ...
         for i in on_main:                          # ... the grouped launches behind the chain
             G["wgrad_" + self._segs[i]].replay()
             if ex is not None and i < len(self._segs) - 1:
                 self._hand(self._seg_spans[i], main)
+        if "wgrad_last_extras" in G and self._extras_main:
+            G["wgrad_last_extras"].replay()
         early_done = ex is None and getattr(self, "norm_overlap", True) and "norm_early" in G
         if early_done:
             main.wait_event(ev_early)
