@@ -8,7 +8,7 @@ HDRS       := $(wildcard $(CSRC)/*.h) include/clite.h
 OBJS       := $(patsubst $(CSRC)/%.hip,build/hip/%.o,$(SRCS))
 SIMOBJS    := $(patsubst $(CSRC)/%.hip,build/sim/%.o,$(SRCS)) build/sim/wavesim.o
 HIPFLAGS   := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wno-unused-value
-SIMFLAGS   := -x c++ -std=c++20 -O1 -g -fPIC -pthread -Itests/wavesim -Iinclude -I$(CSRC) -include tests/wavesim/wavesim.h -Wno-unknown-attributes -Wno-unused-value -Wno-psabi -DCLITE_BN_SLOTS=4 -DCLITE_PATCH_WGS=2 -DCLITE_GROUP_KCHUNK=24 $(SIM_EXTRA)
+SIMFLAGS   := -x c++ -std=c++20 -O1 -g -fPIC -pthread -Itests/wavesim -Iinclude -I$(CSRC) -include tests/wavesim/wavesim.h -Wno-unknown-attributes -Wno-unused-value -Wno-psabi -DCLITE_BN_SLOTS=4 -DCLITE_PATCH_WGS=2 -DCLITE_GROUP_KCHUNK=24 -DCLITE_FOLD_ROWS_WGS=3 $(SIM_EXTRA)
 
 .PHONY: hip sim diag variant clean
 hip: $(LIBDIR)/libclite_hip.so

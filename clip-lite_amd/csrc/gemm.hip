@@ -794,6 +794,10 @@ extern "C" int clite_conv_dgrad_bnfold(const void* pair, const void* w2, int M, 
   g.div_w = fastdiv_make(M);
   const uint32_t ab = (uint32_t)((size_t)2 * M * K * sizeof(T)), wb = (uint32_t)((size_t)Cin * 2 * K * sizeof(T));
   hipStream_t st = (hipStream_t)stream;
+  if (use_dma()) {          // K = 256, Cin = 64 (the 56 x 56 stage): the streaming kernel of fold_dgrad.hip
+    const int rc = launch_fold_dgrad_rows(pair, w2, M, K, Cin, *ep, st);
+    if (rc != WIDE_NOT_TAKEN) return rc;
+  }
   if (Cin <= 64) {
     GatherKC<T, 256, BK, true> la{pair, ab, g};
     GatherKC<T, 64, BK, false> lb{w2, wb, geom_dense(Cin, 2 * K)};

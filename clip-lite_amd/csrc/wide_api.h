@@ -27,6 +27,9 @@ int launch_conv3x3_wgrad_patch(const void* dy, const void* x, const clite_conv& 
 // ... and fused with bn1's backward (the un-pooled gradient formed in LDS from the pooled gradient, the window indices and conv1's output)
 
 int launch_stem_wgrad_patch(const void* dy, const void* xpad, int N, int Hp, int Wp, int Ho, int Wo, float* dw, void* ws, size_t ws_bytes, hipStream_t st);
+// fold_dgrad.hip: the folded BatchNorm backward's input gradient for K = 256, Cin = 64 (the 56 x 56 stage) as a streaming kernel — whole-row K tiles, weights
+// resident in LDS. Returns WIDE_NOT_TAKEN for every launch it does not cover (shape, epilogue form, deterministic mode, a forced tile policy).
+int launch_fold_dgrad_rows(const void* pair, const void* w2, int M, int K, int Cin, const clite_epilogue& ep, hipStream_t st);
 // the tile policy set by clite_set_tile_policy (gemm_wide.hip): 0 = automatic; the forced forms keep every launch on the kernel family they name
 int tile_policy_value();
 

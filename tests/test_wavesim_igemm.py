@@ -534,6 +534,50 @@ def test_folded_batchnorm_backward(M, K, Cin):
     _close(dw, dW_ref, 3e-3)
 
 
+@pytest.mark.policy_independent
+@pytest.mark.parametrize("M", [96, 250, 1000])
+def test_folded_dgrad_streaming_kernel_k256_c64(M):
+    """fold_dgrad.hip: clite_conv_dgrad_bnfold for K = 256, Cin = 64 (ResNet-50 layer1's conv3) under the automatic tile policy — whole-row K tiles by
+    LDS-DMA into XOR-swizzled [row][512 B] images, the weights resident in LDS, a two-tile ring, the two K parts of a tile multiplied by different waves
+    and joined in LDS, the row epilogue with operands requested a tile ahead. Ragged pixel counts (the last tile partial; 1000 pixels = 32 tiles over the
+    simulator build's 3 persistent workgroups); against numpy, and bit-identical in the stored output to the tile engine's launch of the same problem."""
+    from simlib import Bn
+    L = lib()
+    assert L.clite_set_tile_policy(0) == 0
+    K, Cin, R = 256, 64, 2
+    rng = np.random.default_rng(M)
+    dz, _ = _prep(rng.standard_normal((M, K), dtype=np.float32) * 0.1 * (rng.random((M, K)) > 0.4), BF16)
+    y, _ = _prep(rng.standard_normal((M, K), dtype=np.float32) + 0.5, BF16)
+    pair = np.concatenate([to_bf16(dz).reshape(1, M, K), to_bf16(y).reshape(1, M, K)], axis=0).copy()
+    w2f, w2 = _prep(rng.standard_normal((Cin, 2, K), dtype=np.float32) * 0.05, BF16)
+    bias = rng.standard_normal(Cin).astype(np.float32) * 0.1
+    y2, y2b = _prep(rng.standard_normal((M, Cin), dtype=np.float32) + 1.0, BF16)
+    st2 = np.zeros((R, 3, Cin), np.float32)
+    st2[0, 0], st2[1, 0] = 0.5 * y2.sum(0), 0.5 * y2.sum(0)
+    mean2 = y2.mean(0)
+    mask = rng.random((M, Cin)) > 0.3
+    bits = pack_relu_bits(mask.astype(np.float32))
+    L.clite_conv_dgrad_bnfold.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+
+    def run(policy):
+        assert L.clite_set_tile_policy(policy) == 0
+        out, d2 = np.zeros((M, Cin), np.uint16), np.zeros((R, 3, Cin), np.float32)
+        ep = make_ep(out, Cin, bias=bias, colsum=d2, relu_bits=bits)
+        ep.colsum_replicas, ep.colsum_stride = R, 3 * Cin
+        ep.bn_y, ep.bn_stats, ep.bn_replicas, ep.bn_rstride, ep.bn_inv_count = ptr(y2b), ptr(st2), R, 3 * Cin, 1.0 / M
+        assert L.clite_conv_dgrad_bnfold(ptr(pair), ptr(w2), M, K, Cin, C.byref(ep), None) == 0
+        return from_bf16(out), d2.sum(0)
+    got, d = run(0)                    # the streaming kernel
+    ref = (y @ w2f[:, 0, :].T + dz @ w2f[:, 1, :].T + bias) * mask
+    _close(got, ref, 6e-3)
+    _close(d[0], got.sum(0), 5e-3)
+    _close(d[1], (got * (y2 - mean2)).sum(0), 5e-3)
+    got4, d4 = run(4)                  # the 4-wave tile engine on the same problem
+    L.clite_set_tile_policy(0)
+    _close(got, got4, 8e-3)            # (different summation order over k: within one bf16 rounding of each other)
+    _close(d, d4, 5e-3)
+
+
 class TransposeItem(C.Structure):
     _fields_ = [("src_off", C.c_uint64), ("dst_off", C.c_uint64)] + [(n, C.c_uint32) for n in
                 ("rows", "cols", "src_ld", "dst_ld", "batch", "src_bstride", "dst_bstride", "first_tile")]
