@@ -414,6 +414,18 @@ int splitk_plan(const clite_epilogue& ep, int M, int N, int ktiles) {
   return want >= 2 ? (int)want : 0;
 }
 
+// splits of a forward-form product that accumulates into a caller-owned f32 buffer (ep.atomic on gemm_nt / gemm_nn: the loss heads' fused
+// MI blocks, loss.py): few output tiles against megabytes of weights, i.e. the workspace form's balance, not the weight gradients'
+int fewtile_splits(int M, int N, int ktiles) {
+  long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+  if (tiles > 48 || ktiles < 8) return pick_splits(M, N, ktiles);
+  const int pref = splitk_ws_pref();
+  const long target = pref > 1 ? pref : 64;
+  long want = (target + tiles - 1) / tiles, cap = ktiles / 2;
+  if (want > cap) want = cap;
+  return want >= 1 ? (int)want : 1;
+}
+
 template <typename T>
 int splitk_finish(const clite_epilogue& ep, int M, int N, hipStream_t st) {
   hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((N / 8 + 7) / 8), dim3(256), 0, st, (const float*)ep.splitk_ws, ep, M, N);
@@ -430,7 +442,7 @@ template <typename T>
 int gemm_nt(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
   constexpr int BK = Cfg<T>::BK;
   uint32_t ab = span_bytes(M, K, lda, sizeof(T)), bb = span_bytes(N, K, ldb, sizeof(T));
-  int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
+  int splits = ep->atomic ? fewtile_splits(M, N, (K + BK - 1) / BK) : 1;
   if (int sk = splitk_plan<T>(*ep, M, N, (K + BK - 1) / BK)) {
     clite_epilogue e1 = splitk_partial(*ep, N);
     GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K, lda)};
@@ -452,7 +464,7 @@ template <typename T>
 int gemm_nn(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const clite_epilogue* ep, hipStream_t st) {
   constexpr int BK = Cfg<T>::BK;
   uint32_t ab = span_bytes(M, K, lda, sizeof(T)), bb = span_bytes(K, N, ldb, sizeof(T));
-  int splits = ep->atomic ? pick_splits(M, N, (K + BK - 1) / BK) : 1;
+  int splits = ep->atomic ? fewtile_splits(M, N, (K + BK - 1) / BK) : 1;
   if (int sk = splitk_plan<T>(*ep, M, N, (K + BK - 1) / BK)) {
     clite_epilogue e1 = splitk_partial(*ep, N);
     GatherKC<T, 128, BK, false> la{A, ab, geom_dense(M, K, lda)};

@@ -15,6 +15,9 @@ typedef WideCfg<256, 256, 128, 64, 1> W256;       // 2 x 4 waves of 128 x 64, 2-
 
 template <class CFG> struct Stages { static constexpr int n = 3; };
 template <> struct Stages<W256> { static constexpr int n = 2; };
+#ifdef CLITE_W128_STAGES          // A/B builds only: the 128 x 128 wide tile's ring depth (3 stages = 96 KB of LDS, 2 = 64 KB: what fits beside another kernel's workgroup on a CU)
+template <> struct Stages<W128> { static constexpr int n = CLITE_W128_STAGES; };
+#endif
 
 template <int ROWS> WideKC<ROWS, false> mk_kc(const WideOperand& o) { return WideKC<ROWS, false>{o.ptr, o.bytes, o.g}; }
 template <int ROWS> WideKC<ROWS, true> mk_kcd(const WideOperand& o) { return WideKC<ROWS, true>{o.ptr, o.bytes, o.g}; }

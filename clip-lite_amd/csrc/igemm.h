@@ -355,7 +355,10 @@ struct TileCfg {
   static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
   static constexpr int RM = WM / 32, RN = WN / 32;
   static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroups");
-  static constexpr int EPI_PITCH = BN * 4 + 16;
+#ifndef CLITE_EPI_PAD
+#define CLITE_EPI_PAD 16          // A/B builds: 0 makes the BatchNorm-backward kernels' whole-tile staging 64 KB instead of 67.6 (what fits beside a 96 KB workgroup on a CU)
+#endif
+  static constexpr int EPI_PITCH = BN * 4 + CLITE_EPI_PAD;
   static constexpr int EPI_BYTES = WM * EPI_PITCH;
 };
 

@@ -49,6 +49,13 @@ class Bn(C.Structure):
     ]
 
 
+class MiBlock(C.Structure):
+    _fields_ = [("M", C.c_int32), ("Fin", C.c_int32), ("U", C.c_int32), ("updates", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("ln_eps", C.c_float),
+                ("reserved", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("bs", "b2", "gamma", "beta", "running_mean", "running_var", "z", "a", "stats", "sc", "t", "out", "ln_gamma", "ln_beta",
+                                          "ln_stats", "dtt", "dz", "dxs", "dres", "dx", "dgamma", "dbeta", "db2", "dbs")]
+
+
 class WgradItem(C.Structure):
     _fields_ = [("kind", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("cv", Conv),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
@@ -84,6 +91,10 @@ _SIGNATURES = {
     "clite_conv_dgrad_s2class": [_V, _V, _V, _I, _I, _V, _V],
     "clite_conv_dgrad_wt": [_V, _V, _V, _V, _V],
     "clite_conv_dgrad_s2class_wt": [_V, _V, _V, _I, _I, _V, _V],
+    "clite_mi_block_fwd1": [_V, _V],
+    "clite_mi_block_fwd2": [_V, _V],
+    "clite_mi_block_bwd1": [_V, _V],
+    "clite_mi_block_bwd2": [_V, _V],
     "clite_bn_fold_prepare": [_V, _V, _V, _I, _V, _V, _V, _V, _V, _V],
     "clite_conv_dgrad_bnfold": [_V, _V, _I, _I, _I, _V, _V],
     "clite_bn_fold_wgrad_finish": [_V, _V, _I, _I, _V, _V, _I, _I, _I, _V, _V],
@@ -311,6 +322,19 @@ def conv_dgrad(dy, w, cv, ep, wt=False):
     """wt: `w` is the transposed copy [C][R][S][K] (Arena.wt): both GEMM operands k-contiguous (clite_conv_dgrad_wt)."""
     fn = lib().clite_conv_dgrad_wt if wt else lib().clite_conv_dgrad
     check(fn(p(dy), p(w), C.byref(cv), C.byref(ep), stream_ptr(dy)), "conv_dgrad")
+
+
+def mi_block(**kw):
+    """clite_mi_block with the given fields (tensors -> device pointers)."""
+    b = MiBlock()
+    for k, v in kw.items():
+        setattr(b, k, p(v) if torch.is_tensor(v) else v)
+    return b
+
+
+def mi_block_call(which, b, like):
+    """which: "fwd1" | "fwd2" | "bwd1" | "bwd2" (include/clite.h: clite_mi_block_*)."""
+    check(getattr(lib(), "clite_mi_block_" + which)(C.byref(b), stream_ptr(like)), "mi_block_" + which)
 
 
 class BnFold:

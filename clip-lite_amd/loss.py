@@ -138,11 +138,34 @@ def _alloc(rt, *shape):
     return torch.empty(shape, device=rt.device, dtype=rt.tdtype)
 
 
+def _mi_fused_ok(rt, blk, B, training):
+    """The four-kernel form of the block's non-GEMM work (hip.mi_block_call; csrc/heads_fused.hip): bf16 training steps of at most 128 rows."""
+    return (rt.fused_heads and rt.lowp and training and blk.bln and B <= 128 and blk.feature_sz % 16 == 0 and blk.units % 16 == 0 and not rt.precise_bn
+            and not hip.is_deterministic())
+
+
 def mi_block_forward(rt, blk, x, training, updates=2):
     """x: [B][F] compute dtype. Returns (LN(W2 relu(bn(W1 x)) + b2 + Ws x + bs), ctx)."""
     dt, A = rt.dt, rt.arena
     B, Fin, U = x.shape[0], blk.feature_sz, blk.units
     l1, bn, _, l2 = blk.feature_nonlinear
+    if _mi_fused_ok(rt, blk, B, training):
+        # five launches instead of ten: the three products accumulate (split-K, float atomics) into zeroed f32 workspaces, and the column-wise work
+        # (BatchNorm1d statistics, both running-statistics updates, relu) and the row-wise work (biases, shortcut, LayerNorm) are one kernel each
+        sc, ln = blk.feature_shortcut, blk.feature_block_ln
+        z, a, t, out = (_alloc(rt, B, U) for _ in range(4))
+        stats = hip.Stats(torch.empty(3 * U, device=rt.device, dtype=torch.float32), 1, U)
+        lst = torch.empty(B, 2, device=rt.device, dtype=torch.float32)
+        ws1, ws2 = rt.zpool.take(B * 2 * U).view(B, 2 * U), rt.zpool.take(B * U).view(B, U)
+        hip.gemm_nt(dt, x, A.w(l1.weight), B, U, Fin, hip.epilogue(ws1, 2 * U, atomic=True))
+        hip.gemm_nt(dt, x, A.w(sc.weight), B, U, Fin, hip.epilogue(ws1[:, U:], 2 * U, atomic=True))
+        desc = hip.mi_block(M=B, Fin=Fin, U=U, updates=updates, momentum=bn.momentum, eps=bn.eps, ln_eps=ln.eps, bs=sc.bias, b2=l2.bias, gamma=bn.weight,
+                            beta=bn.bias, running_mean=bn.running_mean, running_var=bn.running_var, z=z, a=a, stats=stats.t, sc=ws1, t=t, out=out,
+                            ln_gamma=ln.weight, ln_beta=ln.bias, ln_stats=lst, dxs=ws2)
+        hip.mi_block_call("fwd1", desc, x)
+        hip.gemm_nt(dt, a, A.w(l2.weight), B, U, U, hip.epilogue(ws2, U, atomic=True))
+        hip.mi_block_call("fwd2", desc, x)
+        return out, (x, z, stats, a, t, lst)
     z = _alloc(rt, B, U)
     stats = rt.new_stats(U, B) if training else None
     hip.gemm_nt(dt, x, A.w(l1.weight), B, U, Fin, hip.epilogue(z, U, colsum=stats, ws=rt.gemm_ws(B, U)))
@@ -183,6 +206,22 @@ def mi_block_backward(rt, blk, ctx, dout, dx_residual=None, defer=None):
     else:
         dtt = dout
     sc = blk.feature_shortcut
+    if _mi_fused_ok(rt, blk, B, True) and stats.R == 1 and all(p_.requires_grad for p_ in (l1.weight, l2.weight, sc.weight, bn.weight, bn.bias, l2.bias, sc.bias)):
+        # five launches instead of nine: dtt Ws and dtt W2 accumulate side by side in one f32 workspace [B][Fin + U], one kernel turns the second half into
+        # dz (BatchNorm1d backward, its two parameter gradients, both bias gradients), dz W1 accumulates onto the first half, one kernel stores dx
+        dz, dx = _alloc(rt, B, U), _alloc(rt, B, Fin)
+        ws3 = rt.zpool.take(B * (Fin + U)).view(B, Fin + U)
+        hip.gemm_nn(dt, dtt, A.w(sc.weight), B, Fin, U, hip.epilogue(ws3, Fin + U, atomic=True))
+        hip.gemm_nn(dt, dtt, A.w(l2.weight), B, U, U, hip.epilogue(ws3[:, Fin:], Fin + U, atomic=True))
+        desc = hip.mi_block(M=B, Fin=Fin, U=U, updates=0, momentum=bn.momentum, eps=bn.eps, gamma=bn.weight, z=z, a=a, stats=stats.t, dtt=dtt, dz=dz, dxs=ws3,
+                            dres=dx_residual, dx=dx, dgamma=A.g(bn.weight), dbeta=A.g(bn.bias), db2=A.g(l2.bias), dbs=A.g(sc.bias))
+        hip.mi_block_call("bwd1", desc, dtt)
+        hip.gemm_nn(dt, dz, A.w(l1.weight), B, Fin, U, hip.epilogue(ws3, Fin + U, atomic=True))
+        hip.mi_block_call("bwd2", desc, dtt)
+        _linear_grads(rt, sc, dtt, x, B, bias_done=True, defer=defer)
+        _linear_grads(rt, l2, dtt, a, B, bias_done=True, defer=defer)
+        _linear_grads(rt, l1, dz, x, B, defer=defer)
+        return dx
     _linear_grads(rt, sc, dtt, x, B, defer=defer)
     dx = _alloc(rt, B, Fin)
     hip.gemm_nn(dt, dtt, A.w(sc.weight), B, Fin, U, hip.epilogue(dx, Fin, residual=dx_residual, ws=rt.gemm_ws(B, Fin)))

@@ -307,6 +307,7 @@ class DeviceRuntime:
         self.fuse_bn_backward = True       # BatchNorm-backward reductions inside the dgrad epilogues (resnet.py)
         self.defer_head_wgrads = True      # captured step: the loss heads' Linear weight gradients ride in the encoders' grouped launches (train_loop.py)
         self.compact_shortcut = True       # stride-2 shortcuts' input gradients kept compact, added by the main branch's BatchNorm-backward dgrad (resnet.py; bf16)
+        self.fused_heads = True            # the MI projection blocks' non-GEMM work in four kernels: 5 + 5 launches per block instead of 10 + 9 (loss.mi_block_forward / _backward; csrc/heads_fused.hip; bf16, <= 128 rows)
         self.bn_fold = True                # block-output BatchNorm backward folded into conv3's input + weight gradients: no apply pass, no dy (resnet.py _fold_wanted; bf16)
         self.bn_fold_min_rows = 300000     # ... where the tensors have at least this many rows (56 x 56 at batch 128: 401 408). Same-box A/B of the captured step: off 14.73 ms,
                                            # layer1 14.54, layers 1 + 2 14.75, + layer3 15.5 — below 56 x 56 the doubled K of the input gradient and the Gram

@@ -352,6 +352,53 @@ int clite_bn_fold_wgrad_finish(const float* G, const float* asum, int asum_repli
                                float* dw, void* stream);
 
 
+/* ---- ABI v12: the MI projection block of the loss heads (reference loss.py:12-40: LayerNorm(W2 relu(BatchNorm1d(W1 x)) + b2 + Ws x + bs)): everything
+ * around its six small GEMMs in four kernels, bf16, M <= 128 rows (clip-lite_amd/csrc/heads_fused.hip). The GEMMs stay clite_gemm_nt launches that
+ * ACCUMULATE (ep.atomic, f32) into zeroed workspaces; what the step pays for between the encoders' forward and backward is dependent launches, and these
+ * four replace fifteen of them:
+ *   clite_mi_block_fwd1  sc = f32 [M][2 U] with columns [0, U) = x W1^T and [U, 2 U) = x Ws^T. Per 32-column slab: z <- bf16(sc[:, :U]); stats <- {sum z,
+ *                        sum z^2, 0} of the stored values (one replica); the running statistics updated `updates` times (the reference runs the block twice per
+ *                        step on the same statistics); a <- relu(bn(z)) with the batch statistics.
+ *   clite_mi_block_fwd2  dxs = f32 [M][U] = a W2^T. Per row: t <- bf16(dxs + b2 + sc[:, U:] + bs); out <- LayerNorm(t) (ln_gamma, ln_beta, ln_eps); ln_stats
+ *                        <- {mean, rstd} per row (clite_layernorm_bwd's layout).
+ *   clite_mi_block_bwd1  dxs = f32 [M][Fin + U] with columns [Fin, Fin + U) = dtt W2 (and [0, Fin) = dtt Ws). Per 32-column slab: da masked by a > 0,
+ *                        BatchNorm1d backward -> dz (bf16); dgamma, dbeta +=; db2, dbs += colsum(dtt).
+ *   clite_mi_block_bwd2  after dz W1 has been accumulated onto columns [0, Fin): dx <- bf16(dxs[:, :Fin] + dres).
+ * Fin % 16 == 0, U % 16 == 0, U <= 4096. -1 for M > 128 or a missing operand (the caller then takes the generic kernels). */
+typedef struct clite_mi_block {
+  int32_t M, Fin, U, updates;
+  float momentum, eps, ln_eps;
+  int32_t reserved;
+  const float* bs;          /* f32 [U] or NULL (feature_shortcut.bias) */
+  const float* b2;          /* f32 [U] or NULL */
+  const float* gamma;       /* BatchNorm1d weight / bias, running statistics (updated in place) */
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  void* z;                  /* bf16 [M][U]  pre-BatchNorm, kept for backward */
+  void* a;                  /* bf16 [M][U]  relu(bn(z)) */
+  float* stats;             /* f32 [3][U] */
+  float* sc;                /* f32 [M][2 U] workspace of the first two products */
+  void* t;                  /* bf16 [M][U] */
+  void* out;                /* bf16 [M][U] */
+  const float* ln_gamma;
+  const float* ln_beta;
+  float* ln_stats;          /* f32 [M][2] */
+  const void* dtt;          /* bf16 [M][U] */
+  void* dz;                 /* bf16 [M][U] */
+  float* dxs;               /* forward: f32 [M][U] = a W2^T; backward: f32 [M][Fin + U] */
+  const void* dres;         /* bf16 [M][Fin] or NULL: added to dx (the prior discriminator's gradient w.r.t. the same features) */
+  void* dx;                 /* bf16 [M][Fin] */
+  float* dgamma;            /* f32 [U], +=; any of the four may be NULL */
+  float* dbeta;
+  float* db2;
+  float* dbs;
+} clite_mi_block;
+int clite_mi_block_fwd1(const clite_mi_block* p, void* stream);
+int clite_mi_block_fwd2(const clite_mi_block* p, void* stream);
+int clite_mi_block_bwd1(const clite_mi_block* p, void* stream);
+int clite_mi_block_bwd2(const clite_mi_block* p, void* stream);
+
 /* nn.MaxPool2d(3, stride 2, padding 1) of the ResNet stem; idx holds the window position (0..8) of the first maximum. */
 int clite_maxpool3x3s2_fwd(int dtype, const void* x, void* out, uint8_t* idx, int N, int H, int W, int C, void* stream);
 int clite_maxpool3x3s2_bwd(int dtype, const void* dout, const uint8_t* idx, void* dx, int N, int H, int W, int C, void* stream);

@@ -397,3 +397,75 @@ def test_folded_batchnorm_backward_matches_torch_bn_backward_then_conv_backward(
         assert _rel(dw, dW_ref) < 2e-3, _rel(dw, dW_ref)
     finally:
         hip.set_tile_policy(0)
+
+
+@pytest.mark.parametrize("B,Fin,U", [(128, 2048, 2048), (128, 768, 2048), (6, 512, 2048), (37, 768, 256)])
+def test_fused_mi_block_matches_torch_fp32(B, Fin, U):
+    """clite_mi_block_fwd1/2 + _bwd1/2 (ABI v12; csrc/heads_fused.hip) through loss.mi_block_forward / mi_block_backward: the MI projection block of reference
+    loss.py:12-40 — LayerNorm(W2 relu(BatchNorm1d(W1 x)) + b2 + Ws x + bs) — in bf16 against a plain torch fp32 evaluation on the bf16-rounded weights and
+    input: output within 2e-2 of max (the block is three bf16 roundings deep), input gradient within 3e-2, BatchNorm1d running statistics after the
+    reference's TWO updates per step within 5e-3 / 2e-3, and every parameter gradient — weights through the grouped launch, BatchNorm1d / LayerNorm / both
+    bias gradients from the fused kernels — cosine >= 0.999 against autograd. Also: the fused path really ran (no clite_bn_apply launch)."""
+    from clip_lite_amd import hip as H
+    from clip_lite_amd.loss import MILinearBlock, mi_block_backward, mi_block_forward
+    from clip_lite_amd.runtime import DeviceRuntime
+    torch.manual_seed(B + Fin)
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.loss = torch.nn.Module()
+            self.loss.blk = MILinearBlock(Fin, U)
+    Mh = Holder()
+    with torch.no_grad():
+        Mh.loss.blk.feature_shortcut.weight.copy_(torch.randn(U, Fin) * 0.03)
+        Mh.loss.blk.feature_nonlinear[1].weight.copy_(torch.rand(U) + 0.5)
+        Mh.loss.blk.feature_nonlinear[1].bias.copy_(torch.randn(U) * 0.1)
+    Mh.cuda()
+    rt = DeviceRuntime(Mh, torch.device("cuda", torch.cuda.current_device()), lowp=True)
+    blk = Mh.loss.blk
+    assert rt.fused_heads
+    x = torch.randn(B, Fin, device="cuda").bfloat16()
+    dout = (torch.randn(B, U, device="cuda") * 0.1).bfloat16()
+    dres = (torch.randn(B, Fin, device="cuda") * 0.1).bfloat16()
+    calls = []
+    orig = H.bn_apply
+    H.bn_apply = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out, ctx = mi_block_forward(rt, blk, x, True, updates=2)
+    finally:
+        H.bn_apply = orig
+    assert not calls
+    grp = H.WgradGroup(H.BF16)
+    dx = mi_block_backward(rt, blk, ctx, dout, dres, defer=grp)
+    grp.launch()
+    torch.cuda.synchronize()
+    # reference: torch modules in fp32 on the bf16-rounded weights
+    l1, bn, _, l2 = blk.feature_nonlinear
+    r = lambda p_: p_.detach().float().bfloat16().float().requires_grad_(True)
+    w1, w2, ws = r(l1.weight), r(l2.weight), r(blk.feature_shortcut.weight)
+    g_, b_ = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    b2, bs = l2.bias.detach().clone().requires_grad_(True), blk.feature_shortcut.bias.detach().clone().requires_grad_(True)
+    lw, lb = blk.feature_block_ln.weight.detach().clone().requires_grad_(True), blk.feature_block_ln.bias.detach().clone().requires_grad_(True)
+    xf = x.float().requires_grad_(True)
+    z = xf @ w1.t()
+    mean, var = z.mean(0), z.var(0, unbiased=False)
+    a = torch.relu((z - mean) * torch.rsqrt(var + bn.eps) * g_ + b_)
+    t = a @ w2.t() + b2 + xf @ ws.t() + bs
+    ref = F.layer_norm(t, (U,), lw, lb, 1e-5)
+    ref.backward(dout.float())
+    assert _rel(out, ref.detach()) < 2e-2
+    assert _rel(dx, xf.grad + dres.float()) < 3e-2
+    unb = var.detach() * B / max(B - 1, 1)
+    rm, rv = torch.zeros(U, device="cuda"), torch.ones(U, device="cuda")
+    for _ in range(2):
+        rm, rv = 0.9 * rm + 0.1 * mean.detach(), 0.9 * rv + 0.1 * unb
+    assert _rel(bn.running_mean, rm) < 5e-3 and _rel(bn.running_var, rv) < 2e-3          # (statistics of the bf16-STORED z, like the unfused path's)
+    A = rt.arena
+    for name, p_, want in (("w1", l1.weight, w1.grad), ("w2", l2.weight, w2.grad), ("ws", blk.feature_shortcut.weight, ws.grad), ("gamma", bn.weight, g_.grad),
+                           ("beta", bn.bias, b_.grad), ("b2", l2.bias, b2.grad), ("bs", blk.feature_shortcut.bias, bs.grad),
+                           ("ln.w", blk.feature_block_ln.weight, lw.grad), ("ln.b", blk.feature_block_ln.bias, lb.grad)):
+        got = A.g(p_).flatten().float()
+        cos = (got @ want.flatten() / (got.norm() * want.norm()).clamp_min(1e-20)).item()
+        assert cos >= 0.999, (name, cos)
+        assert abs(got.norm().item() / want.norm().item() - 1) < 2e-2, (name, got.norm().item(), want.norm().item())

@@ -578,3 +578,75 @@ def test_sum_slices_fixed_order():
     assert np.array_equal(dst[:n], ref) and not dst[n:].any()
     assert L.clite_sum_slices(ptr(src), W, stride + 1, n, ptr(dst), None) == -1        # stride must keep the 16-byte alignment of every slice
 
+
+
+class MiBlock(C.Structure):      # include/clite.h: clite_mi_block
+    _fields_ = [("M", C.c_int32), ("Fin", C.c_int32), ("U", C.c_int32), ("updates", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("ln_eps", C.c_float),
+                ("reserved", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("bs", "b2", "gamma", "beta", "running_mean", "running_var", "z", "a", "stats", "sc", "t", "out", "ln_gamma", "ln_beta",
+                                          "ln_stats", "dtt", "dz", "dxs", "dres", "dx", "dgamma", "dbeta", "db2", "dbs")]
+
+
+@pytest.mark.parametrize("M,Fin,U", [(128, 64, 96), (37, 48, 4096), (5, 32, 2064)])
+def test_mi_block_kernels_around_the_products(M, Fin, U):
+    """clite_mi_block_fwd1 / fwd2 / bwd1 / bwd2 (csrc/heads_fused.hip): everything of reference loss.py:12-40's MI block that is not a GEMM, given the f32
+    products in the workspaces — bf16 z / a / t / out / dz / dx against numpy on the same workspaces (1e-2 of max: one bf16 rounding), the BatchNorm1d sums and
+    the running statistics after two updates (unbiased variance), LayerNorm statistics, and the four parameter-gradient accumulations (+= onto ones)."""
+    rng = np.random.default_rng(M + U)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    L = lib()
+    for n in ("fwd1", "fwd2", "bwd1", "bwd2"):
+        getattr(L, "clite_mi_block_" + n).argtypes = [C.c_void_p, C.c_void_p]
+    ws1, ws2 = f(M, 2 * U) * 1.3 + 0.2, f(M, U)
+    gamma, beta, b2, bs = 1 + 0.1 * f(U), 0.1 * f(U), 0.1 * f(U), 0.1 * f(U)
+    lg, lb = 1 + 0.1 * f(U), 0.1 * f(U)
+    rm, rv = np.zeros(U, np.float32), np.ones(U, np.float32)
+    z, a, t, out = (outbuf((M, U), BF16) for _ in range(4))
+    stats = np.full(3 * U, 7.0, np.float32)
+    lst = np.zeros((M, 2), np.float32)
+    b = MiBlock(M=M, Fin=Fin, U=U, updates=2, momentum=0.1, eps=1e-5, ln_eps=1e-5)
+    for k, v in dict(bs=bs, b2=b2, gamma=gamma, beta=beta, running_mean=rm, running_var=rv, z=z, a=a, stats=stats, sc=ws1, t=t, out=out, ln_gamma=lg, ln_beta=lb,
+                     ln_stats=lst, dxs=ws2).items():
+        setattr(b, k, ptr(v))
+    assert L.clite_mi_block_fwd1(C.byref(b), None) == 0
+    assert L.clite_mi_block_fwd2(C.byref(b), None) == 0
+    from simlib import bf16_round
+    zr = bf16_round(ws1[:, :U])
+    assert np.array_equal(val(z, BF16), zr)
+    mean, var = zr.mean(0), zr.var(0)
+    _close(stats[:U], zr.sum(0), 1e-5); _close(stats[U:2 * U], (zr * zr).sum(0), 1e-5)
+    assert not stats[2 * U:].any()
+    ar = np.maximum((zr - mean) / np.sqrt(var + 1e-5) * gamma + beta, 0)
+    _close(val(a, BF16), ar, 1e-2)
+    unb = var * (M / (M - 1))
+    _close(rm, 0.19 * mean, 1e-4); _close(rv, 0.81 + 0.19 * unb, 1e-4)
+    tr = bf16_round(ws2 + b2 + ws1[:, U:] + bs)
+    _close(val(t, BF16), tr, 1e-2)
+    tv = val(t, BF16)
+    mu, rs = tv.mean(1), 1 / np.sqrt(tv.var(1) + 1e-5)
+    _close(lst[:, 0], mu, 1e-4); _close(lst[:, 1], rs, 1e-4)
+    _close(val(out, BF16), (tv - mu[:, None]) * rs[:, None] * lg + lb, 1e-2)
+    # backward
+    ws3 = f(M, Fin + U)
+    dtt, dttb = prep(f(M, U), BF16)
+    dres, dresb = prep(f(M, Fin), BF16)
+    dz, dx = outbuf((M, U), BF16), outbuf((M, Fin), BF16)
+    dg, dbt, db2, dbs = (np.ones(U, np.float32) for _ in range(4))
+    for k, v in dict(dtt=dttb, dz=dz, dxs=ws3, dres=dresb, dx=dx, dgamma=dg, dbeta=dbt, db2=db2, dbs=dbs).items():
+        setattr(b, k, ptr(v))
+    b.updates = 0
+    assert L.clite_mi_block_bwd1(C.byref(b), None) == 0
+    assert L.clite_mi_block_bwd2(C.byref(b), None) == 0
+    av = val(a, BF16)
+    d = np.where(av > 0, ws3[:, Fin:], 0)
+    rstd = 1 / np.sqrt(var + 1e-5)
+    xh = (zr - mean) * rstd
+    _close(dbt, 1 + d.sum(0), 1e-4); _close(dg, 1 + (d * xh).sum(0), 1e-3)
+    _close(db2, 1 + dtt.sum(0), 1e-4); assert np.array_equal(db2, dbs)
+    _close(val(dz, BF16), gamma * rstd * (d - d.mean(0) - xh * (d * xh).mean(0)), 1e-2)
+    _close(val(dx, BF16), ws3[:, :Fin] + dres, 1e-2)
+    # shapes the kernels do not take
+    b.M = 129
+    assert L.clite_mi_block_fwd1(C.byref(b), None) == -1
+    b.M, b.U = M, 4112
+    assert L.clite_mi_block_fwd2(C.byref(b), None) == -1
