@@ -187,21 +187,31 @@ def test_checkpoint_resume_equivalence_fast_mode(tmp_path):
     4-sample BatchNorms amplify the switched gradient ~10x per step (tools/diag_ragged_fwd.py; observed once: 2.4e-2 on the momentum arena).
     Round 2 answered that with a blanket 25x looser bound, which a small real restore bug would also have passed. Instead the
     whole save / restore / continue experiment is repeated three times and every tensor is judged by the MEDIAN of its three errors at the
-    tight bound: a kink event is one outlier in one repeat; a restore that misses state is wrong in all three."""
+    tight bound: a kink event is an outlier in a minority of the repeats; a restore that misses state is wrong in all of them."""
     errs = {}
-    for rep in range(3):
+
+    def judge():
+        bad, events = [], 0
+        for k, es in errs.items():
+            tol = 1e-2 if k == "__momentum__" else 2e-3
+            rel = sorted(e / sc for e, sc in es)
+            events += rel[-1] > tol >= rel[len(rel) // 2]
+            if rel[len(rel) // 2] > tol:
+                bad.append((k, rel))
+        return bad, events
+
+    # three repeats; two more when the median of three fails (round 5: one full-suite run on a fresh box had the SAME event, 2.426e-2 on the momentum arena,
+    # in two of its three repeats, and none in the 15 repeats of the next five runs: events cluster within a process, so the verdict of a failing triple is taken
+    # from five)
+    for rep in range(5):
         d = tmp_path / f"rep{rep}"
         d.mkdir()
         want, got = _resume_problem(d, False)
         for k in want:
             errs.setdefault(k, []).append(((got[k] - want[k]).norm().item(), max(want[k].norm().item(), 1e-3)))
-    bad, events = [], 0
-    for k, es in errs.items():
-        tol = 1e-2 if k == "__momentum__" else 2e-3
-        rel = sorted(e / sc for e, sc in es)
-        events += rel[2] > tol >= rel[1]
-        if rel[1] > tol:
-            bad.append((k, rel))
+        if rep == 2 and not judge()[0]:
+            break
+    bad, events = judge()
     print(f"{events} tensors had one repeat beyond the tight bound (ReLU-kink events)")
     assert not bad, bad[:5]
 
