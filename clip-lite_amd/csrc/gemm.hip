@@ -162,6 +162,11 @@ int colstats_det(const clite_epilogue& ep, const RowMap& rm, int M, int N, hipSt
 
 // Split-bf16 form of the exact-f32 mode's MFMA loops (igemm_dma.h split_bf16x3): process-wide switch like the deterministic mode
 static std::atomic<int> g_f32_split{0};
+#ifdef CLITE_PROBE_AFRAG
+// probe builds (tools/probe_afrag.py): scale / shift of a BatchNorm applied to the A fragments of the next persistent 1 x 1 forward launches
+static const float* g_probe_aff[2] = {nullptr, nullptr};
+extern "C" void clite_probe_set_affine(const float* scale, const float* shift) { g_probe_aff[0] = scale; g_probe_aff[1] = shift; }
+#endif
 bool f32_split() { return g_f32_split.load(std::memory_order_relaxed) != 0; }
 
 template <typename T, class CFG, class LA, class LB>
@@ -257,6 +262,13 @@ int launch(const LA& la, const LB& lb, const clite_epilogue& ep, int M, int N, i
         int rows_per_wg = ((M + slices - 1) / slices + 7) & ~7;
         if (rows_per_wg < CFG::BM) rows_per_wg = CFG::BM;
         slices = (M + rows_per_wg - 1) / rows_per_wg;
+#ifdef CLITE_PROBE_AFRAG
+        if (g_probe_aff[0] && ktiles * CFG::BK <= 512) {
+          hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 4, false, false, true>), dim3(slices * tiles_n), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep,
+                             rm, M, N, ktiles, rows_per_wg, g_probe_aff[0], g_probe_aff[1]);
+          return (int)hipGetLastError();
+        }
+#endif
         hipLaunchKernelGGL((igemm_dma_bn_kernel<T, CFG, DA, DB, 4>), dim3(slices * tiles_n), dim3(256), 0, st, ToDma<LA>::make(la), ToDma<LB>::make(lb), ep, rm, M, N, ktiles,
                            rows_per_wg, nullptr, nullptr);
         return (int)hipGetLastError();

@@ -504,7 +504,11 @@ DEV int fp8_frag_off64(int x0, int half, int lane) {
 // F8 (clite_conv_dgrad_fp8): T stays bf16 (the epilogue's tensors), the operands are one-byte images - A = the gradient in e5m2, B = the transposed
 // weights in e4m3 - multiplied by the block-scaled instruction at unit scales; the accumulators are de-quantised (f8_a[1] * f8_b[1], the inverse
 // per-tensor scales) before the epilogue, which is the bf16 kernel's.
-template <typename T, class CFG, class LA, class LB, int FORM = 0, bool SPLIT = false, bool F8 = false>
+// AFF (probe builds only, -DCLITE_PROBE_AFRAG; tools/probe_afrag.py): the A operand is a raw convolution output and relu(a * scale[k] + shift[k]) — the
+// BatchNorm in front of a 1 x 1 convolution — is applied to each A fragment between the LDS read and the MFMA; f8_a / f8_b carry scale / shift (f32 [K]),
+// staged once per workgroup behind the operand ring. A lane's fragment holds 8 consecutive k of one row, so each k-step reads 8 + 8 coefficients (two
+// half-wave broadcast reads each).
+template <typename T, class CFG, class LA, class LB, int FORM = 0, bool SPLIT = false, bool F8 = false, bool AFF = false>
 __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dma_bn_kernel(LA la, LB lb, Epilogue ep, RowMap rm, int M, int N, int ktiles, int rows_per_wg,
                                                                                             const float* f8_a, const float* f8_b) {
   constexpr int BM = CFG::BM, BN = CFG::BN, BK = CFG::BK;
@@ -517,9 +521,12 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
   constexpr int EPIB = (CFG::BM / ((FORM && CLITE_BN_HALF) ? 2 : 1)) * CFG::EPI_PITCH;      // the epilogue stages the whole tile, or half of it at a time (igemm_epilogue_bn NP)
   constexpr int RED = (256 / (CFG::BN / 8)) * (CFG::BN / 8) * 16 * 4;      // bn_epi_finish's fold image
   constexpr int SMEM0 = (NSTAGE * STAGE > EPIB) ? NSTAGE * STAGE : EPIB;
-  constexpr int SMEM = SMEM0 > RED ? SMEM0 : RED;
+  constexpr int SMEM1 = SMEM0 > RED ? SMEM0 : RED;
+  constexpr int AFFB = AFF ? 2 * 512 * 4 : 0;                 // scale | shift of up to 512 input channels
+  constexpr int SMEM = SMEM1 + AFFB;
   constexpr int LOADS_PER_TILE = LA::NI + LB::NI;            // per wave
   static_assert(sizeof(T) == 2 || sizeof(T) == 4, "bf16 or f32");
+  static_assert(!AFF || (sizeof(T) == 2 && !F8), "fragment-side affine: bf16 operands");
   // (Measured and rejected, round 3: touching every 128-byte line of the tile's BatchNorm-input / residual rows by LDS-DMA into a scratch at
   // the start of the tile, so that the epilogue's loads hit L2 — same-box A/B 16.99 -> 17.20 ms: the extra requests compete with the
   // operand ring for the same L2 -> CU path that bounds the main loop.)
@@ -564,6 +571,11 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
 #if CLITE_STAMP
   if (tid == 0) { for (int i = 0; i < 7; ++i) clite_ph[i] = 0; clite_ph[7] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+  if constexpr (AFF) {
+    float* tbl = (float*)(smem + SMEM1);
+    for (int k = tid; k < ktiles * BK; k += 256) { tbl[k] = f8_a[k]; tbl[512 + k] = f8_b[k]; }
+    // (the first tile's barrier_raw orders these stores before the first fragment's reads)
+  }
   BnEpiState est;
   bn_epi_begin<CFG>(est, ep, N, n0, tid);
   PHASE(0);          // launch prologue: addresses, BatchNorm means
@@ -640,6 +652,17 @@ __global__ __launch_bounds__(256, (FORM && CLITE_BN_HALF) ? 3 : 2) void igemm_dm
           for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
 #pragma unroll
           for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
+          if constexpr (AFF) {
+            const float* sc = (const float*)(smem + SMEM1) + t * BK + (ks * 2 + (lane >> 5)) * 8;
+            const f32x4 s0 = *(const f32x4*)sc, s1 = *(const f32x4*)(sc + 4), h0 = *(const f32x4*)(sc + 512), h1 = *(const f32x4*)(sc + 516);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float v = fmaf(bf2f(af[i][e]), e < 4 ? s0[e & 3] : s1[e & 3], e < 4 ? h0[e & 3] : h1[e & 3]);
+                af[i][e] = f2bf(fmaxf(v, 0.f));
+              }
+          }
 #pragma unroll
           for (int i = 0; i < RM; ++i)
 #pragma unroll
