@@ -631,29 +631,38 @@ __global__ __launch_bounds__(512) void igemm_wide_kernel(LA la, LB lb, Epilogue 
   for (int t = t_begin; t < t_end; ++t) {
     // tile t has landed once at most min(NSTAGE-2, tiles after t) younger tiles are still outstanding
     const int after = t_end - 1 - t;
-    if (NSTAGE >= 3 && after >= 1) wait_vmcnt<LOADS_PER_TILE>();
+    if (NSTAGE >= 4 && after >= 2) wait_vmcnt<2 * LOADS_PER_TILE>();
+    else if (NSTAGE >= 3 && after >= 1) wait_vmcnt<LOADS_PER_TILE>();
     else wait_vmcnt<0>();
     barrier_raw();            // everyone's part of tile t has landed; everyone is done reading the buffer tile t+NSTAGE-1 overwrites
     const char* abuf = smem + buf * STAGE;
     const char* bbuf = abuf + LA::BYTES;
     // first k-step's fragment reads go out before the next tile's DMA is issued (the issue overlaps the LDS latency)
+    // (diagnostic variants, `make variant VAR_EXTRA=-DCLITE_ABLATE=n`, tools/probe_rows768.py, profiles/r5_wide_ablation.txt: 1 = no fragment reads / MFMAs (the
+    // memory side alone), 2 = no DMA (reads + MFMAs + barriers), 3 = neither DMA nor fragment reads (MFMAs + barriers). Round 5, 3840 x 768 x 3072 on the
+    // 128 x 128 tile: whole 32.5 us, 1: 22.8, 2: 24.9, 3: 23.2 — two sides of equal length that overlap to 70 %; the MFMA side is the matrix pipe itself
+    // (53 cycles per 32x32x16 instruction with two waves per SIMD), the memory side one CU's LDS-DMA ingest (86 GB/s, the same with 90 tiles as with 180).
+    // Tried on top of that and removed: a 4-stage ring (32.2 us); fragments of k-step s + 1 read under the MFMAs of k-step s across the tile boundary, with
+    // the compiler's waits (33.0) and with hand-counted s_waitcnt lgkmcnt on untracked reads (32.1; compute side alone 23.9) — and +0.15 ms in the step.)
     bf16x8 af0[RM], bf0[RN];
 #pragma unroll
     for (int i = 0; i < RM; ++i) af0[i] = LA::frag_at(abuf + aoff[i][0]);
 #pragma unroll
     for (int j = 0; j < RN; ++j) bf0[j] = LB::frag_at(bbuf + boff[j][0]);
+#if CLITE_ABLATE != 2 && CLITE_ABLATE != 3
     if (t + NSTAGE - 1 < t_end) {
       int nb = buf + NSTAGE - 1; if (nb >= NSTAGE) nb -= NSTAGE;
       WideIssue<LA>::go(la, sa, smem + nb * STAGE, wave, lane, m0);
       WideIssue<LB>::go(lb, sb, smem + nb * STAGE + LA::BYTES, wave, lane, n0);
     }
+#endif
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int ks = 0; ks < (CLITE_ABLATE == 1 ? 0 : KS); ++ks) {
       bf16x8 af[RM], bfr[RN];
 #pragma unroll
-      for (int i = 0; i < RM; ++i) af[i] = ks == 0 ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
+      for (int i = 0; i < RM; ++i) af[i] = (ks == 0 || CLITE_ABLATE == 3) ? af0[i] : LA::frag_at(abuf + aoff[i][ks]);
 #pragma unroll
-      for (int j = 0; j < RN; ++j) bfr[j] = ks == 0 ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
+      for (int j = 0; j < RN; ++j) bfr[j] = (ks == 0 || CLITE_ABLATE == 3) ? bf0[j] : LB::frag_at(bbuf + boff[j][ks]);
 #pragma unroll
       for (int i = 0; i < RM; ++i)
 #pragma unroll
