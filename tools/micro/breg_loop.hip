@@ -1,7 +1,8 @@
 // Microbenchmark (round 5): does the WEIGHT operand of a 128 x 128 x 64 tile cost less when it goes from L2 straight into registers (global_load_dwordx4 in
 // the MFMA fragment pattern: lane l reads 16 B = 8 k of column l & 31) than through the LDS-DMA ring beside the activation operand? Memory side only (no
 // LDS reads, no MFMAs), 8 waves, 128-byte K rows, 3 stages, counted vmcnt, one barrier per K tile — csrc/igemm_wide.h's W128 loop.
-//   mode 0: A and B by `buffer_load ... lds` (the product)      mode 1: A by LDS-DMA, B by register loads two tiles ahead      mode 2: A alone
+//   mode 0: A and B by `buffer_load ... lds` (the product)      mode 1: A by LDS-DMA, B by register loads two tiles ahead      mode 2: A alone      mode 3: B alone
+// Each shape twice: dense rows (pitch = 2 K bytes) and rows padded by 128 bytes (is the 24 x 256-byte pitch of K = 3072 a channel-aliasing problem?)
 // Build on the GPU box: hipcc --offload-arch=gfx950 -O3 tools/micro/breg_loop.hip -o tools/micro/breg_loop
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -37,16 +38,18 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* A, uint32_t abyte
   const char* bp[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) bp[j] = B + (size_t)(tn * BN + wn * 64 + 32 * j + (lane & 31)) * pitch + (kg * 2 * 16 + (lane >> 5) * 8) * 2;
-  constexpr int LPT = MODE == 0 ? NA + NB : (MODE == 1 ? NA + 4 : NA);          // loads per wave per tile
+  constexpr int LPT = MODE == 0 ? NA + NB : (MODE == 1 ? NA + 4 : (MODE == 2 ? NA : NB));          // loads per wave per tile
   u32x4 r[3][4];
   uint32_t acc = 0;
   int kcur = 0;
   auto issue = [&](int buf, u32x4 (&rr)[4]) {
     char* base = lds + buf * STAGE;
     const uint32_t kb = (uint32_t)kcur * RB;
+    if (MODE != 3) {
 #pragma unroll
-    for (int j = 0; j < NA; ++j) dma16(ra, offa[j] + kb, base + (wave * NA + j) * 1024);
-    if (MODE == 0) {
+      for (int j = 0; j < NA; ++j) dma16(ra, offa[j] + kb, base + (wave * NA + j) * 1024);
+    }
+    if (MODE == 0 || MODE == 3) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) dma16(rb, offb[j] + kb, base + BM * RB + (wave * NB + j) * 1024);
     } else if (MODE == 1) {
@@ -75,8 +78,8 @@ __global__ __launch_bounds__(512) void loop_kernel(const char* A, uint32_t abyte
 }
 
 template <int MODE>
-void run(char* A, char* B, int M, int N, int K, int* sink) {
-  int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128, tiles = tiles_m * tiles_n, ktiles = K * 2 / 128, pitch = K * 2;
+void run(char* A, char* B, int M, int N, int K, int* sink, int pad) {
+  int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128, tiles = tiles_m * tiles_n, ktiles = K * 2 / 128, pitch = K * 2 + pad;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 2; ++rep) {
     hipEventRecord(e0);
@@ -85,7 +88,7 @@ void run(char* A, char* B, int M, int N, int K, int* sink) {
     hipEventRecord(e1); hipEventSynchronize(e1);
   }
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
-  printf("  mode %d: tiles %4d  k tiles %3d  %7.1f us  (%5.3f us per K tile)\n", MODE, tiles, ktiles, ms * 1e3, ms * 1e3 / ktiles);
+  printf("  mode %d pitch %5d: tiles %4d  k tiles %3d  %7.1f us  (%5.3f us per K tile)\n", MODE, pitch, tiles, ktiles, ms * 1e3, ms * 1e3 / ktiles);
 }
 
 int main() {
@@ -94,9 +97,12 @@ int main() {
   int shapes[][3] = {{3840, 768, 3072}, {1920, 768, 3072}, {3840, 768, 768}, {3840, 768, 2304}};
   for (auto& s : shapes) {
     printf("M=%d N=%d K=%d (memory side of the 128 x 128 x 64 tile loop, 8 waves, 3 stages)\n", s[0], s[1], s[2]);
-    run<0>(A, B, s[0], s[1], s[2], sink);
-    run<1>(A, B, s[0], s[1], s[2], sink);
-    run<2>(A, B, s[0], s[1], s[2], sink);
+    for (int pad = 0; pad <= 128; pad += 128) {
+      run<0>(A, B, s[0], s[1], s[2], sink, pad);
+      run<1>(A, B, s[0], s[1], s[2], sink, pad);
+      run<2>(A, B, s[0], s[1], s[2], sink, pad);
+      run<3>(A, B, s[0], s[1], s[2], sink, pad);
+    }
   }
   return 0;
 }
