@@ -345,25 +345,22 @@ class TrainStep:
                 capture("heads_m2", pool_main, heads_m2)
                 for i, tg in enumerate(tsegs):
                     capture("text_bwd" if nts == 1 else "text_bwd_" + tg, pool_side, text_bwd(i))
-                # Which stream replays a segment's grouped weight gradients: the side stream (behind BERT's backward) by default, the main stream (behind
-                # the whole chain) for the segments in `wgrad_main` ("1", "0,1": tools/ab_runtime.py step.wgrad_main=1) — always the last one. Measured with
-                # the folded BatchNorm backward (which shortens the chain): layer2's group on the main stream 15.03 ms against 14.86 on the side stream,
-                # same box — whatever runs beside the chain slows it by about what the move gains; the default stays the side stream.
-                on_main = self._wgrad_on_main = sorted(set(int(x) for x in str(getattr(self, "wgrad_main", "")).split(",") if x != "" and int(x) < len(segs) - 1) | {len(segs) - 1})
+                # Which stream replays a segment's grouped weight gradients: the side stream (behind BERT's backward) for every segment but the last, whose group
+                # follows the chain on the main stream. (Round 5 built a switch that moved earlier segments' groups behind the whole chain: layer2's group there
+                # cost 15.03 against 14.86 ms, and 14.94 against 14.59 in alternating order — whatever runs beside the chain slows it by less than the move
+                # costs; the switch is gone. A third stream for the early groups: 14.88 against 14.72. The last segment's stand-alone launches on the main
+                # stream instead of the side stream: no difference. DESIGN.md sections 0 and 8.)
+                last = len(segs) - 1
                 for i, sg in enumerate(segs):
                     capture("image_bwd_" + sg, pool_main, image_bwd(i))
                     if i == 0 and (keep["wg_h"].items or keep["wg_h"].extra):          # (never an empty capture: the A/B switch defer_head_wgrads=0 leaves the group empty)
                         capture("wgrad_heads", pool_side, wgrad_heads)          # (capture order = replay order on a stream: shared pool)
-                    if i not in on_main:
+                    if i != last:
                         capture("wgrad_" + sg, pool_side, wgrad(i))
-                for i in on_main:          # behind the chain, in segment order
-                    capture("wgrad_" + segs[i], pool_main, wgrad(i))
-                # the last segment's stand-alone launches (bn1's backward + conv1's weight gradient, 0.2 ms): beside the last group on the side stream, or
-                # behind it on the main stream (extras_on_main) - whichever stream ends earlier (round 5: the folded BatchNorm backward shortened the main
-                # stream's chain; same-box A/B in DESIGN.md section 5)
-                self._extras_main = bool(getattr(self, "extras_on_main", False))
+                capture("wgrad_" + segs[last], pool_main, wgrad(last))          # behind the chain
+                # the last segment's stand-alone launches (bn1's backward + conv1's weight gradient, 0.2 ms): beside the last group, on the side stream
                 if keep["wg_" + segs[-1]].extra:
-                    capture("wgrad_last_extras", pool_main if self._extras_main else pool_side, wgrad_last_extras)
+                    capture("wgrad_last_extras", pool_side, wgrad_last_extras)
                 if self.clip and self.clip > 0:          # (without clipping there is no norm: an empty capture is not worth finding out about)
                     capture("norm_early", pool_main, norm_early)
                 capture("norm", pool_main, norm)
@@ -441,9 +438,8 @@ class TrainStep:
                     if ex is not None:
                         self._hand(span, side)
         G["heads_m2"].replay()                     # image block backward, beside it
-        on_main = self._wgrad_on_main
         ev_early = None
-        for i, sg in enumerate(self._segs[:-1]):   # a segment's weight gradients go to the side stream as soon as its chain is enqueued (or wait for the chain's end: on_main)
+        for i, sg in enumerate(self._segs[:-1]):   # a segment's weight gradients go to the side stream as soon as its chain is enqueued
             G["image_bwd_" + sg].replay()
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -454,23 +450,17 @@ class TrainStep:
                         G["wgrad_heads"].replay()
                     if ex is not None:
                         self._hand(self._regions["loss"], side)
-                if i not in on_main:
-                    G["wgrad_" + sg].replay()
+                G["wgrad_" + sg].replay()
                 if i == 0:
-                    ev_early = side.record_event()          # text encoder, loss heads (+ layer3 / layer4 unless on_main): the side stream's share of the norm's early spans
-            if ex is not None and i not in on_main:   # BatchNorm gradients came with the chain (main), weight gradients with the group (side, which waited for main)
+                    ev_early = side.record_event()          # text encoder, loss heads, layer3 / layer4: the side stream's share of the norm's early spans
+            if ex is not None:   # BatchNorm gradients came with the chain (main), weight gradients with the group (side, which waited for main)
                 self._hand(self._seg_spans[i], side)
         G["image_bwd_" + self._segs[-1]].replay()
         side.wait_stream(main)
-        if "wgrad_last_extras" in G and not self._extras_main:
+        if "wgrad_last_extras" in G:
             with torch.cuda.stream(side):
                 G["wgrad_last_extras"].replay()    # bn1's backward + the stem's weight gradient, beside ...
-        for i in on_main:                          # ... the grouped launches behind the chain
-            G["wgrad_" + self._segs[i]].replay()
-            if ex is not None and i < len(self._segs) - 1:
-                self._hand(self._seg_spans[i], main)
-        if "wgrad_last_extras" in G and self._extras_main:
-            G["wgrad_last_extras"].replay()
+        G["wgrad_" + self._segs[-1]].replay()      # ... the last grouped launch behind the chain
         early_done = ex is None and getattr(self, "norm_overlap", True) and "norm_early" in G
         if early_done:
             main.wait_event(ev_early)
